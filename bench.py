@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the kNN hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: 1024 cosine queries (k=10) against the
+10M x 768 fp32 corpus of EHX-GAUSS-1 (include/ehx_datagen.h), resident in HBM.  With N > 1
+(launched by torch.distributed.run, one rank per GPU over RCCL) the corpus is row-sharded —
+rank r holds rows [r*N/G, (r+1)*N/G) — every rank scans its shard for the same query batch,
+the local top-k lists are all-gathered over xGMI and merged on every rank (strong scaling:
+the total index is fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the scan
+kernel (matrix-core bound) and `cpu_baseline` (the oracle = restated hnswlib, on the host cores,
+on a bounded sample of the same workload; N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+METRIC_NAME = "kNN queries/sec at recall@10>=0.95, 10Mx768 cosine, batch=1024"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="total corpus rows (all GPUs)")
+    ap.add_argument("--dims", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=6000)
+    ap.add_argument("--cpu-sample-queries", type=int, default=256)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle (restated hnswlib, SSE order) on the host cores, bounded sample of the workload:
+    sequential HNSW build (M=16, efC=200, seed=100 — the reference's defaults) over the first
+    S corpus rows, then batched search at the smallest ef reaching recall@10 >= 0.95 against the
+    oracle's own exhaustive search over the same S rows."""
+    import numpy as np
+    from oracle import pyoracle
+    cores = os.cpu_count() or 1
+    S, nq, d, k = args.cpu_sample_rows, args.cpu_sample_queries, args.dims, args.k
+    X = pyoracle.gen_rows(20250211, 0, S, d, normalize=True)
+    Q = pyoracle.gen_rows(20250212, 0, nq, d, normalize=True)
+    truth, _, _, ex_sec = pyoracle.exhaustive(X, Q, k, pyoracle.METRIC_COSINE, threads=cores, return_time=True)
+    h = pyoracle.Hnsw(d, pyoracle.METRIC_COSINE, S)
+    build_sec = h.add_rows(X)
+    best = None
+    for ef in (10, 20, 40, 80, 160, 320, 640, 1280, 2560):
+        h.set_ef(ef)
+        labels, _, _, sec, st = h.search_batch(Q, k, threads=cores)
+        recall = float(np.mean([len(set(labels[i]) & set(truth[i])) / k for i in range(nq)]))
+        best = dict(ef=ef, recall=recall, qps=nq / sec, n_dist=st["n_dist"] / nq, n_hops=(st["n_hops0"] + st["n_hops_up"]) / nq)
+        if recall >= 0.95:
+            break
+    h.set_ef(best["ef"])
+    for _ in range(3):  # best of 3: the first multi-threaded pass after the serial build runs cold
+        _, _, _, sec, _ = h.search_batch(Q, k, threads=cores)
+        best["qps"] = max(best["qps"], nq / sec)
+    for _ in range(2):
+        _, _, _, ex2 = pyoracle.exhaustive(X, Q, k, pyoracle.METRIC_COSINE, threads=cores, return_time=True)
+        ex_sec = min(ex_sec, ex2)
+    _, _, _, sec1, _ = h.search_batch(Q[:64], k, threads=1)
+    return {
+        "value": round(best["qps"], 1), "unit": "queries/s", "cores": cores, "kind": "port",
+        "sample": ("oracle HNSW (M=16, efC=200, sequential build %.1fs) over the first %d of %d corpus rows, %d queries, "
+                   "ef=%d -> recall@10=%.3f, n_dist/query=%.0f; single-thread %.1f q/s; oracle exhaustive scan of the "
+                   "same sample %.1f q/s on %d threads (= %.2e row-distances/s)" % (
+                       build_sec, S, args.rows, nq, best["ef"], best["recall"], best["n_dist"], 64 / sec1,
+                       nq / ex_sec, cores, nq * S / ex_sec)),
+        "ef": best["ef"], "recall_at_10": round(best["recall"], 4),
+        "exhaustive_row_dists_per_s": nq * S / ex_sec,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import embeddinghub_amd as ehx
+    from embeddinghub_amd import _lib
+    L = _lib.load()
+    dev = (C.c_int * 1)(local_rank)
+    _lib.check(L.ehx_init(dev, 1))
+
+    G = world
+    shard = args.rows // G
+    row0 = rank * shard
+    if rank == G - 1:
+        shard = args.rows - row0
+    B, d, k = args.batch, args.dims, args.k
+    t_fill = time.time()
+    space = ehx.Space("bench-r%d" % rank, d, metric=ehx.METRIC_COSINE, initial_capacity=shard)
+    space.fill_synthetic(ehx.SEED_CORPUS, row0, shard, True)
+    torch.cuda.synchronize()
+    t_fill = time.time() - t_fill
+
+    stream = torch.cuda.current_stream().cuda_stream
+    n_batches = args.warmup + args.steps
+    queries = torch.empty((n_batches, B, d), dtype=torch.float32, device="cuda")
+    for i in range(n_batches):  # distinct query batches, resident in HBM before the timed region
+        _lib.check(L.ehx_gen_rows_device(C.c_void_p(stream), ehx.SEED_QUERY, i * B, B, d, 1,
+                                         C.c_void_p(queries[i].data_ptr())))
+    ids = torch.empty((B, k), dtype=torch.int64, device="cuda")
+    dst = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    cnt = torch.empty((B,), dtype=torch.int32, device="cuda")
+    if G > 1:
+        g_ids = torch.empty((G, B, k), dtype=torch.int64, device="cuda")
+        g_dst = torch.empty((G, B, k), dtype=torch.float32, device="cuda")
+        g_cnt = torch.empty((G, B), dtype=torch.int32, device="cuda")
+        m_ids = torch.empty((B, k), dtype=torch.int64, device="cuda")
+        m_dst = torch.empty((B, k), dtype=torch.float32, device="cuda")
+        m_cnt = torch.empty((B,), dtype=torch.int32, device="cuda")
+
+    def step(i):
+        space.knn_device(queries[i], k, ids, dst, cnt, stream=stream)
+        if G > 1:
+            ids.add_(row0)  # local row id -> global id
+            dist.all_gather_into_tensor(g_ids, ids)
+            dist.all_gather_into_tensor(g_dst, dst)
+            dist.all_gather_into_tensor(g_cnt, cnt)
+            _lib.check(L.ehx_merge_topk_device(C.c_void_p(stream), B, k, G, C.c_void_p(g_ids.data_ptr()),
+                                               C.c_void_p(g_dst.data_ptr()), C.c_void_p(g_cnt.data_ptr()),
+                                               C.c_void_p(m_ids.data_ptr()), C.c_void_p(m_dst.data_ptr()),
+                                               C.c_void_p(m_cnt.data_ptr())))
+
+    def barrier():
+        if G > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    space.stats_reset()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if G > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if G > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = space.stats()  # per-launch scan-kernel durations from HIP events on the launch stream
+    scan_ms = st["scan_ms_mean"]
+    flops_per_launch = 2.0 * B * shard * d                    # 2*B*N*d per batch (this shard)
+    achieved = flops_per_launch / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+    out = {
+        "metric": METRIC_NAME, "value": round(args.steps * B / elapsed, 1), "unit": "queries/s",
+        "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "%dx%d cosine (EHX-GAUSS-1 seed %d), batch=%d, k=%d; exhaustive fp32 MFMA scan + "
+                        "canonical re-rank = exact kNN (recall@10 = 1.0 vs exhaustive by construction)" % (
+                            args.rows, d, ehx.SEED_CORPUS, B, k),
+            "rows_total": args.rows, "rows_per_gpu": shard, "dims": d, "batch": B, "k": k, "path": "flat",
+            "parallelism": "row-shard x%d + all-gather top-k merge" % G if G > 1 else "single GPU",
+            "fill_seconds": round(t_fill, 2),
+        },
+        "recall_at_10": 1.0,
+        "roofline": {
+            "bound": "mfma", "kernel": "flat_scan_kernel", "achieved": round(achieved, 2),
+            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+            "traffic": None, "kernel_ms": round(scan_ms, 4), "launches_timed": int(st["scan_launches"]),
+            "flops_per_launch": flops_per_launch,
+            "hbm_frac_of_8TBps": round((shard * d * 4 + B * d * 4 + B * k * 12) / (scan_ms * 1e-3) / 8e12, 4) if scan_ms > 0 else None,
+        },
+        "n_uncertified": int(st["n_uncertified"]),
+    }
+    if rank == 0 and G == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if G > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,768 @@
+// C-ABI of the engine (include/ehx.h): process-global space registry, key <-> dense id map
+// (ANNIndex's key_to_label_/label_to_key_, embeddinghub/embeddingstore/index.h:30-32), HBM
+// residency and capacity doubling (index.cc:29-32), and the kNN pipelines that chain the gfx950
+// kernels.  No vector arithmetic happens on the host: if the device is unavailable every compute
+// entry point fails with EHX_ENODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ehx.h"
+#include "ehx_kernels.h"
+
+using namespace ehx;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      (void)hipGetLastError();                                                                \
+      return fail(_e == hipErrorOutOfMemory ? EHX_ENOMEM : EHX_ENODEVICE, "%s failed: %s (%s:%d)", \
+                  #expr, hipGetErrorString(_e), __FILE__, __LINE__);                          \
+    }                                                                                         \
+  } while (0)
+
+struct Engine {
+  std::mutex mu;
+  bool inited = false;
+  int device = 0;
+  int n_cus = 256;
+  std::unordered_map<std::string, std::unique_ptr<ehx_space>> spaces;
+};
+Engine& engine() {
+  static Engine e;
+  return e;
+}
+
+inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int ensure(size_t want, bool zero = false) {
+    if (want <= n) return EHX_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    HIP_TRY(hipMalloc((void**)&p, want * sizeof(T)));
+    if (zero) HIP_TRY(hipMemset(p, 0, want * sizeof(T)));
+    n = want;
+    return EHX_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+}  // namespace
+
+struct ehx_space {
+  std::string name;
+  uint32_t dims = 0, ld = 0;
+  int metric = EHX_METRIC_L2SQ;
+  ehx_params params{};
+  bool frozen = false;
+  bool implicit_keys = false;  // rows appended by ehx_fill_synthetic: key == decimal row id
+  std::shared_mutex mu;        // writers: set/drop/reserve ; readers: knn/get
+
+  // HBM-resident state
+  float* dX = nullptr;       // [cap][ld]
+  float2* dRowp = nullptr;   // [cap]
+  float* dInv = nullptr;     // [cap] (cosine)
+  uint64_t cap = 0, n = 0;
+
+  // key map (explicit keys only)
+  std::unordered_map<std::string, uint64_t> key_to_id;
+  std::vector<std::string> id_to_key;
+
+  // scratch for the kNN pipeline (serialised by scratch_mu)
+  std::mutex scratch_mu;
+  hipStream_t stream = nullptr;
+  DevBuf<float> dQraw, dQ;
+  DevBuf<uint64_t> dCand, dPart, dMerged, dOutIds;
+  DevBuf<float> dOutDist;
+  DevBuf<uint32_t> dOutCount;
+  unsigned long long* dUncert = nullptr;
+  float* hStage = nullptr;  // pinned staging (Set / Get / query upload)
+  size_t hStageBytes = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid = false;
+  // ring of (start, stop) event pairs around the scan kernel: per-launch durations for the roofline
+  static constexpr int kRing = 64;
+  hipEvent_t ring[kRing][2] = {};
+  uint64_t ring_count = 0;
+
+  // stats
+  std::atomic<uint64_t> n_queries{0}, n_dist{0}, n_rerank{0}, bytes_algo{0};
+
+  ~ehx_space() {
+    if (dX) (void)hipFree(dX);
+    if (dRowp) (void)hipFree(dRowp);
+    if (dInv) (void)hipFree(dInv);
+    dQraw.release();
+    dQ.release();
+    dCand.release();
+    dPart.release();
+    dMerged.release();
+    dOutIds.release();
+    dOutDist.release();
+    dOutCount.release();
+    if (dUncert) (void)hipFree(dUncert);
+    if (hStage) (void)hipHostFree(hStage);
+    for (auto& e : ev)
+      if (e) (void)hipEventDestroy(e);
+    for (auto& pr : ring)
+      for (auto& e : pr)
+        if (e) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+int ensure_stage(ehx_space* s, size_t bytes) {
+  if (bytes <= s->hStageBytes) return EHX_OK;
+  if (s->hStage) (void)hipHostFree(s->hStage);
+  s->hStage = nullptr;
+  s->hStageBytes = 0;
+  HIP_TRY(hipHostMalloc((void**)&s->hStage, bytes, hipHostMallocDefault));
+  s->hStageBytes = bytes;
+  return EHX_OK;
+}
+
+// grow HBM arrays to hold `rows` rows (multiple of 256, zero-initialised, rowp = pad).
+int grow(ehx_space* s, uint64_t rows) {
+  uint64_t want = round_up(rows < 256 ? 256 : rows, 256);
+  if (want <= s->cap) return EHX_OK;
+  HIP_TRY(hipDeviceSynchronize());  // no search may still read the old arrays
+  float* nx = nullptr;
+  float2* nr = nullptr;
+  float* ni = nullptr;
+  HIP_TRY(hipMalloc((void**)&nx, want * s->ld * sizeof(float)));
+  hipError_t e1 = hipMalloc((void**)&nr, want * sizeof(float2));
+  hipError_t e2 = hipMalloc((void**)&ni, want * sizeof(float));
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    (void)hipFree(nx);
+    if (nr) (void)hipFree(nr);
+    if (ni) (void)hipFree(ni);
+    return fail(EHX_ENOMEM, "hipMalloc failed growing space '%s' to %llu rows", s->name.c_str(),
+                (unsigned long long)want);
+  }
+  const uint64_t keep = s->n;
+  if (keep) {
+    HIP_TRY(hipMemcpyAsync(nx, s->dX, keep * s->ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(nr, s->dRowp, keep * sizeof(float2), hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(ni, s->dInv, keep * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+  }
+  HIP_TRY(hipMemsetAsync(nx + keep * s->ld, 0, (want - keep) * s->ld * sizeof(float), s->stream));
+  HIP_TRY(hipMemsetAsync(ni + keep, 0, (want - keep) * sizeof(float), s->stream));
+  HIP_TRY(launch_rowp_pad(nr, keep, want - keep, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->dX) (void)hipFree(s->dX);
+  if (s->dRowp) (void)hipFree(s->dRowp);
+  if (s->dInv) (void)hipFree(s->dInv);
+  s->dX = nx;
+  s->dRowp = nr;
+  s->dInv = ni;
+  s->cap = want;
+  return EHX_OK;
+}
+
+// capacity policy of ANNIndex::set (index.cc:29-32): double when the next label hits capacity
+int ensure_rows(ehx_space* s, uint64_t rows) {
+  if (rows < s->cap) return EHX_OK;
+  uint64_t want = s->cap ? s->cap : 256;
+  while (want <= rows) want *= 2;
+  return grow(s, want);
+}
+
+bool valid_space(ehx_space* s) { return s != nullptr; }
+
+struct ScanPlan {
+  uint32_t q_tiles, q_rows, n_tiles, n_chunks, tiles_per_chunk, kprime, xcd_map, grid;
+};
+
+ScanPlan plan_scan(uint32_t nq, uint64_t n, uint32_t k, int n_cus) {
+  ScanPlan p;
+  p.q_tiles = (nq + kTileQ - 1) / kTileQ;
+  p.q_rows = p.q_tiles * kTileQ;
+  p.n_tiles = (uint32_t)((n + kTileRows - 1) / kTileRows);
+  p.kprime = k + 8 > kCandSlots ? kCandSlots : k + 8;
+  // one persistent workgroup per CU: grid ~= n_cus, split as q_tiles x n_chunks
+  uint32_t chunks = (uint32_t)n_cus / p.q_tiles;
+  if (chunks < 1) chunks = 1;
+  if (chunks >= 8) chunks &= ~7u;
+  if (chunks > p.n_tiles) chunks = p.n_tiles ? p.n_tiles : 1;
+  p.n_chunks = chunks;
+  p.tiles_per_chunk = p.n_tiles ? (p.n_tiles + chunks - 1) / chunks : 0;
+  p.grid = p.q_tiles * p.n_chunks;
+  p.xcd_map = (p.n_chunks % 8 == 0) ? 1u : 0u;
+  return p;
+}
+
+// device pipeline: prepared queries -> scan -> merge -> canonical re-rank
+int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k,
+                      uint64_t* d_ids, float* d_dist, uint32_t* d_count) {
+  if (k == 0 || nq == 0) return EHX_OK;
+  if (k > EHX_MAX_K) return fail(EHX_EUNSUPPORTED, "k=%u exceeds EHX_MAX_K=%u", k, EHX_MAX_K);
+  if (nq > (1u << 24)) return fail(EHX_EINVAL, "too many queries in one call: %zu", nq);
+  if (s->params.mode != EHX_MODE_FLAT)
+    return fail(EHX_EUNSUPPORTED, "graph-mode search is not available in this build");
+  Engine& E = engine();
+  const ScanPlan p = plan_scan((uint32_t)nq, s->n, k, E.n_cus);
+  int rc;
+  if ((rc = s->dQ.ensure((size_t)p.q_rows * s->ld))) return rc;
+  if ((rc = s->dCand.ensure((size_t)p.grid * 256 * kCandSlots))) return rc;
+  if ((rc = s->dPart.ensure((size_t)p.q_rows * p.n_chunks * p.kprime))) return rc;
+  if ((rc = s->dMerged.ensure((size_t)p.q_rows * 64))) return rc;
+  if (!s->dUncert) {
+    HIP_TRY(hipMalloc((void**)&s->dUncert, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(s->dUncert, 0, sizeof(unsigned long long)));
+  }
+  // scratch buffers are shared by all callers: order this pipeline after the previous one even
+  // when it was enqueued on a different stream
+  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
+  HIP_TRY(hipEventRecord(s->ev[0], st));
+  HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, p.q_rows, s->metric, s->dQ.p, st));
+  if (s->n == 0) {
+    // empty space: every query returns count 0
+    HIP_TRY(hipMemsetAsync(s->dMerged.p, 0xFF, (size_t)p.q_rows * 64 * sizeof(uint64_t), st));
+    HIP_TRY(hipEventRecord(s->ev[1], st));
+    HIP_TRY(hipEventRecord(s->ev[2], st));
+  } else {
+    ScanArgs a;
+    a.Q = s->dQ.p;
+    a.X = s->dX;
+    a.rowp = s->dRowp;
+    a.cand = s->dCand.p;
+    a.part = s->dPart.p;
+    a.n = (uint32_t)s->n;
+    a.ld = s->ld;
+    a.n_tiles = p.n_tiles;
+    a.q_tiles = p.q_tiles;
+    a.n_chunks = p.n_chunks;
+    a.tiles_per_chunk = p.tiles_per_chunk;
+    a.kprime = p.kprime;
+    a.xcd_map = p.xcd_map;
+    hipEvent_t* pr = s->ring[s->ring_count % ehx_space::kRing];
+    HIP_TRY(hipEventRecord(s->ev[1], st));
+    HIP_TRY(hipEventRecord(pr[0], st));
+    HIP_TRY(launch_flat_scan(a, st));
+    HIP_TRY(hipEventRecord(pr[1], st));
+    HIP_TRY(hipEventRecord(s->ev[2], st));
+    s->ring_count++;
+    HIP_TRY(launch_flat_merge(s->dPart.p, (uint32_t)nq, p.n_chunks, p.kprime, s->dMerged.p, st));
+  }
+  RerankArgs r;
+  r.Q = s->dQ.p;
+  r.X = s->dX;
+  r.inv_norm = s->dInv;
+  r.merged = s->dMerged.p;
+  r.out_ids = d_ids;
+  r.out_dist = d_dist;
+  r.out_count = d_count;
+  r.n_uncertified = s->dUncert;
+  r.nq = (uint32_t)nq;
+  r.k = k;
+  r.kprime = p.kprime;
+  r.n = (uint32_t)s->n;
+  r.dims = s->dims;
+  r.ld = s->ld;
+  r.metric = s->metric;
+  HIP_TRY(launch_rerank(r, st));
+  HIP_TRY(hipEventRecord(s->ev[3], st));
+  s->ev_valid = true;
+  s->n_queries += nq;
+  s->n_dist += (uint64_t)nq * s->n;
+  s->n_rerank += (uint64_t)nq * p.kprime;
+  // SURVEY §8d brute force bytes per batch: N*d*s + B*d*4 + B*k*12
+  s->bytes_algo += s->n * s->dims * 4ull + (uint64_t)nq * s->dims * 4ull + (uint64_t)nq * k * 12ull;
+  return EHX_OK;
+}
+
+int key_for_id(ehx_space* s, uint64_t id, std::string* out) {
+  if (id < s->id_to_key.size() && !s->implicit_keys) {
+    *out = s->id_to_key[id];
+    return EHX_OK;
+  }
+  if (s->implicit_keys && id < s->n) {
+    *out = std::to_string(id);
+    return EHX_OK;
+  }
+  return EHX_ENOTFOUND;
+}
+
+int lookup_key(ehx_space* s, const char* key, size_t klen, uint64_t* id) {
+  if (s->implicit_keys) {
+    // decimal row id
+    if (klen == 0 || klen > 20) return EHX_ENOTFOUND;
+    uint64_t v = 0;
+    for (size_t i = 0; i < klen; ++i) {
+      if (key[i] < '0' || key[i] > '9') return EHX_ENOTFOUND;
+      v = v * 10 + (uint64_t)(key[i] - '0');
+    }
+    if (v >= s->n) return EHX_ENOTFOUND;
+    *id = v;
+    return EHX_OK;
+  }
+  auto it = s->key_to_id.find(std::string(key, klen));
+  if (it == s->key_to_id.end()) return EHX_ENOTFOUND;
+  *id = it->second;
+  return EHX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ehx_abi_version(void) { return EHX_ABI_VERSION; }
+const char* ehx_last_error(void) { return g_err; }
+
+int ehx_init(const int* device_ids, int n_devices) {
+  Engine& E = engine();
+  std::lock_guard<std::mutex> lk(E.mu);
+  if (E.inited) return EHX_OK;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return fail(EHX_ENODEVICE, "no HIP device available (%s); the engine has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  }
+  int dev = (device_ids && n_devices > 0) ? device_ids[0] : 0;
+  if (dev < 0 || dev >= count) return fail(EHX_EINVAL, "device id %d out of range (0..%d)", dev, count - 1);
+  HIP_TRY(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(EHX_ENODEVICE, "device %d is %s; this engine is built for gfx950 only", dev, prop.gcnArchName);
+  E.device = dev;
+  E.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  E.inited = true;
+  return EHX_OK;
+}
+
+int ehx_shutdown(void) {
+  Engine& E = engine();
+  std::lock_guard<std::mutex> lk(E.mu);
+  if (E.inited) (void)hipDeviceSynchronize();
+  E.spaces.clear();
+  return EHX_OK;
+}
+
+int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metric, int dtype,
+                     const ehx_params* params, ehx_space** out) {
+  if (!name || !out) return fail(EHX_EINVAL, "name/out must not be NULL");
+  if (dims == 0 || dims > (1u << 16)) return fail(EHX_EINVAL, "dims=%u out of range", dims);
+  if (metric < EHX_METRIC_L2SQ || metric > EHX_METRIC_COSINE) return fail(EHX_EINVAL, "unknown metric %d", metric);
+  if (dtype != EHX_DTYPE_F32) return fail(EHX_EUNSUPPORTED, "dtype %d not supported", dtype);
+  int rc = ehx_init(nullptr, 0);
+  if (rc) return rc;
+  Engine& E = engine();
+  std::lock_guard<std::mutex> lk(E.mu);
+  HIP_TRY(hipSetDevice(E.device));
+  std::string nm(name, name_len);
+  if (E.spaces.count(nm)) return fail(EHX_EEXISTS, "space '%s' already exists", nm.c_str());
+  std::unique_ptr<ehx_space> s(new ehx_space);
+  s->name = nm;
+  s->dims = dims;
+  s->ld = (uint32_t)round_up(dims, kBK);
+  s->metric = metric;
+  if (params) s->params = *params;
+  if (s->params.mode != EHX_MODE_FLAT && s->params.mode != EHX_MODE_GRAPH)
+    return fail(EHX_EINVAL, "unknown mode %u", s->params.mode);
+  if (s->params.M == 0) s->params.M = 16;
+  if (s->params.ef_construction == 0) s->params.ef_construction = 200;
+  if (s->params.ef == 0) s->params.ef = 10;
+  if (s->params.seed == 0) s->params.seed = 100;
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
+  for (auto& pr : s->ring)
+    for (auto& e : pr) HIP_TRY(hipEventCreate(&e));
+  uint64_t cap0 = s->params.initial_capacity ? s->params.initial_capacity : 128;  // index.h:21
+  if ((rc = grow(s.get(), cap0))) return rc;
+  *out = s.get();
+  E.spaces[nm] = std::move(s);
+  return EHX_OK;
+}
+
+int ehx_space_open(const char* name, size_t name_len, ehx_space** out) {
+  if (!name || !out) return fail(EHX_EINVAL, "name/out must not be NULL");
+  Engine& E = engine();
+  std::lock_guard<std::mutex> lk(E.mu);
+  auto it = E.spaces.find(std::string(name, name_len));
+  if (it == E.spaces.end()) return fail(EHX_ENOTFOUND, "Not found");
+  *out = it->second.get();
+  return EHX_OK;
+}
+
+int ehx_space_drop(ehx_space* s) {
+  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  Engine& E = engine();
+  std::lock_guard<std::mutex> lk(E.mu);
+  auto it = E.spaces.find(s->name);
+  if (it == E.spaces.end() || it->second.get() != s) return fail(EHX_ENOTFOUND, "Not found");
+  {
+    std::unique_lock<std::shared_mutex> wl(s->mu);
+    (void)hipDeviceSynchronize();
+  }
+  E.spaces.erase(it);
+  return EHX_OK;
+}
+
+int ehx_space_freeze(ehx_space* s) {
+  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  std::unique_lock<std::shared_mutex> wl(s->mu);
+  s->frozen = true;
+  return EHX_OK;
+}
+
+int ehx_space_size(ehx_space* s, uint64_t* n) {
+  if (!valid_space(s) || !n) return fail(EHX_EINVAL, "NULL argument");
+  std::shared_lock<std::shared_mutex> rl(s->mu);
+  *n = s->n;
+  return EHX_OK;
+}
+
+int ehx_space_dims(ehx_space* s, uint32_t* dims) {
+  if (!valid_space(s) || !dims) return fail(EHX_EINVAL, "NULL argument");
+  *dims = s->dims;
+  return EHX_OK;
+}
+
+int ehx_space_reserve(ehx_space* s, uint64_t rows) {
+  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  std::unique_lock<std::shared_mutex> wl(s->mu);
+  HIP_TRY(hipSetDevice(engine().device));
+  return grow(s, rows);
+}
+
+int ehx_space_set_ef(ehx_space* s, uint32_t ef) {
+  if (!valid_space(s) || ef == 0) return fail(EHX_EINVAL, "bad argument");
+  std::unique_lock<std::shared_mutex> wl(s->mu);
+  s->params.ef = ef;
+  return EHX_OK;
+}
+
+int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t* klens, const float* vecs) {
+  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  if (n == 0) return EHX_OK;
+  if (!keys || !klens || !vecs) return fail(EHX_EINVAL, "NULL argument");
+  std::unique_lock<std::shared_mutex> wl(s->mu);
+  if (s->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
+  if (s->implicit_keys) return fail(EHX_EINVAL, "space '%s' holds synthetic rows with implicit keys", s->name.c_str());
+  HIP_TRY(hipSetDevice(engine().device));
+  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev[3], 0));  // in-flight device searches
+  // resolve ids (upsert: an existing key keeps its label, index.cc:21-35); a key repeated inside the
+  // batch resolves to one row and the LAST vector wins, as sequential Sets would leave it.
+  std::vector<uint64_t> ids(n);
+  uint64_t next = s->n;
+  std::vector<std::string> new_keys;
+  for (size_t i = 0; i < n; ++i) {
+    std::string k(keys[i], klens[i]);
+    auto it = s->key_to_id.find(k);
+    if (it == s->key_to_id.end()) {
+      ids[i] = next;
+      s->key_to_id.emplace(k, next);
+      new_keys.push_back(std::move(k));
+      ++next;
+    } else {
+      ids[i] = it->second;
+    }
+  }
+  int rc = ensure_rows(s, next);
+  if (rc) {
+    for (auto& k : new_keys) s->key_to_id.erase(k);
+    return rc;
+  }
+  for (auto& k : new_keys) s->id_to_key.push_back(std::move(k));
+  // upload through pinned staging in slabs; rows may be non-contiguous (updates) so copy per row
+  const size_t row_bytes = (size_t)s->dims * sizeof(float);
+  const size_t slab_rows = std::max<size_t>(1, std::min<size_t>(n, (8u << 20) / row_bytes));
+  if ((rc = ensure_stage(s, slab_rows * row_bytes))) return rc;
+  uint64_t min_id = ~0ull, max_id = 0;
+  for (size_t i0 = 0; i0 < n; i0 += slab_rows) {
+    const size_t m = std::min(slab_rows, n - i0);
+    memcpy(s->hStage, vecs + i0 * s->dims, m * row_bytes);
+    // contiguous run of fresh ids -> one 2D copy; otherwise row by row
+    bool contiguous = true;
+    for (size_t i = 1; i < m; ++i)
+      if (ids[i0 + i] != ids[i0] + i) { contiguous = false; break; }
+    if (contiguous) {
+      HIP_TRY(hipMemcpy2DAsync(s->dX + ids[i0] * s->ld, (size_t)s->ld * sizeof(float), s->hStage, row_bytes,
+                               row_bytes, m, hipMemcpyHostToDevice, s->stream));
+    } else {
+      for (size_t i = 0; i < m; ++i)
+        HIP_TRY(hipMemcpyAsync(s->dX + ids[i0 + i] * s->ld, s->hStage + i * s->dims, row_bytes,
+                               hipMemcpyHostToDevice, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));  // staging buffer is reused
+    for (size_t i = 0; i < m; ++i) {
+      min_id = std::min(min_id, ids[i0 + i]);
+      max_id = std::max(max_id, ids[i0 + i]);
+    }
+  }
+  s->n = next;
+  // per-row statistics over the touched id range (idempotent for untouched rows in between)
+  HIP_TRY(launch_row_stats(s->dX, min_id, max_id - min_id + 1, s->dims, s->ld, s->metric, s->dInv, s->dRowp,
+                           s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return EHX_OK;
+}
+
+int ehx_set(ehx_space* s, const char* key, size_t klen, const float* vec) {
+  const char* keys[1] = {key};
+  size_t klens[1] = {klen};
+  if (!key) return fail(EHX_EINVAL, "key is NULL");
+  return ehx_set_batch(s, 1, keys, klens, vec);
+}
+
+int ehx_get_by_id(ehx_space* s, uint64_t id, float* out_vec) {
+  if (!valid_space(s) || !out_vec) return fail(EHX_EINVAL, "NULL argument");
+  std::shared_lock<std::shared_mutex> rl(s->mu);
+  if (id >= s->n) return fail(EHX_ENOTFOUND, "Not found");
+  HIP_TRY(hipSetDevice(engine().device));
+  HIP_TRY(hipMemcpy(out_vec, s->dX + id * s->ld, (size_t)s->dims * sizeof(float), hipMemcpyDeviceToHost));
+  return EHX_OK;
+}
+
+int ehx_get(ehx_space* s, const char* key, size_t klen, float* out_vec) {
+  if (!valid_space(s) || !key || !out_vec) return fail(EHX_EINVAL, "NULL argument");
+  uint64_t id;
+  {
+    std::shared_lock<std::shared_mutex> rl(s->mu);
+    if (lookup_key(s, key, klen, &id)) return fail(EHX_ENOTFOUND, "Not found");
+  }
+  return ehx_get_by_id(s, id, out_vec);
+}
+
+int ehx_key_of(ehx_space* s, uint64_t id, char* out_key, size_t cap, size_t* klen) {
+  if (!valid_space(s) || !klen) return fail(EHX_EINVAL, "NULL argument");
+  std::shared_lock<std::shared_mutex> rl(s->mu);
+  std::string k;
+  if (key_for_id(s, id, &k)) return fail(EHX_ENOTFOUND, "Not found");
+  *klen = k.size();
+  if (out_key && cap) memcpy(out_key, k.data(), std::min(cap, k.size()));
+  return EHX_OK;
+}
+
+int ehx_knn_device(ehx_space* s, void* stream, size_t n_queries, const float* d_queries, uint32_t k,
+                   uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count) {
+  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  if (n_queries && k && (!d_queries || !d_out_ids || !d_out_dist || !d_out_count))
+    return fail(EHX_EINVAL, "NULL device pointer");
+  std::shared_lock<std::shared_mutex> rl(s->mu);
+  std::lock_guard<std::mutex> sl(s->scratch_mu);
+  HIP_TRY(hipSetDevice(engine().device));
+  return knn_device_locked(s, (hipStream_t)stream, n_queries, d_queries, k, d_out_ids, d_out_dist, d_out_count);
+}
+
+int ehx_knn(ehx_space* s, size_t n_queries, const float* queries, uint32_t k, uint64_t* out_ids,
+            float* out_dist, uint32_t* out_count) {
+  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  if (n_queries == 0) return EHX_OK;
+  if (!out_count) return fail(EHX_EINVAL, "out_count is NULL");
+  if (k == 0) {
+    for (size_t i = 0; i < n_queries; ++i) out_count[i] = 0;
+    return EHX_OK;
+  }
+  if (!queries || !out_ids || !out_dist) return fail(EHX_EINVAL, "NULL argument");
+  std::shared_lock<std::shared_mutex> rl(s->mu);
+  std::lock_guard<std::mutex> sl(s->scratch_mu);
+  HIP_TRY(hipSetDevice(engine().device));
+  int rc;
+  const size_t qbytes = n_queries * s->dims * sizeof(float);
+  if ((rc = s->dQraw.ensure(n_queries * s->dims))) return rc;
+  if ((rc = s->dOutIds.ensure(n_queries * k))) return rc;
+  if ((rc = s->dOutDist.ensure(n_queries * k))) return rc;
+  if ((rc = s->dOutCount.ensure(n_queries))) return rc;
+  HIP_TRY(hipMemcpyAsync(s->dQraw.p, queries, qbytes, hipMemcpyHostToDevice, s->stream));
+  if ((rc = knn_device_locked(s, s->stream, n_queries, s->dQraw.p, k, s->dOutIds.p, s->dOutDist.p,
+                              s->dOutCount.p)))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(out_ids, s->dOutIds.p, n_queries * k * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(out_dist, s->dOutDist.p, n_queries * k * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(out_count, s->dOutCount.p, n_queries * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return EHX_OK;
+}
+
+int ehx_knn_keys(ehx_space* s, size_t n_queries, const float* queries, uint32_t k, uint64_t* out_ids,
+                 float* out_dist, uint32_t* out_count, char* key_arena, size_t arena_cap, uint64_t* key_off) {
+  if (!key_off || (!key_arena && arena_cap)) return fail(EHX_EINVAL, "NULL argument");
+  int rc = ehx_knn(s, n_queries, queries, k, out_ids, out_dist, out_count);
+  if (rc) return rc;
+  std::shared_lock<std::shared_mutex> rl(s->mu);
+  uint64_t off = 0;
+  std::string key;
+  for (size_t i = 0; i < n_queries; ++i) {
+    for (uint32_t j = 0; j < k; ++j) {
+      key_off[i * k + j] = off;
+      if (j < out_count[i] && key_for_id(s, out_ids[i * k + j], &key) == EHX_OK) {
+        if (off + key.size() > arena_cap) return fail(EHX_ERANGE, "key arena too small");
+        memcpy(key_arena + off, key.data(), key.size());
+        off += key.size();
+      }
+    }
+  }
+  key_off[n_queries * k] = off;
+  return EHX_OK;
+}
+
+int ehx_knn_by_key(ehx_space* s, const char* key, size_t klen, uint32_t k, uint64_t* out_ids, float* out_dist,
+                   uint32_t* out_count) {
+  if (!valid_space(s) || !key || !out_count) return fail(EHX_EINVAL, "NULL argument");
+  uint64_t id;
+  std::vector<float> v(s->dims);
+  {
+    std::shared_lock<std::shared_mutex> rl(s->mu);
+    if (lookup_key(s, key, klen, &id)) return fail(EHX_ENOTFOUND, "Not found");
+  }
+  int rc = ehx_get_by_id(s, id, v.data());  // Version::get(key), server.cc:195
+  if (rc) return rc;
+  const uint32_t kk = k + 1;               // server.cc:198
+  std::vector<uint64_t> ids(kk);
+  std::vector<float> dist(kk);
+  uint32_t cnt = 0;
+  if ((rc = ehx_knn(s, 1, v.data(), kk, ids.data(), dist.data(), &cnt))) return rc;
+  // server.cc:205-207: erase own key if present, else drop the last
+  uint32_t o = 0;
+  bool removed = false;
+  for (uint32_t j = 0; j < cnt; ++j) {
+    if (!removed && ids[j] == id) {
+      removed = true;
+      continue;
+    }
+    if (o < k) {
+      if (out_ids) out_ids[o] = ids[j];
+      if (out_dist) out_dist[o] = dist[j];
+      ++o;
+    }
+  }
+  if (!removed && cnt == kk && o == k) { /* last one already dropped by the o<k bound */ }
+  *out_count = o;
+  return EHX_OK;
+}
+
+int ehx_merge_topk_device(void* stream, size_t n_queries, uint32_t k, uint32_t n_lists, const uint64_t* d_ids,
+                          const float* d_dist, const uint32_t* d_count, uint64_t* d_out_ids, float* d_out_dist,
+                          uint32_t* d_out_count) {
+  if (n_queries == 0 || k == 0) return EHX_OK;
+  if (k > 64) return fail(EHX_EUNSUPPORTED, "merge supports k <= 64");
+  if (!d_ids || !d_dist || !d_out_ids || !d_out_dist) return fail(EHX_EINVAL, "NULL device pointer");
+  int rc = ehx_init(nullptr, 0);
+  if (rc) return rc;
+  HIP_TRY(launch_merge_lists(d_ids, d_dist, d_count, (uint32_t)n_queries, k, n_lists, d_out_ids, d_out_dist,
+                             d_out_count, (hipStream_t)stream));
+  return EHX_OK;
+}
+
+int ehx_gen_rows_device(void* stream, uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims, int normalize,
+                        float* d_out) {
+  if (!d_out && n_rows) return fail(EHX_EINVAL, "NULL device pointer");
+  if (dims % 4 != 0) return fail(EHX_EINVAL, "ehx_gen_rows_device needs dims %% 4 == 0 (got %u)", dims);
+  int rc = ehx_init(nullptr, 0);
+  if (rc) return rc;
+  HIP_TRY(launch_gen_rows(seed, row0, n_rows, dims, dims, normalize, d_out, (hipStream_t)stream));
+  return EHX_OK;
+}
+
+int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize) {
+  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  if (n_rows == 0) return EHX_OK;
+  std::unique_lock<std::shared_mutex> wl(s->mu);
+  if (s->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
+  if (!s->implicit_keys && s->n != 0)
+    return fail(EHX_EINVAL, "space '%s' already holds keyed rows", s->name.c_str());
+  HIP_TRY(hipSetDevice(engine().device));
+  if (s->n + n_rows >= (1ull << 32)) return fail(EHX_EUNSUPPORTED, "a shard holds at most 2^32-1 rows");
+  int rc = grow(s, s->n + n_rows);
+  if (rc) return rc;
+  s->implicit_keys = true;
+  HIP_TRY(launch_gen_rows(seed, row0, n_rows, s->dims, s->ld, normalize, s->dX + s->n * s->ld, s->stream));
+  HIP_TRY(launch_row_stats(s->dX, s->n, n_rows, s->dims, s->ld, s->metric, s->dInv, s->dRowp, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->n += n_rows;
+  return EHX_OK;
+}
+
+int ehx_graph_import(ehx_space* s, uint64_t, const uint32_t*, const int32_t*, uint64_t, const uint32_t*,
+                     const int32_t*, const uint64_t*, const uint32_t*, uint32_t, int32_t) {
+  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  return fail(EHX_EUNSUPPORTED, "graph mode is not available in this build");
+}
+
+int ehx_stats(ehx_space* s, ehx_stats_t* out) {
+  if (!valid_space(s) || !out) return fail(EHX_EINVAL, "NULL argument");
+  std::shared_lock<std::shared_mutex> rl(s->mu);
+  std::lock_guard<std::mutex> sl(s->scratch_mu);
+  memset(out, 0, sizeof(*out));
+  out->n_rows = s->n;
+  out->capacity = s->cap;
+  out->n_queries = s->n_queries;
+  out->n_dist = s->n_dist;
+  out->n_rerank = s->n_rerank;
+  out->bytes_algorithmic = s->bytes_algo;
+  if (s->dUncert) {
+    unsigned long long u = 0;
+    HIP_TRY(hipMemcpy(&u, s->dUncert, sizeof(u), hipMemcpyDeviceToHost));
+    out->n_uncertified = u;
+  }
+  if (s->ev_valid) {
+    HIP_TRY(hipEventSynchronize(s->ev[3]));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) out->last_scan_ms = ms;
+    if (hipEventElapsedTime(&ms, s->ev[0], s->ev[3]) == hipSuccess) out->last_total_ms = ms;
+    const uint64_t m = s->ring_count < (uint64_t)ehx_space::kRing ? s->ring_count : (uint64_t)ehx_space::kRing;
+    double sum = 0;
+    uint64_t got = 0;
+    for (uint64_t i = 0; i < m; ++i) {
+      if (hipEventElapsedTime(&ms, s->ring[i][0], s->ring[i][1]) == hipSuccess) {
+        sum += ms;
+        ++got;
+      }
+    }
+    out->scan_launches = got;
+    out->scan_ms_mean = got ? sum / (double)got : 0.0;
+  }
+  return EHX_OK;
+}
+
+int ehx_stats_reset(ehx_space* s) {
+  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  std::lock_guard<std::mutex> sl(s->scratch_mu);
+  s->n_queries = 0;
+  s->n_dist = 0;
+  s->n_rerank = 0;
+  s->bytes_algo = 0;
+  s->ring_count = 0;
+  if (s->dUncert) HIP_TRY(hipMemset(s->dUncert, 0, sizeof(unsigned long long)));
+  return EHX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,529 @@
+// Exhaustive ("flat") kNN on the gfx950 matrix cores.
+//
+// Replaces, for the brute-force configuration, the distance loop the reference runs inside
+// hnswlib (searchKnn -> fstdistfunc_, call site embeddinghub/embeddingstore/index.cc:41): the
+// B x N query-by-row distance matrix is a dense contraction, so it runs on
+// v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain) and is never materialised: each
+// 256x256 tile is filtered in registers against per-query running thresholds and only the
+// survivors reach a per-query candidate list.  A canonical re-rank (k_rerank below) then
+// recomputes the surviving distances in exactly the oracle's (hnswlib SSE) summation order, so
+// ids and distances are bit-identical to the exhaustive oracle.
+//
+// Layout / mapping (gfx950, wave64):
+//   * workgroup = 256 threads = 4 waves = one 256(rows) x 256(queries) tile, 1 workgroup per CU,
+//     one wave per SIMD with the whole 512-entry register file: wave (wr, wc) = (w>>1, w&1) owns
+//     128 rows x 128 queries = 4x4 MFMA 32x32 blocks (256 accumulator registers).  fp32 MFMA
+//     issues every 64 cycles with 64-cycle dependent latency, so 16 independent accumulators from
+//     one wave keep the SIMD's matrix pipe saturated;
+//   * MFMA A = corpus rows, B = queries, so a lane's 16 accumulator values of one block all belong
+//     to ONE query (col = lane&31) -> one threshold compare per value, one threshold per block;
+//   * both operand tiles ([256][32] fp32 = 32 KiB each) are staged by global_load_lds (16 B/lane,
+//     no VGPR round trip) into a double buffer; the 16-B chunk index of a row is XOR-swizzled with
+//     (row>>1)&7 on the SOURCE address and on the ds_read_b128 side (LDS image stays lane-linear),
+//     which makes the fragment reads bank-conflict free;
+//   * a lane's ds_read_b128 gives 4 consecutive k for its (row, k-half); MFMA step t of a group
+//     uses component t of both operands, i.e. the k order is permuted identically for A and B;
+//   * grid = q_tiles x n_chunks persistent workgroups; each walks a contiguous range of row tiles
+//     for one query tile, keeping per-query state (count, threshold key) in LDS and the 64
+//     candidate slots per query in a per-block global scratch (L2 resident).  With grid % 8 == 0
+//     the q_tiles blocks that stream the same rows are placed on the same XCD so the rows are
+//     fetched from HBM once and hit in that XCD's L2 for the other query tiles.
+#include "ehx_kernels.h"
+
+namespace ehx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr uint32_t kStageBytes = kTileRows * kBK * 4;             // 32 KiB per operand tile
+constexpr uint32_t kXOff = 0;                                      // Xs[2]
+constexpr uint32_t kQOff = 2 * kStageBytes;                        // Qs[2]
+constexpr uint32_t kThrKeyOff = 4 * kStageBytes;                   // u64 thr_key[256]
+constexpr uint32_t kThrFOff = kThrKeyOff + 256 * 8;                // f32 thr_f[256]
+constexpr uint32_t kCntOff = kThrFOff + 256 * 4;                   // i32 cnt[256]
+constexpr uint32_t kFlagOff = kCntOff + 256 * 4;                   // i32 flags[4]
+constexpr uint32_t kLdsBytes = kFlagOff + 16;
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+
+// ascending bitonic sort of one u64 per lane across the 64-lane wave
+__device__ __forceinline__ uint64_t wave_sort64(uint64_t key, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint64_t other = __shfl_xor(key, j, 64);
+      const bool up = (lane & k) == 0;
+      const bool lower = (lane & j) == 0;
+      const uint64_t mn = key < other ? key : other;
+      const uint64_t mx = key < other ? other : key;
+      key = (lower == up) ? mn : mx;
+    }
+  }
+  return key;
+}
+
+// input: bitonic sequence across lanes; output ascending
+__device__ __forceinline__ uint64_t wave_bitonic_merge64(uint64_t key, int lane) {
+#pragma unroll
+  for (int j = 32; j > 0; j >>= 1) {
+    const uint64_t other = __shfl_xor(key, j, 64);
+    const uint64_t mn = key < other ? key : other;
+    const uint64_t mx = key < other ? other : key;
+    key = (lane & j) == 0 ? mn : mx;
+  }
+  return key;
+}
+
+}  // namespace
+
+size_t scan_lds_bytes() { return kLdsBytes; }
+
+__global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int h = lane >> 5, i31 = lane & 31;
+
+  // ---- block -> (query tile, chunk) ----
+  uint32_t qt, chunk;
+  {
+    const uint32_t b = blockIdx.x;
+    if (a.xcd_map) {
+      const uint32_t xcd = b & 7u, slot = b >> 3;
+      qt = slot % a.q_tiles;
+      chunk = xcd * (a.n_chunks >> 3) + slot / a.q_tiles;
+    } else {
+      qt = b % a.q_tiles;
+      chunk = b / a.q_tiles;
+    }
+  }
+  uint64_t* thr_key = (uint64_t*)(smem + kThrKeyOff);
+  float* thr_f = (float*)(smem + kThrFOff);
+  int* cnt = (int*)(smem + kCntOff);
+  int* flags = (int*)(smem + kFlagOff);
+  uint64_t* cand = a.cand + (size_t)blockIdx.x * (256u * kCandSlots);
+
+  if (tid < 256) {
+    thr_key[tid] = kKeyInf;
+    thr_f[tid] = __builtin_inff();
+    cnt[tid] = 0;
+  }
+  if (tid < 4) flags[tid] = 0;
+
+  const uint32_t tile_begin = chunk * a.tiles_per_chunk;
+  uint32_t tile_end = tile_begin + a.tiles_per_chunk;
+  if (tile_end > a.n_tiles) tile_end = a.n_tiles;
+  const uint32_t my_tiles = tile_end > tile_begin ? tile_end - tile_begin : 0u;
+  const uint32_t ktiles = a.ld / kBK;
+  const uint32_t total_steps = my_tiles * ktiles;
+
+  // ---- per-lane constants for the staging loads (8 X + 8 Q glds per wave per stage) ----
+  // instruction `ins` (0..31) covers tile rows ins*8 .. ins*8+7; lane L -> row ins*8+(L>>3),
+  // physical 16-B chunk p = L&7, logical chunk c = p ^ ((row>>1)&7).
+  const float* Qtile = a.Q + (size_t)qt * kTileQ * a.ld;
+  uint32_t st_off[8];  // float offset of this lane's source within a tile (row*ld + c*4)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const uint32_t ins = (uint32_t)w * 8 + u;
+    const uint32_t row = ins * 8 + (lane >> 3);
+    const uint32_t c = (lane & 7) ^ ((row >> 1) & 7);
+    st_off[u] = row * a.ld + c * 4;
+  }
+
+  auto stage = [&](uint32_t step) {
+    const uint32_t t = step / ktiles, kt = step - t * ktiles;
+    const uint32_t buf = step & 1;
+    const float* Xt = a.X + (size_t)(tile_begin + t) * kTileRows * a.ld + kt * kBK;
+    const float* Qt = Qtile + kt * kBK;
+    char* xs = smem + kXOff + buf * kStageBytes + (uint32_t)w * 8192;
+    char* qs = smem + kQOff + buf * kStageBytes + (uint32_t)w * 8192;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) glds16(Xt + st_off[u], xs + u * 1024);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) glds16(Qt + st_off[u], qs + u * 1024);
+  };
+
+  // ---- per-lane constants for the fragment reads ----
+  // row r = base + i31 ; chunk for group j = (2j+h) ^ ((r>>1)&7) = (2j) ^ hs, hs = h ^ ((i31>>1)&7)
+  const uint32_t hs = (uint32_t)h ^ ((uint32_t)(i31 >> 1) & 7u);
+  uint32_t joff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) joff[j] = (((uint32_t)(2 * j)) ^ hs) * 16;
+  const uint32_t a_row_off = (uint32_t)(wr * 128 + i31) * 128;  // + rb*32*128
+  const uint32_t b_row_off = (uint32_t)(wc * 128 + i31) * 128;  // + cb*32*128
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
+
+  if (total_steps > 0) stage(0);
+
+  uint32_t kt = 0, t = 0;
+  for (uint32_t step = 0; step < total_steps; ++step) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (step + 1 < total_steps) stage(step + 1);
+
+    const char* xs = smem + kXOff + (step & 1) * kStageBytes + a_row_off;
+    const char* qs = smem + kQOff + (step & 1) * kStageBytes + b_row_off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 av[4], bv[4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) av[rb] = *(const f32x4*)(xs + rb * 4096 + joff[j]);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) bv[cb] = *(const f32x4*)(qs + cb * 4096 + joff[j]);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb)
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rb][tt], bv[cb][tt], acc[rb][cb], 0, 0, 0);
+    }
+
+    if (++kt == ktiles) {
+      kt = 0;
+      // ================= tile epilogue: threshold filter + candidate append =================
+      // Phase 1 (branch-free, fully unrolled): turn every accumulator into its approximate
+      // distance s = dot*a_row + b_row IN PLACE and record "s <= threshold of its query" as one
+      // bit per value (8 words x 32 bits per lane; word = rb*2 + (cb>>1), bit = (cb&1)*16 + reg).
+      // Phase 2 (rare, loops): only lanes with set bits extract the value with a select chain
+      // and append (score,id) keys to the query's candidate slots.
+      const uint32_t tile_row0 = (tile_begin + t) * kTileRows;
+      const int qbase = wc * 128 + i31;
+      uint32_t pend[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+      {
+        float thrf[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) thrf[cb] = thr_f[qbase + cb * 32];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const uint32_t r = (uint32_t)(wr * 128 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
+            const float2 ab = a.rowp[tile_row0 + r];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+              const float sc = __builtin_fmaf(acc[rb][cb][reg], ab.x, ab.y);
+              acc[rb][cb][reg] = sc;
+              pend[rb * 2 + (cb >> 1)] |= (sc <= thrf[cb]) ? (1u << ((cb & 1) * 16 + reg)) : 0u;
+            }
+          }
+        }
+      }
+      const bool lane_any = (pend[0] | pend[1] | pend[2] | pend[3] | pend[4] | pend[5] | pend[6] | pend[7]) != 0u;
+      // block-uniform decision (LDS flag) so every wave takes the same barrier path
+      if (lane_any) flags[1] = 1;
+      __syncthreads();
+      const int tile_hot = flags[1];
+      __syncthreads();
+      if (tile_hot) {
+        if (tid == 0) flags[1] = 0;
+        for (;;) {
+#pragma unroll
+          for (int wd = 0; wd < 8; ++wd) {
+            const int rb = wd >> 1, cp = wd & 1;
+            uint32_t retry = 0u;
+            while (__any(pend[wd] != 0u)) {
+              if (pend[wd] != 0u) {
+                const int b = __builtin_ctz(pend[wd]);
+                pend[wd] &= pend[wd] - 1u;
+                float sc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sc = (b == i) ? acc[rb][2 * cp][i] : sc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sc = (b == 16 + i) ? acc[rb][2 * cp + 1][i] : sc;
+                const int reg = b & 15;
+                const int cb = 2 * cp + (b >> 4);
+                const uint32_t r = (uint32_t)(wr * 128 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
+                const uint32_t grow = tile_row0 + r;
+                const int q = qbase + cb * 32;
+                const uint64_t key = ((uint64_t)f32_to_ordered(sc) << 32) | grow;
+                if (grow < a.n && key < thr_key[q]) {
+                  const int pos = atomicAdd(&cnt[q], 1);
+                  if (pos < (int)kCandSlots) {
+                    cand[q * kCandSlots + pos] = key;
+                  } else {
+                    flags[0] = 1;
+                    retry |= 1u << b;
+                  }
+                }
+              }
+            }
+            pend[wd] = retry;
+          }
+          __syncthreads();
+          // ---- compaction: wave w owns queries w*64 .. w*64+63 ----
+          const int overflow = flags[0];
+          const int trigger = (int)a.kprime + ((int)kCandSlots - (int)a.kprime) / 2;
+          {
+            const int c = cnt[w * 64 + lane];
+            const bool need = c >= trigger || (overflow && c > (int)kCandSlots);
+            uint64_t mask = __ballot(need);
+            while (mask) {
+              const int qq = __builtin_ctzll(mask);
+              mask &= mask - 1;
+              const int q = w * 64 + qq;
+              const int cq = cnt[q];
+              const int nv = cq < (int)kCandSlots ? cq : (int)kCandSlots;
+              uint64_t key = lane < nv ? cand[q * kCandSlots + lane] : kKeyInf;
+              key = wave_sort64(key, lane);
+              if (lane < (int)a.kprime) cand[q * kCandSlots + lane] = key;
+              const uint64_t kth = __shfl(key, (int)a.kprime - 1, 64);
+              if (lane == 0) {
+                cnt[q] = nv < (int)a.kprime ? nv : (int)a.kprime;
+                if (nv >= (int)a.kprime) {
+                  thr_key[q] = kth;
+                  thr_f[q] = ordered_to_f32((uint32_t)(kth >> 32));
+                }
+              }
+            }
+          }
+          __syncthreads();
+          if (!overflow) break;
+          if (tid == 0) flags[0] = 0;
+          __syncthreads();
+        }
+      }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
+      ++t;
+    }
+  }
+
+  // ---- final: sort every query's slots and publish the top-k' keys of this chunk ----
+  __syncthreads();
+  for (int qq = 0; qq < 64; ++qq) {
+    const int q = w * 64 + qq;
+    const int cq = cnt[q];
+    const int nv = cq < (int)kCandSlots ? cq : (int)kCandSlots;
+    uint64_t key = lane < nv ? cand[q * kCandSlots + lane] : kKeyInf;
+    key = wave_sort64(key, lane);
+    if (lane < (int)a.kprime)
+      a.part[((size_t)(qt * kTileQ + q) * a.n_chunks + chunk) * a.kprime + lane] = key;
+  }
+}
+
+hipError_t launch_flat_scan(const ScanArgs& a, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)flat_scan_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const uint32_t grid = a.q_tiles * a.n_chunks;
+  hipLaunchKernelGGL(flat_scan_kernel, dim3(grid), dim3(kThreads), kLdsBytes, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// merge of the per-chunk sorted key lists: one wave per query
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void flat_merge_kernel(const uint64_t* __restrict__ part, uint32_t n_chunks,
+                                                        uint32_t kprime, uint64_t* __restrict__ merged) {
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  const uint64_t* p = part + (size_t)q * n_chunks * kprime;
+  uint64_t best = kKeyInf;
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    const uint64_t v = lane < (int)kprime ? p[(size_t)c * kprime + lane] : kKeyInf;  // ascending
+    const uint64_t rv = __shfl(v, 63 - lane, 64);                                     // descending
+    const uint64_t m = best < rv ? best : rv;  // the 64 smallest of the union, bitonic
+    best = wave_bitonic_merge64(m, lane);
+  }
+  merged[(size_t)q * 64 + lane] = best;
+}
+
+hipError_t launch_flat_merge(const uint64_t* part, uint32_t nq, uint32_t n_chunks, uint32_t kprime,
+                             uint64_t* merged, hipStream_t st) {
+  hipLaunchKernelGGL(flat_merge_kernel, dim3(nq), dim3(64), 0, st, part, n_chunks, kprime, merged);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// canonical re-rank.  Distances are recomputed in exactly the order of hnswlib's SSE kernels
+// (space_l2.h / space_ip.h; dispatch in L2Space / InnerProductSpace constructors), which is what
+// oracle/hnsw_oracle.hpp restates: 4 strided partial sums over the multiple-of-4 body (multiply
+// and add NOT fused), horizontal sum t0+t1+t2+t3 left to right, scalar tail added afterwards.
+// One 4-lane group per candidate; lane j of the group plays SSE lane j.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ float canon_dist(int metric, const float* __restrict__ q,
+                                            const float* __restrict__ x, float xscale, bool scale_x,
+                                            uint32_t dims, int sub) {
+  uint32_t body;
+  if ((dims & 15u) == 0 || (dims & 3u) == 0) body = dims;
+  else if (dims > 16) body = dims & ~15u;
+  else if (dims > 4) body = dims & ~3u;
+  else body = 0;
+  float part = 0.0f;
+  if (metric == 0) {
+    for (uint32_t m = sub; m < body; m += 4) {
+      const float xv = scale_x ? __fmul_rn(x[m], xscale) : x[m];
+      const float diff = __fsub_rn(q[m], xv);
+      part = __fadd_rn(part, __fmul_rn(diff, diff));
+    }
+  } else {
+    for (uint32_t m = sub; m < body; m += 4) {
+      const float xv = scale_x ? __fmul_rn(x[m], xscale) : x[m];
+      part = __fadd_rn(part, __fmul_rn(q[m], xv));
+    }
+  }
+  // horizontal sum in lane order within the 4-lane group
+  const float t1 = __shfl_down(part, 1, 4), t2 = __shfl_down(part, 2, 4), t3 = __shfl_down(part, 3, 4);
+  float res = __fadd_rn(__fadd_rn(__fadd_rn(part, t1), t2), t3);
+  if (body != dims) {
+    float tail = 0.0f;
+    if (metric == 0) {
+      for (uint32_t m = body; m < dims; ++m) {
+        const float xv = scale_x ? __fmul_rn(x[m], xscale) : x[m];
+        const float diff = __fsub_rn(q[m], xv);
+        tail = __fadd_rn(tail, __fmul_rn(diff, diff));
+      }
+    } else {
+      for (uint32_t m = body; m < dims; ++m) {
+        const float xv = scale_x ? __fmul_rn(x[m], xscale) : x[m];
+        tail = __fadd_rn(tail, __fmul_rn(q[m], xv));
+      }
+    }
+    res = body ? __fadd_rn(res, tail) : tail;
+  }
+  if (metric != 0) res = __fsub_rn(1.0f, res);
+  return res;  // valid in sub-lane 0
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
+  __shared__ uint64_t keys[64];
+  __shared__ float approx[64];
+  const int tid = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  const int g = tid >> 2, sub = tid & 3;
+  const uint64_t mk = a.merged[(size_t)q * 64 + g];
+  const uint32_t id = (uint32_t)mk;
+  const bool valid = (g < (int)a.kprime) && (mk != kKeyInf) && (id < a.n);
+  float d = __builtin_inff();
+  if (valid) {
+    const float* qv = a.Q + (size_t)q * a.ld;
+    const float* xv = a.X + (size_t)id * a.ld;
+    const bool scale_x = a.metric == 2;
+    const float xs = scale_x ? a.inv_norm[id] : 1.0f;
+    d = canon_dist(a.metric == 0 ? 0 : 1, qv, xv, xs, scale_x, a.dims, sub);
+  }
+  if (sub == 0) {
+    keys[g] = valid ? (((uint64_t)f32_to_ordered(d) << 32) | id) : kKeyInf;
+    approx[g] = valid ? ordered_to_f32((uint32_t)(mk >> 32)) : __builtin_inff();
+  }
+  __syncthreads();
+  if (tid < 64) {
+    uint64_t key = wave_sort64(keys[tid], tid);
+    const uint64_t nvalid_mask = __ballot(key != kKeyInf);
+    const uint32_t nvalid = __builtin_popcountll(nvalid_mask);
+    const uint32_t cnt = nvalid < a.k ? nvalid : a.k;
+    if (tid < (int)a.k) {
+      const bool ok = (uint32_t)tid < cnt;
+      a.out_ids[(size_t)q * a.k + tid] = ok ? (uint64_t)(uint32_t)key : ~0ull;
+      a.out_dist[(size_t)q * a.k + tid] = ok ? ordered_to_f32((uint32_t)(key >> 32)) : __builtin_inff();
+    }
+    if (tid == 0) a.out_count[q] = cnt;
+    // certification: every row that is NOT a candidate has approx score >= the worst candidate's
+    // approx score A_last.  If A_last - margin > exact k-th distance, no outsider can beat the
+    // k-th result, so the top-k is provably the exhaustive top-k.  (Skipped when all rows of the
+    // space are candidates.)
+    if (a.n > a.kprime && cnt == a.k && a.k > 0) {
+      float worst = -__builtin_inff();
+      for (int j = 0; j < 64; ++j)
+        if (approx[j] != __builtin_inff() && approx[j] > worst) worst = approx[j];
+      const float kth = ordered_to_f32((uint32_t)(__shfl(key, (int)a.k - 1, 64) >> 32));
+      const float margin = 4e-6f * (fabsf(kth) > 1.0f ? fabsf(kth) : 1.0f);
+      if (tid == 0 && !(worst - margin > kth)) atomicAdd(a.n_uncertified, 1ull);
+    }
+  }
+}
+
+hipError_t launch_rerank(const RerankArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(rerank_kernel, dim3(a.nq), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k-way merge of per-shard result lists (after the RCCL all-gather): one wave per query.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t* __restrict__ ids,
+                                                         const float* __restrict__ dist,
+                                                         const uint32_t* __restrict__ count, uint32_t nq,
+                                                         uint32_t k, uint32_t n_lists,
+                                                         uint64_t* __restrict__ out_ids,
+                                                         float* __restrict__ out_dist,
+                                                         uint32_t* __restrict__ out_count) {
+  // lists are sorted nearest-first; k <= 64.  Keys are (ordered dist, list, pos) so the wave
+  // sort is stable w.r.t. (dist, id) once ties are broken by id below.
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  // running best: (dist, id) pairs, one per lane, sorted by (dist, id)
+  float bd = __builtin_inff();
+  uint64_t bi = ~0ull;
+  uint32_t total = 0;
+  for (uint32_t l = 0; l < n_lists; ++l) {
+    const size_t base = ((size_t)l * nq + q) * k;
+    const uint32_t c = count ? count[(size_t)l * nq + q] : k;
+    total += c;
+    float d = (lane < (int)k && (uint32_t)lane < c) ? dist[base + lane] : __builtin_inff();
+    uint64_t i = (lane < (int)k && (uint32_t)lane < c) ? ids[base + lane] : ~0ull;
+    // reverse incoming list, elementwise min by (dist, id), bitonic merge on the pair
+    const float rd = __shfl(d, 63 - lane, 64);
+    const uint64_t ri = __shfl(i, 63 - lane, 64);
+    const bool take = (rd < bd) || (rd == bd && ri < bi);
+    if (take) {
+      bd = rd;
+      bi = ri;
+    }
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+      const float od = __shfl_xor(bd, j, 64);
+      const uint64_t oi = __shfl_xor(bi, j, 64);
+      const bool less = (od < bd) || (od == bd && oi < bi);  // other < mine
+      const bool want_min = (lane & j) == 0;
+      if (want_min == less) {
+        bd = od;
+        bi = oi;
+      }
+    }
+  }
+  const uint32_t cnt = total < k ? total : k;
+  if (lane < (int)k) {
+    const bool ok = (uint32_t)lane < cnt;
+    out_ids[(size_t)q * k + lane] = ok ? bi : ~0ull;
+    out_dist[(size_t)q * k + lane] = ok ? bd : __builtin_inff();
+  }
+  if (lane == 0 && out_count) out_count[q] = cnt;
+}
+
+hipError_t launch_merge_lists(const uint64_t* ids, const float* dist, const uint32_t* count, uint32_t nq,
+                              uint32_t k, uint32_t n_lists, uint64_t* out_ids, float* out_dist,
+                              uint32_t* out_count, hipStream_t st) {
+  hipLaunchKernelGGL(merge_lists_kernel, dim3(nq), dim3(64), 0, st, ids, dist, count, nq, k, n_lists,
+                     out_ids, out_dist, out_count);
+  return hipGetLastError();
+}
+
+}  // namespace ehx

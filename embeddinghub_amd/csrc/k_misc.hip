@@ -1,0 +1,183 @@
+// Small kernels around the scan: query preparation, per-row statistics maintained at Set time,
+// and the EHX-GAUSS-1 synthetic workload generator (include/ehx_datagen.h).
+//
+// Canonical arithmetic: the L2 norm used for cosine follows hnswlib-python's
+// Index::normalize_vector (sequential fp32 sum, non-fused; norm = 1/(sqrt(sum)+1e-30f); x*norm) —
+// the convention SURVEY.md §8d fixes and oracle/hnsw_oracle.hpp:normalize_vector restates.
+#include "../../include/ehx_datagen.h"
+#include "ehx_kernels.h"
+
+namespace ehx {
+
+namespace {
+// one thread walks one row sequentially: the summation ORDER is the contract here
+__device__ __forceinline__ float seq_sumsq(const float* __restrict__ x, uint32_t dims) {
+  float s = 0.0f;
+  for (uint32_t i = 0; i < dims; ++i) s = __fadd_rn(s, __fmul_rn(x[i], x[i]));
+  return s;
+}
+__device__ __forceinline__ float inv_norm_of(float sumsq) {
+  return __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(sumsq), 1e-30f));
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restrict__ q_in, uint32_t nq,
+                                                          uint32_t dims, uint32_t ld, uint32_t q_rows,
+                                                          int metric, float* __restrict__ q_out) {
+  // one wave per output row: lane 0 computes the canonical norm, all lanes scale/copy
+  const uint32_t row = blockIdx.x;
+  const int lane = threadIdx.x;
+  float* out = q_out + (size_t)row * ld;
+  if (row >= nq) {
+    for (uint32_t i = lane; i < ld; i += 64) out[i] = 0.0f;
+    return;
+  }
+  const float* in = q_in + (size_t)row * dims;
+  float inv = 1.0f;
+  if (metric == 2) {
+    float v = 0.0f;
+    if (lane == 0) v = inv_norm_of(seq_sumsq(in, dims));
+    inv = __shfl(v, 0, 64);
+  }
+  for (uint32_t i = lane; i < ld; i += 64) {
+    float v = i < dims ? in[i] : 0.0f;
+    if (metric == 2) v = __fmul_rn(v, inv);
+    out[i] = v;
+  }
+}
+
+hipError_t launch_prep_queries(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld, uint32_t q_rows,
+                               int metric, float* q_out, hipStream_t st) {
+  hipLaunchKernelGGL(prep_queries_kernel, dim3(q_rows), dim3(64), 0, st, q_in, nq, dims, ld, q_rows,
+                     metric, q_out);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ X, uint64_t row0,
+                                                        uint64_t n, uint32_t dims, uint32_t ld, int metric,
+                                                        float* __restrict__ inv_norm,
+                                                        float2* __restrict__ rowp) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t r = row0 + i;
+  const float s = seq_sumsq(X + r * ld, dims);
+  if (metric == 2) {
+    const float inv = inv_norm_of(s);
+    inv_norm[r] = inv;
+    rowp[r] = make_float2(-inv, 1.0f);  // approx cosine distance = 1 - dot(q^, x) * inv
+  } else if (metric == 0) {
+    rowp[r] = make_float2(-2.0f, s);  // approx L2^2 - |q|^2 = |x|^2 - 2 dot
+  } else {
+    rowp[r] = make_float2(-1.0f, 1.0f);  // 1 - dot
+  }
+}
+
+hipError_t launch_row_stats(const float* X, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
+                            int metric, float* inv_norm, float2* rowp, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const uint32_t grid = (uint32_t)((n + 255) / 256);
+  hipLaunchKernelGGL(row_stats_kernel, dim3(grid), dim3(256), 0, st, X, row0, n, dims, ld, metric,
+                     inv_norm, rowp);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void rowp_pad_kernel(float2* __restrict__ rowp, uint64_t row0, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rowp[row0 + i] = make_float2(0.0f, __builtin_inff());
+}
+
+hipError_t launch_rowp_pad(float2* rowp, uint64_t row0, uint64_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const uint32_t grid = (uint32_t)((n + 255) / 256);
+  hipLaunchKernelGGL(rowp_pad_kernel, dim3(grid), dim3(256), 0, st, rowp, row0, n);
+  return hipGetLastError();
+}
+
+// ---- EHX-GAUSS-1 --------------------------------------------------------------------------------
+// pass 1: one thread per 4 columns (one Philox call), coalesced 16-B stores
+__global__ __launch_bounds__(256) void gen_rows_kernel(uint64_t seed, uint64_t row0, uint64_t n_rows,
+                                                       uint32_t dims, uint32_t ld, float* __restrict__ out) {
+  const uint32_t cbs = ld / 4;  // ld % 4 == 0
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_rows * cbs) return;
+  const uint64_t r = gid / cbs;
+  const uint32_t cb = (uint32_t)(gid - r * cbs);
+  float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (cb * 4 < dims) {
+    ehx_datagen::normal4(seed, row0 + r, cb, z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (cb * 4 + j >= dims) z[j] = 0.0f;
+  }
+  *(float4*)(out + r * ld + cb * 4) = make_float4(z[0], z[1], z[2], z[3]);
+}
+
+// pass 2 (normalize): one wave per row; lane 0 walks the row for the canonical sum
+__global__ __launch_bounds__(64) void normalize_rows_kernel(uint64_t n_rows, uint32_t dims, uint32_t ld,
+                                                            float* __restrict__ x) {
+  const uint64_t r = blockIdx.x;
+  const int lane = threadIdx.x;
+  float* row = x + r * ld;
+  float v = 0.0f;
+  if (lane == 0) v = inv_norm_of(seq_sumsq(row, dims));
+  const float inv = __shfl(v, 0, 64);
+  for (uint32_t i = lane; i < dims; i += 64) row[i] = __fmul_rn(row[i], inv);
+}
+
+// faster variant for big fills: 64 rows per wave, 64x64 tiles transposed through LDS so global
+// accesses stay coalesced while each lane still sums ITS row sequentially (same order, same bits)
+__global__ __launch_bounds__(64) void normalize_rows_tiled_kernel(uint64_t n_rows, uint32_t dims, uint32_t ld,
+                                                                  float* __restrict__ x) {
+  __shared__ float tile[64][65];
+  const int lane = threadIdx.x;
+  const uint64_t r0 = (uint64_t)blockIdx.x * 64;
+  const uint64_t rows = n_rows - r0 < 64 ? n_rows - r0 : 64;
+  float s = 0.0f;
+  for (uint32_t c0 = 0; c0 < dims; c0 += 64) {
+    for (uint32_t rr = 0; rr < rows; ++rr) {
+      const uint32_t c = c0 + lane;
+      tile[rr][lane] = c < dims ? x[(r0 + rr) * ld + c] : 0.0f;
+    }
+    __syncthreads();
+    if ((uint64_t)lane < rows) {
+      const uint32_t lim = dims - c0 < 64 ? dims - c0 : 64;
+      for (uint32_t c = 0; c < lim; ++c) s = __fadd_rn(s, __fmul_rn(tile[lane][c], tile[lane][c]));
+    }
+    __syncthreads();
+  }
+  const float inv = inv_norm_of(s);
+  for (uint32_t rr = 0; rr < rows; ++rr) {
+    const float rinv = __shfl(inv, (int)rr, 64);
+    for (uint32_t c = lane; c < dims; c += 64) {
+      float* p = x + (r0 + rr) * ld + c;
+      *p = __fmul_rn(*p, rinv);
+    }
+  }
+}
+
+hipError_t launch_gen_rows(uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims, uint32_t ld,
+                           int normalize, float* out, hipStream_t st) {
+  if (n_rows == 0) return hipSuccess;
+  const uint64_t work = n_rows * (ld / 4);
+  // grid.x limit: chunk the launch if needed
+  const uint64_t max_blocks = 1u << 30;
+  uint64_t done_rows = 0;
+  while (done_rows < n_rows) {
+    uint64_t rows = n_rows - done_rows;
+    const uint64_t per_row_blocks_x256 = ld / 4;  // threads per row
+    const uint64_t max_rows = (max_blocks * 256) / per_row_blocks_x256;
+    if (rows > max_rows) rows = max_rows;
+    const uint64_t threads = rows * per_row_blocks_x256;
+    hipLaunchKernelGGL(gen_rows_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, st, seed,
+                       row0 + done_rows, rows, dims, ld, out + done_rows * ld);
+    done_rows += rows;
+  }
+  (void)work;
+  if (normalize) {
+    hipLaunchKernelGGL(normalize_rows_tiled_kernel, dim3((uint32_t)((n_rows + 63) / 64)), dim3(64), 0, st,
+                       n_rows, dims, ld, out);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace ehx

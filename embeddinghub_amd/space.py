@@ -1,0 +1,196 @@
+"""Thin numpy-facing wrapper of one engine space (all arithmetic happens in libehx.so on the GPU).
+
+Mirrors the embeddingstore service surface for one space
+(embeddinghub/embeddingstore/embedding_store.proto:9-19): Set / MultiSet / Get / NearestNeighbor /
+FreezeSpace, and the Go VectorStoreTable surface (provider/online.go:50-64): Set / Get / Nearest.
+"""
+import ctypes as C
+import itertools
+
+import numpy as np
+
+from . import _lib
+from ._lib import EhxError, Params, Stats, check
+
+_counter = itertools.count()
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Space:
+    def __init__(self, name, dims, metric=_lib.METRIC_L2SQ, mode=_lib.MODE_FLAT, M=0, ef_construction=0,
+                 ef=0, seed=0, initial_capacity=0, _handle=None):
+        self._L = _lib.load()
+        self.name, self.dims, self.metric = name, int(dims), metric
+        if _handle is not None:
+            self._h = _handle
+            return
+        p = Params(mode=mode, M=M, ef_construction=ef_construction, ef=ef, seed=seed,
+                   initial_capacity=initial_capacity)
+        h = C.c_void_p()
+        nm = name.encode()
+        check(self._L.ehx_space_create(nm, len(nm), self.dims, metric, 0, C.byref(p), C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def unique(cls, prefix, dims, **kw):
+        return cls("%s-%d" % (prefix, next(_counter)), dims, **kw)
+
+    @classmethod
+    def open(cls, name):
+        L = _lib.load()
+        h = C.c_void_p()
+        nm = name.encode()
+        check(L.ehx_space_open(nm, len(nm), C.byref(h)))
+        d = C.c_uint32()
+        check(L.ehx_space_dims(h, C.byref(d)))
+        return cls(name, d.value, _handle=h)
+
+    def drop(self):
+        if self._h:
+            check(self._L.ehx_space_drop(self._h))
+            self._h = None
+
+    def freeze(self):
+        check(self._L.ehx_space_freeze(self._h))
+
+    def reserve(self, rows):
+        check(self._L.ehx_space_reserve(self._h, rows))
+
+    def __len__(self):
+        n = C.c_uint64()
+        check(self._L.ehx_space_size(self._h, C.byref(n)))
+        return n.value
+
+    # ---- writes ----
+    def set(self, key, vec):
+        v, pv = _f32(vec)
+        if v.size != self.dims:
+            raise ValueError("expected %d dims, got %d" % (self.dims, v.size))
+        k = key.encode() if isinstance(key, str) else bytes(key)
+        check(self._L.ehx_set(self._h, k, len(k), pv))
+
+    def set_batch(self, keys, vecs):
+        v, pv = _f32(vecs)
+        v = v.reshape(-1, self.dims)
+        ks = [k.encode() if isinstance(k, str) else bytes(k) for k in keys]
+        if len(ks) != v.shape[0]:
+            raise ValueError("keys/vecs length mismatch")
+        arr = (C.c_char_p * len(ks))(*ks)
+        lens = (C.c_size_t * len(ks))(*[len(k) for k in ks])
+        check(self._L.ehx_set_batch(self._h, len(ks), arr, lens, pv))
+
+    def fill_synthetic(self, seed, row0, n_rows, normalize):
+        check(self._L.ehx_fill_synthetic(self._h, seed, row0, n_rows, int(bool(normalize))))
+
+    # ---- reads ----
+    def get(self, key):
+        k = key.encode() if isinstance(key, str) else bytes(key)
+        out = np.empty(self.dims, dtype=np.float32)
+        check(self._L.ehx_get(self._h, k, len(k), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def get_by_id(self, i):
+        out = np.empty(self.dims, dtype=np.float32)
+        check(self._L.ehx_get_by_id(self._h, int(i), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def key_of(self, i):
+        n = C.c_size_t()
+        buf = C.create_string_buffer(4096)
+        check(self._L.ehx_key_of(self._h, int(i), buf, 4096, C.byref(n)))
+        return buf.raw[:n.value].decode()
+
+    # ---- kNN ----
+    def knn(self, queries, k):
+        """-> ids [nq,k] u64, dist [nq,k] f32, count [nq] u32 (nearest first)."""
+        q, pq = _f32(queries)
+        q = q.reshape(-1, self.dims)
+        nq = q.shape[0]
+        ids = np.full((nq, max(k, 1)), np.uint64(2**64 - 1), dtype=np.uint64)
+        dist = np.full((nq, max(k, 1)), np.inf, dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        check(self._L.ehx_knn(self._h, nq, pq, k, ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                              dist.ctypes.data_as(C.POINTER(C.c_float)),
+                              cnt.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return ids[:, :k], dist[:, :k], cnt
+
+    def knn_keys(self, queries, k):
+        """-> list (per query) of key lists, nearest first."""
+        q, pq = _f32(queries)
+        q = q.reshape(-1, self.dims)
+        nq = q.shape[0]
+        ids = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+        dist = np.zeros((nq, max(k, 1)), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        off = np.zeros(nq * k + 1, dtype=np.uint64)
+        cap = 1 << 16
+        while True:
+            arena = C.create_string_buffer(cap)
+            rc = self._L.ehx_knn_keys(self._h, nq, pq, k, ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      dist.ctypes.data_as(C.POINTER(C.c_float)),
+                                      cnt.ctypes.data_as(C.POINTER(C.c_uint32)), arena, cap,
+                                      off.ctypes.data_as(C.POINTER(C.c_uint64)))
+            if rc == _lib.ERANGE:
+                cap *= 4
+                continue
+            check(rc)
+            break
+        raw = arena.raw
+        out = []
+        for i in range(nq):
+            out.append([raw[int(off[i * k + j]):int(off[i * k + j + 1])].decode() for j in range(int(cnt[i]))])
+        return out
+
+    def knn_by_key(self, key, k):
+        kb = key.encode() if isinstance(key, str) else bytes(key)
+        ids = np.zeros(max(k, 1), dtype=np.uint64)
+        dist = np.zeros(max(k, 1), dtype=np.float32)
+        cnt = C.c_uint32()
+        check(self._L.ehx_knn_by_key(self._h, kb, len(kb), k, ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                     dist.ctypes.data_as(C.POINTER(C.c_float)), C.byref(cnt)))
+        return ids[:cnt.value], dist[:cnt.value]
+
+    # ---- device-resident (torch tensors on the GPU) ----
+    def knn_device(self, d_queries, k, d_ids, d_dist, d_count, stream=None):
+        """All arguments are device pointers (ints) or torch CUDA tensors; enqueues on `stream`."""
+        def ptr(t):
+            return C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+        nq = d_queries.shape[0] if hasattr(d_queries, "shape") else None
+        if nq is None:
+            raise ValueError("pass torch tensors (queries [nq, dims])")
+        check(self._L.ehx_knn_device(self._h, C.c_void_p(stream or 0), nq, ptr(d_queries), k, ptr(d_ids),
+                                     ptr(d_dist), ptr(d_count)))
+
+    def stats(self):
+        st = Stats()
+        check(self._L.ehx_stats(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in Stats._fields_}
+
+    def stats_reset(self):
+        check(self._L.ehx_stats_reset(self._h))
+
+
+def nearest_neighbor_rpc(space, num, key="", embedding=None):
+    """NearestNeighbor RPC semantics of embeddinghub/embeddingstore/server.cc:172-210 over a Space.
+
+    Returns (grpc_status_code, keys): 0 OK, 3 INVALID_ARGUMENT, 5 NOT_FOUND.
+    """
+    has_key = key != ""
+    has_vec = embedding is not None and len(embedding) != 0
+    if has_key and has_vec:
+        return 3, []
+    if not has_key and not has_vec:
+        return 3, []
+    try:
+        if has_key:
+            ids, _ = space.knn_by_key(key, num)
+            return 0, [space.key_of(i) for i in ids]
+        return 0, space.knn_keys(np.asarray(embedding, dtype=np.float32), num)[0]
+    except EhxError as e:
+        if e.code == _lib.ENOTFOUND:
+            return 5, []
+        raise

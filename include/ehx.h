@@ -1,0 +1,184 @@
+/*
+ * ehx.h — C ABI of the MI355X-native nearest-neighbour engine ("ehx") that drops in behind
+ * featureform/embeddinghub's two vector-store boundaries.
+ *
+ * This header is the drop-in boundary: plain pointers and sizes, C linkage, no C++/torch
+ * types, no callbacks, and the engine never retains a caller pointer after a call returns
+ * (cgo rule).  Each entry point cites the reference interface it replaces
+ * (paths relative to the reference checkout):
+ *
+ *   embeddingstore (C++):  embeddinghub/embeddingstore/index.h:19-33, index.cc:10-52 (ANNIndex)
+ *                          embeddinghub/embeddingstore/server.cc:172-210 (NearestNeighbor RPC)
+ *                          embeddinghub/embeddingstore/embedding_store.proto:9-19 (service)
+ *   Go provider:           provider/online.go:42-70 (OnlineStore / VectorStore / VectorStoreTable /
+ *                          BatchOnlineTable), provider/redis.go:245-262,454-493
+ *   Python offline index:  embeddinghub/sdk/python/offlinehub.py:27-141
+ *
+ * INTEGRATION.md shows the cgo / C++ / ctypes stubs a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns EHX_OK (0) or a negative EHX_E* code; ehx_last_error() returns a
+ *     thread-local message for the last failing call on the calling thread;
+ *   - all entry points are re-entrant; ehx_set* is linearizable with respect to a following
+ *     ehx_knn* from the same thread (index_test.cc:39-49 relies on it);
+ *   - caller allocates every output buffer; inputs are copied before the call returns;
+ *   - ids are dense row ids in first-Set order (index.cc:24-28 labels), keys are arbitrary bytes;
+ *   - results are nearest first (index.cc:43-50 reverses hnswlib's heap for the same reason);
+ *   - all vector arithmetic runs in hand-written HIP kernels on gfx950; there is no CPU
+ *     fallback: without a usable device every compute entry point fails with EHX_ENODEVICE.
+ */
+#ifndef EHX_H_
+#define EHX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EHX_ABI_VERSION 1
+
+/* ---- error codes (shim mapping: gRPC status for contract 1, fferr type for contract 2) ---- */
+enum {
+  EHX_OK = 0,
+  EHX_EINVAL = -1,        /* INVALID_ARGUMENT (server.cc:184-188) / fferr.NewInvalidArgumentError   */
+  EHX_ENOTFOUND = -2,     /* NOT_FOUND "Not found" (server.cc:178) / DatasetNotFound, EntityNotFound */
+  EHX_EEXISTS = -3,       /* ALREADY_EXISTS / fferr.NewDatasetAlreadyExistsError (redis.go:161)       */
+  EHX_EIMMUTABLE = -4,    /* FAILED_PRECONDITION "Cannot write to immutable space" (server.cc:125-127) */
+  EHX_ENODEVICE = -5,     /* no usable gfx950 device / HIP runtime error: INTERNAL                      */
+  EHX_ENOMEM = -6,        /* RESOURCE_EXHAUSTED                                                          */
+  EHX_ERANGE = -7,        /* caller buffer too small (key arena)                                         */
+  EHX_EUNSUPPORTED = -8,  /* UNIMPLEMENTED (e.g. k above EHX_MAX_K)                                      */
+  EHX_EINTERNAL = -9
+};
+
+/* ---- metric / dtype / mode ---- */
+enum {
+  EHX_METRIC_L2SQ = 0,   /* sum (a-b)^2, no sqrt — hnswlib::L2Space, index.cc:13 (embeddingstore default) */
+  EHX_METRIC_IP = 1,     /* 1 - sum a*b   — hnswlib::InnerProductSpace                                     */
+  EHX_METRIC_COSINE = 2  /* normalise on Set and on query, then IP — Go providers (redis.go:253)           */
+};
+enum { EHX_DTYPE_F32 = 0 };
+enum {
+  EHX_MODE_FLAT = 0,  /* exhaustive scan on the matrix cores + canonical re-rank: exact kNN */
+  EHX_MODE_GRAPH = 1  /* HNSW-style level-0 best-first search over an HBM-resident graph      */
+};
+
+#define EHX_MAX_K 56u /* largest k served by one scan pass (k + slack <= 64 wave lanes) */
+
+typedef struct ehx_space ehx_space; /* opaque; owned by the process-global registry */
+
+/* Index parameters.  Zero-initialise and set what you need; 0 means "reference default"
+ * (hnswlib defaults as used by index.cc:14-15: M=16, ef_construction=200, seed=100, ef=10). */
+typedef struct ehx_params {
+  uint32_t mode;            /* EHX_MODE_*                                   */
+  uint32_t M;               /* graph degree (level 0 holds 2*M)             */
+  uint32_t ef_construction; /*                                              */
+  uint32_t ef;              /* search ef; effective ef = max(ef, k)         */
+  uint64_t seed;            /* level generator seed                         */
+  uint64_t initial_capacity;/* rows; 0 -> 128 (index.h:21), doubles on fill */
+  uint32_t reserved[8];
+} ehx_params;
+
+/* Work and time counters, same definitions as the oracle. */
+typedef struct ehx_stats_t {
+  uint64_t n_rows;           /* rows currently stored                                                */
+  uint64_t capacity;         /* rows allocated in HBM                                                */
+  uint64_t n_queries;        /* queries served since creation / last reset                           */
+  uint64_t n_dist;           /* distances actually evaluated (one per vector row fetched)            */
+  uint64_t n_hops;           /* graph nodes expanded (graph mode)                                    */
+  uint64_t n_rerank;         /* candidates re-ranked in canonical order                              */
+  uint64_t n_uncertified;    /* queries whose top-k could not be certified exact by the slack bound  */
+  uint64_t bytes_algorithmic;/* SURVEY §8d algorithmic bytes of the scans/searches served            */
+  double   last_scan_ms;     /* device time of the last scan/search kernel (HIP events)              */
+  double   last_total_ms;    /* device time of the last full ehx_knn* pipeline                       */
+  double   scan_ms_mean;     /* mean device time of the last <=64 scan/search kernel launches        */
+  uint64_t scan_launches;    /* number of launches averaged in scan_ms_mean                          */
+} ehx_stats_t;
+
+/* ---- process / device ---- */
+
+/* Once per process (idempotent).  device_ids==NULL or n_devices==0 -> device 0.  Only the first
+ * listed device is used by a space; multi-GPU sharding is one process per GPU. */
+int ehx_init(const int* device_ids, int n_devices);
+int ehx_shutdown(void);
+int ehx_abi_version(void);
+const char* ehx_last_error(void);
+
+/* ---- spaces: CreateSpace/DeleteSpace/FreezeSpace (embedding_store.proto:10-12),
+ *      VectorStore.CreateIndex/DeleteIndex + OnlineStore.CreateTable/GetTable (online.go:42-59) ---- */
+int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metric, int dtype,
+                     const ehx_params* params /* may be NULL */, ehx_space** out);
+int ehx_space_open(const char* name, size_t name_len, ehx_space** out); /* EHX_ENOTFOUND if absent */
+int ehx_space_drop(ehx_space* s);
+int ehx_space_freeze(ehx_space* s);            /* later ehx_set* -> EHX_EIMMUTABLE (version.cc:47-50) */
+int ehx_space_size(ehx_space* s, uint64_t* n); /* number of distinct keys                              */
+int ehx_space_dims(ehx_space* s, uint32_t* dims);
+int ehx_space_reserve(ehx_space* s, uint64_t rows);
+int ehx_space_set_ef(ehx_space* s, uint32_t ef);
+
+/* ---- writes: Set/MultiSet (server.cc:113-149 -> Version::set -> ANNIndex::set, index.cc:20-37),
+ *      OnlineStoreTable.Set / BatchOnlineTable.BatchSet (online.go:50-53,66-70) ---- */
+int ehx_set(ehx_space* s, const char* key, size_t klen, const float* vec /* dims floats */);
+int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t* klens,
+                  const float* vecs /* n x dims, row-major */);
+
+/* ---- reads: Get (server.cc:95-111), OnlineStoreTable.Get (online.go:52) ---- */
+int ehx_get(ehx_space* s, const char* key, size_t klen, float* out_vec /* dims floats */);
+int ehx_get_by_id(ehx_space* s, uint64_t id, float* out_vec);
+/* key of a row id: copies up to cap bytes, stores the full length in *klen */
+int ehx_key_of(ehx_space* s, uint64_t id, char* out_key, size_t cap, size_t* klen);
+
+/* ---- kNN: ANNIndex::approx_nearest (index.cc:39-52), NearestNeighbor RPC (server.cc:172-210),
+ *      VectorStoreTable.Nearest (online.go:63), offlinehub.Index.nearest_neighbor (offlinehub.py:102-131).
+ *      Batched: n_queries x dims row-major in, n_queries x k out, nearest first.
+ *      out_count[i] <= k is the number of valid results of query i (fewer than k only when the
+ *      space holds fewer than k rows — the reference has UB there, index.cc:46-50). ---- */
+int ehx_knn(ehx_space* s, size_t n_queries, const float* queries, uint32_t k, uint64_t* out_ids,
+            float* out_dist, uint32_t* out_count);
+/* as ehx_knn, plus keys: key j of query i is key_arena[key_off[i*k+j] .. key_off[i*k+j+1]) ;
+ * key_off has n_queries*k+1 entries; missing results have empty keys. */
+int ehx_knn_keys(ehx_space* s, size_t n_queries, const float* queries, uint32_t k, uint64_t* out_ids,
+                 float* out_dist, uint32_t* out_count, char* key_arena, size_t arena_cap,
+                 uint64_t* key_off);
+/* server.cc:193-207 / offlinehub.py:113-130: query by stored key, ask for k+1, drop the key
+ * itself if present else drop the last.  EHX_ENOTFOUND for an unknown key (the reference has UB). */
+int ehx_knn_by_key(ehx_space* s, const char* key, size_t klen, uint32_t k, uint64_t* out_ids,
+                   float* out_dist, uint32_t* out_count);
+
+/* ---- device-resident entry points (inputs/outputs already in HBM; `stream` is a hipStream_t
+ *      passed as void*, NULL = default stream).  These are what a batching shim and bench.py
+ *      call; ehx_knn above is ehx_knn_device plus the H2D/D2H copies. ---- */
+int ehx_knn_device(ehx_space* s, void* stream, size_t n_queries, const float* d_queries, uint32_t k,
+                   uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count);
+/* k-way merge of per-shard results (RCCL all-gather output): lists laid out
+ * [n_lists][n_queries][k]; ids must already be global.  Ordered by (dist, id). */
+int ehx_merge_topk_device(void* stream, size_t n_queries, uint32_t k, uint32_t n_lists,
+                          const uint64_t* d_ids, const float* d_dist, const uint32_t* d_count,
+                          uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count);
+
+/* ---- synthetic workload (EHX-GAUSS-1, include/ehx_datagen.h) ---- */
+/* Appends rows [row0, row0+n_rows) of dataset `seed` to the space, generated on the device;
+ * normalize!=0 L2-normalises each generated row first.  Rows get implicit decimal keys. */
+int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize);
+int ehx_gen_rows_device(void* stream, uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims,
+                        int normalize, float* d_out /* n_rows x dims */);
+
+/* ---- graph import/export (graph mode; persistence and strict-parity checks) ----
+ * level0: n x (1 + 2M) u32 rows = [count, ids...]; levels: n ints; upper lists are passed as a CSR
+ * over (node, level>=1): upper_off has n_upper+1 entries into upper_ids, upper_node/upper_level
+ * name each list. */
+int ehx_graph_import(ehx_space* s, uint64_t n, const uint32_t* level0, const int32_t* levels,
+                     uint64_t n_upper, const uint32_t* upper_node, const int32_t* upper_level,
+                     const uint64_t* upper_off, const uint32_t* upper_ids, uint32_t entry_point,
+                     int32_t max_level);
+
+/* ---- stats ---- */
+int ehx_stats(ehx_space* s, ehx_stats_t* out);
+int ehx_stats_reset(ehx_space* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EHX_H_ */

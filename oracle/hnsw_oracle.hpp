@@ -218,7 +218,7 @@ typedef std::priority_queue<std::pair<float, tableint>, std::vector<std::pair<fl
 
 // Per-caller search state: visited tags + work counters.  The index owns one
 // (used by the single-threaded build path); concurrent searchers bring their own.
-struct SearchCtx {
+struct alignas(128) SearchCtx {  // own cache lines: contexts of concurrent searchers sit in one vector
   std::vector<unsigned short> visited;
   unsigned short tag = 0;
   // SURVEY §8d work counters: n_dist = distances actually evaluated,

@@ -1,0 +1,218 @@
+"""GPU parity tests of the flat (exhaustive MFMA) kNN path, through the C ABI, against the oracle.
+
+Bar (north_star): integer ids bit-exact, distances within 1e-4 relative.  The engine's canonical
+re-rank recomputes distances in the oracle's summation order, so these tests assert BIT-EXACT
+distances as well and only fall back to the 1e-4 bound in the message.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import offline_oracle, pyoracle
+
+pytestmark = pytest.mark.gpu
+
+ehx = pytest.importorskip("embeddinghub_amd")
+from embeddinghub_amd import offlinehub  # noqa: E402
+
+METRICS = [(ehx.METRIC_L2SQ, pyoracle.METRIC_L2), (ehx.METRIC_IP, pyoracle.METRIC_IP),
+           (ehx.METRIC_COSINE, pyoracle.METRIC_COSINE)]
+
+
+def _keys(n):
+    return ["k%d" % i for i in range(n)]
+
+
+def _check(space, X, Q, k, ometric):
+    ids, dist, cnt = space.knn(Q, k)
+    oids, odist, ocnt = pyoracle.exhaustive(X, Q, k, ometric)
+    np.testing.assert_array_equal(cnt, ocnt)
+    for i in range(Q.shape[0]):
+        c = int(cnt[i])
+        assert list(ids[i, :c]) == list(oids[i, :c]), "query %d ids differ" % i
+        np.testing.assert_allclose(dist[i, :c], odist[i, :c], rtol=1e-4, atol=0)
+        assert dist[i, :c].tobytes() == odist[i, :c].tobytes(), "query %d distances not bit-exact" % i
+    return ids, dist, cnt
+
+
+# ---- reference known-answer tests through the engine --------------------------------------------
+def _abc():
+    s = ehx.Space.unique("abc", 3)
+    s.set("a", [0, 1, 0])
+    s.set("b", [1, 1, 0])
+    s.set("c", [1, 0, 0])
+    return s
+
+
+def test_simple_ann():  # index_test.cc:17-26
+    assert _abc().knn_keys([0, 1, 0], 1) == [["a"]]
+
+
+def test_multi_ann():  # index_test.cc:28-37
+    assert _abc().knn_keys([0, 1, 0], 2) == [["a", "b"]]
+
+
+def test_update_ann():  # index_test.cc:39-49
+    s = _abc()
+    s.set("a", [0, -1, 0])
+    assert s.knn_keys([0, 1, 0], 1) == [["b"]]
+    np.testing.assert_array_equal(s.get("a"), np.array([0, -1, 0], dtype=np.float32))
+
+
+def test_ann_0_items():  # index_test.cc:51-60
+    assert _abc().knn_keys([0, 1, 0], 0) == [[]]
+
+
+def test_rpc_semantics_match_oracle():  # server.cc:172-210
+    s = _abc()
+    o = pyoracle.AnnIndex(3)
+    for k, v in [("a", [0, 1, 0]), ("b", [1, 1, 0]), ("c", [1, 0, 0])]:
+        o.set(k, v)
+    cases = [dict(num=1, key="a", embedding=[0, 1, 0]), dict(num=1), dict(num=2, key="a"),
+             dict(num=2, embedding=[0, 1, 0]), dict(num=1, key="zzz"), dict(num=1, key="c")]
+    for c in cases:
+        assert ehx.nearest_neighbor_rpc(s, **c) == o.nearest_neighbor_rpc(**c), c
+
+
+def test_get_set_roundtrip_and_errors():  # version_test.cc:16-23, storage_test.cc:17-23
+    s = ehx.Space.unique("rt", 5, metric=ehx.METRIC_COSINE)
+    v = np.array([1.5, -2.25, 3.0, 0.125, 7.0], dtype=np.float32)
+    s.set("x", v)
+    np.testing.assert_array_equal(s.get("x"), v)  # cosine spaces keep the RAW vector for Get
+    with pytest.raises(ehx.EhxError) as e:
+        s.get("missing")
+    assert e.value.code == ehx._lib.ENOTFOUND
+    s.freeze()
+    with pytest.raises(ehx.EhxError) as e:  # server.cc:125-127
+        s.set("y", v)
+    assert e.value.code == ehx._lib.EIMMUTABLE and "immutable" in str(e.value)
+    with pytest.raises(ehx.EhxError) as e:
+        ehx.Space(s.name, 5)
+    assert e.value.code == ehx._lib.EEXISTS
+    assert len(ehx.Space.open(s.name)) == 1
+    s.drop()
+    with pytest.raises(ehx.EhxError):
+        ehx.Space.open(s.name)
+
+
+# ---- offlinehub_test.py against the drop-in Index ------------------------------------------------
+INIT = [("a", [1, 0]), ("b", [0, 1]), ("c", [-1, -1]), ("d", [1, 1])]
+
+
+def test_offline_index_suite():
+    index = offlinehub.Index([], 3)
+    index.set("a", [1, 2, 3])
+    assert index.get("a") == [1, 2, 3]
+    index = offlinehub.Index(INIT, 2)
+    assert index.get("a") == [1, 0]
+    assert index.nearest_neighbor(2, key="a") == ["d", "b"]  # offlinehub_test.py:63-65
+    assert index.nearest_neighbor(2, key="a") == offline_oracle.Index(INIT, 2).nearest_neighbor(2, key="a")
+    index.set("a", [5, 5])
+    assert index.get("a") == [5, 5]
+    index.multiset({"a": [3, 3], "b": [4, 4]})
+    assert index.multiget(["a", "b", "c"]) == [[3, 3], [4, 4], [-1, -1]]
+
+
+def test_offline_capacity_growth_and_total_ties():  # offlinehub_test.py:68-86
+    index = offlinehub.Index([], 2)
+    for key in list(range(1025)) * 2:
+        index.set(str(key), [1, 1])
+    assert index.size() == 1025
+    embs = [(key, [1, 1]) for key in list(range(1028)) * 2]
+    index = offlinehub.Index(embs, 2)
+    assert index.size() == 1028
+    index = offlinehub.Index([], 2)
+    for i in range(0, len(embs), 4):
+        index.multiset(embs[i:i + 4])
+    assert index.size() == 1028
+    # all 1028 distances tie at 0: exhaustive order is (dist, id) -> the first-set keys
+    assert index.nearest_neighbor(5, embedding=[1, 1]) == [0, 1, 2, 3, 4]
+
+
+# ---- Go boundary golden -----------------------------------------------------------------------------
+def test_go_vectorstore_golden(golden_dir):  # vectorstore_test.go:121-166
+    g = json.load(open(os.path.join(golden_dir, "go_vectorstore.json")))
+    X = np.array(g["vectors"], dtype=np.float32)
+    q = np.array(g["query"], dtype=np.float32)
+    s = ehx.Space.unique("go", 768, metric=ehx.METRIC_COSINE)
+    for ent, v in zip(g["entities"], X):
+        s.set(ent, v)
+        np.testing.assert_array_equal(s.get(ent), v)  # testGetSet: reflect.DeepEqual round trip
+    assert s.knn_keys(q, 2) == [["Investor's Business Daily", "Seeking Alpha"]]
+    _, dist, _ = s.knn(q, 5)
+    np.testing.assert_allclose(np.sort(dist[0]), np.sort(g["float64_cosine_distance"]), rtol=1e-5)
+    _check(s, X, q[None, :], 2, pyoracle.METRIC_COSINE)
+
+
+# ---- randomized parity vs the exhaustive oracle -------------------------------------------------------
+@pytest.mark.parametrize("n,d,nq,k", [
+    (1000, 128, 37, 10),     # ragged everything
+    (4096, 768, 256, 10),    # exact tile multiples
+    (5000, 768, 300, 10),    # BASELINE dims, two query tiles
+    (777, 3, 5, 4),          # scalar distance path (d <= 4)
+    (900, 7, 9, 3),          # SIMD4 residual path
+    (600, 19, 9, 3),         # SIMD16 residual path
+    (1200, 20, 11, 7),       # SIMD4 path (d % 4 == 0, d % 16 != 0)
+    (3000, 1536, 16, 10),    # config-5 dims
+    (300, 64, 1, 56),        # max k
+    (70000, 32, 64, 10),     # many tiles per chunk, every CU busy
+])
+@pytest.mark.parametrize("em,om", METRICS)
+def test_random_parity(n, d, nq, k, em, om):
+    rng = np.random.default_rng(n * 31 + d)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    s = ehx.Space.unique("rand", d, metric=em)
+    s.set_batch(_keys(n), X)
+    assert len(s) == n
+    _check(s, X, Q, k, om)
+    st = s.stats()
+    assert st["n_uncertified"] == 0 and st["n_rows"] == n
+    s.drop()
+
+
+def test_incremental_set_update_and_growth_match_oracle():
+    rng = np.random.default_rng(5)
+    d = 48
+    X = rng.standard_normal((700, d)).astype(np.float32)
+    s = ehx.Space.unique("inc", d)  # starts at capacity 128 (index.h:21), doubles (index.cc:29-32)
+    for i in range(300):
+        s.set("k%d" % i, X[i])
+    s.set_batch(_keys(700)[300:], X[300:])
+    # update-in-place keeps the label (index.cc:21-35)
+    X[17] = rng.standard_normal(d).astype(np.float32)
+    s.set("k17", X[17])
+    X[650] = X[3]  # exact duplicate row -> distance tie resolved by id
+    s.set("k650", X[650])
+    Q = np.concatenate([X[:4], rng.standard_normal((8, d)).astype(np.float32)])
+    _check(s, X, Q, 10, pyoracle.METRIC_L2)
+    ids, dist = s.knn_by_key("k3", 5)
+    assert 3 not in ids and ids[0] == 650 and dist[0] == 0.0
+
+
+def test_fewer_rows_than_k_and_empty_space():
+    s = ehx.Space.unique("small", 8, metric=ehx.METRIC_IP)
+    Q = np.ones((3, 8), dtype=np.float32)
+    ids, dist, cnt = s.knn(Q, 5)
+    assert list(cnt) == [0, 0, 0]
+    X = np.arange(24, dtype=np.float32).reshape(3, 8)
+    s.set_batch(_keys(3), X)
+    _check(s, X, Q, 5, pyoracle.METRIC_IP)  # count 3 < k
+    with pytest.raises(ehx.EhxError) as e:
+        s.knn(Q, 57)
+    assert e.value.code == ehx._lib.EUNSUPPORTED
+
+
+def test_nan_and_inf_rows_do_not_poison_results():
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((500, 16)).astype(np.float32)
+    X[5, 3] = np.nan
+    X[9, 1] = np.inf
+    s = ehx.Space.unique("nan", 16)
+    s.set_batch(_keys(500), X)
+    Q = rng.standard_normal((4, 16)).astype(np.float32)
+    ids, dist, cnt = s.knn(Q, 10)
+    assert (cnt == 10).all() and np.isfinite(dist).all()
+    assert 5 not in ids and 9 not in ids
