@@ -12,7 +12,7 @@ LIB = os.path.join(LIB_DIR, "libehx.so")
 SOURCES = ["ehx_api.cpp", "k_flat.hip", "k_misc.hip", "k_graph.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc", "-I", os.path.join(ROOT, "include")]
+         "-fno-gpu-rdc", "-ffp-contract=off", "-I", os.path.join(ROOT, "include")]
 
 
 def _stale():

@@ -212,7 +212,7 @@ ScanPlan plan_scan(uint32_t nq, uint64_t n, uint32_t k, int n_cus) {
   p.q_tiles = (nq + kTileQ - 1) / kTileQ;
   p.q_rows = p.q_tiles * kTileQ;
   p.n_tiles = (uint32_t)((n + kTileRows - 1) / kTileRows);
-  p.kprime = k + 8 > kCandSlots ? kCandSlots : k + 8;
+  p.kprime = k + 8;  // EHX_MAX_K + 8 = 56 < kCandSlots: a compacted candidate list always has free slots
   // one persistent workgroup per CU: grid ~= n_cus, split as q_tiles x n_chunks
   uint32_t chunks = (uint32_t)n_cus / p.q_tiles;
   if (chunks < 1) chunks = 1;
@@ -241,8 +241,8 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   if ((rc = s->dPart.ensure((size_t)p.q_rows * p.n_chunks * p.kprime))) return rc;
   if ((rc = s->dMerged.ensure((size_t)p.q_rows * 64))) return rc;
   if (!s->dUncert) {
-    HIP_TRY(hipMalloc((void**)&s->dUncert, sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(s->dUncert, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&s->dUncert, 2 * sizeof(unsigned long long)));  // [0] uncertified, [1] scan error
+    HIP_TRY(hipMemset(s->dUncert, 0, 2 * sizeof(unsigned long long)));
   }
   // scratch buffers are shared by all callers: order this pipeline after the previous one even
   // when it was enqueued on a different stream
@@ -269,6 +269,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     a.tiles_per_chunk = p.tiles_per_chunk;
     a.kprime = p.kprime;
     a.xcd_map = p.xcd_map;
+    a.err = (uint32_t*)(s->dUncert + 1);
     hipEvent_t* pr = s->ring[s->ring_count % ehx_space::kRing];
     HIP_TRY(hipEventRecord(s->ev[1], st));
     HIP_TRY(hipEventRecord(pr[0], st));
@@ -729,9 +730,10 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
   out->n_rerank = s->n_rerank;
   out->bytes_algorithmic = s->bytes_algo;
   if (s->dUncert) {
-    unsigned long long u = 0;
-    HIP_TRY(hipMemcpy(&u, s->dUncert, sizeof(u), hipMemcpyDeviceToHost));
-    out->n_uncertified = u;
+    unsigned long long u[2] = {0, 0};
+    HIP_TRY(hipMemcpy(u, s->dUncert, sizeof(u), hipMemcpyDeviceToHost));
+    out->n_uncertified = u[0];
+    if (u[1]) return fail(EHX_EINTERNAL, "scan kernel tripped its bounded-retry guard %llu times", u[1]);
   }
   if (s->ev_valid) {
     HIP_TRY(hipEventSynchronize(s->ev[3]));
@@ -761,7 +763,7 @@ int ehx_stats_reset(ehx_space* s) {
   s->n_rerank = 0;
   s->bytes_algo = 0;
   s->ring_count = 0;
-  if (s->dUncert) HIP_TRY(hipMemset(s->dUncert, 0, sizeof(unsigned long long)));
+  if (s->dUncert) HIP_TRY(hipMemset(s->dUncert, 0, 2 * sizeof(unsigned long long)));
   return EHX_OK;
 }
 

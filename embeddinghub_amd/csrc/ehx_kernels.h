@@ -7,7 +7,7 @@
 
 namespace ehx {
 
-constexpr uint32_t kTileRows = 256;   // corpus rows per scan tile
+constexpr uint32_t kTileRows = 128;   // corpus rows per scan tile
 constexpr uint32_t kTileQ = 256;      // queries per scan tile
 constexpr uint32_t kBK = 32;          // k-depth of one LDS stage (floats)
 constexpr uint32_t kCandSlots = 64;   // per-(query, block) candidate slots = one wave row
@@ -34,19 +34,30 @@ __host__ __device__ inline float ordered_to_f32(uint32_t o) {
 #endif
 }
 
+// Exactly-rounded single operations for the canonical (oracle-order) arithmetic.  HIP's
+// __fmul_rn/__fadd_rn are plain * and + (contractible) and __fsqrt_rn is the approximate native
+// sqrt, so they are NOT used; the library is built with -ffp-contract=off and relies on hipcc's
+// default -fhip-fp32-correctly-rounded-divide-sqrt for / and sqrt.
+__device__ __forceinline__ float ex_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float ex_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float ex_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float ex_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float ex_sqrt(float a) { return __builtin_sqrtf(a); }
+
 struct ScanArgs {
   const float* Q;        // [q_tiles*256][ld] prepared queries (zero padded)
-  const float* X;        // [cap][ld] stored rows, cap % 256 == 0, pad columns zero
+  const float* X;        // [cap][ld] stored rows, cap % 256 == 0 (>= n_tiles*128), pad columns zero
   const float2* rowp;    // [cap] epilogue (a, b): approx distance = dot*a + b
   uint64_t* cand;        // [grid][256][64] per-block candidate slots (scratch)
   uint64_t* part;        // [q_tiles*256][n_chunks][kprime] sorted partial top-k' keys
   uint32_t n;            // valid rows
   uint32_t ld;           // row stride in floats, % 32 == 0
-  uint32_t n_tiles;      // ceil(n / 256)
+  uint32_t n_tiles;      // ceil(n / 128)
   uint32_t q_tiles;
   uint32_t n_chunks;
   uint32_t tiles_per_chunk;
   uint32_t kprime;       // <= 64
+  uint32_t* err;         // device error counter (bounded-retry guard tripped)
   uint32_t xcd_map;      // 1: blocks of one chunk share an XCD (grid % 8 == 0, n_chunks % 8 == 0)
 };
 

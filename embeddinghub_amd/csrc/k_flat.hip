@@ -4,21 +4,21 @@
 // hnswlib (searchKnn -> fstdistfunc_, call site embeddinghub/embeddingstore/index.cc:41): the
 // B x N query-by-row distance matrix is a dense contraction, so it runs on
 // v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain) and is never materialised: each
-// 256x256 tile is filtered in registers against per-query running thresholds and only the
-// survivors reach a per-query candidate list.  A canonical re-rank (k_rerank below) then
-// recomputes the surviving distances in exactly the oracle's (hnswlib SSE) summation order, so
-// ids and distances are bit-identical to the exhaustive oracle.
+// 128(rows) x 256(queries) tile is filtered in registers against per-query running thresholds and
+// only the survivors reach a per-query candidate list.  A canonical re-rank (rerank_kernel below)
+// then recomputes the surviving distances in exactly the oracle's (hnswlib SSE) summation order,
+// so ids and distances are bit-identical to the exhaustive oracle.
 //
 // Layout / mapping (gfx950, wave64):
-//   * workgroup = 256 threads = 4 waves = one 256(rows) x 256(queries) tile, 1 workgroup per CU,
-//     one wave per SIMD with the whole 512-entry register file: wave (wr, wc) = (w>>1, w&1) owns
-//     128 rows x 128 queries = 4x4 MFMA 32x32 blocks (256 accumulator registers).  fp32 MFMA
-//     issues every 64 cycles with 64-cycle dependent latency, so 16 independent accumulators from
+//   * workgroup = 256 threads = 4 waves, one per SIMD, 1 workgroup per CU; wave (wr, wc) =
+//     (w>>1, w&1) owns 64 rows x 128 queries = 2x4 MFMA 32x32 blocks = 128 accumulator registers
+//     (AGPRs), leaving the whole architectural VGPR file to fragments and the epilogue.  fp32 MFMA
+//     issues every 64 cycles with 64-cycle dependent latency, so 8 independent accumulators from
 //     one wave keep the SIMD's matrix pipe saturated;
 //   * MFMA A = corpus rows, B = queries, so a lane's 16 accumulator values of one block all belong
-//     to ONE query (col = lane&31) -> one threshold compare per value, one threshold per block;
-//   * both operand tiles ([256][32] fp32 = 32 KiB each) are staged by global_load_lds (16 B/lane,
-//     no VGPR round trip) into a double buffer; the 16-B chunk index of a row is XOR-swizzled with
+//     to ONE query (col = lane&31) -> one threshold per block;
+//   * both operand tiles ([128|256][32] fp32) are staged by global_load_lds (16 B/lane, no VGPR
+//     round trip) into a double buffer; the 16-B chunk index of a row is XOR-swizzled with
 //     (row>>1)&7 on the SOURCE address and on the ds_read_b128 side (LDS image stays lane-linear),
 //     which makes the fragment reads bank-conflict free;
 //   * a lane's ds_read_b128 gives 4 consecutive k for its (row, k-half); MFMA step t of a group
@@ -38,14 +38,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int kThreads = 256;
-constexpr uint32_t kStageBytes = kTileRows * kBK * 4;             // 32 KiB per operand tile
+constexpr uint32_t kXStage = kTileRows * kBK * 4;                  // 16 KiB
+constexpr uint32_t kQStage = kTileQ * kBK * 4;                     // 32 KiB
 constexpr uint32_t kXOff = 0;                                      // Xs[2]
-constexpr uint32_t kQOff = 2 * kStageBytes;                        // Qs[2]
-constexpr uint32_t kThrKeyOff = 4 * kStageBytes;                   // u64 thr_key[256]
+constexpr uint32_t kQOff = 2 * kXStage;                            // Qs[2]
+constexpr uint32_t kThrKeyOff = kQOff + 2 * kQStage;               // u64 thr_key[256]
 constexpr uint32_t kThrFOff = kThrKeyOff + 256 * 8;                // f32 thr_f[256]
 constexpr uint32_t kCntOff = kThrFOff + 256 * 4;                   // i32 cnt[256]
 constexpr uint32_t kFlagOff = kCntOff + 256 * 4;                   // i32 flags[4]
 constexpr uint32_t kLdsBytes = kFlagOff + 16;
+static_assert(kTileRows == 128 && kTileQ == 256 && kBK == 32, "kernel geometry is hard-wired");
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -81,6 +83,8 @@ __device__ __forceinline__ uint64_t wave_bitonic_merge64(uint64_t key, int lane)
   return key;
 }
 
+#define EHX_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
+
 }  // namespace
 
 size_t scan_lds_bytes() { return kLdsBytes; }
@@ -112,11 +116,9 @@ __global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a
   int* flags = (int*)(smem + kFlagOff);
   uint64_t* cand = a.cand + (size_t)blockIdx.x * (256u * kCandSlots);
 
-  if (tid < 256) {
-    thr_key[tid] = kKeyInf;
-    thr_f[tid] = __builtin_inff();
-    cnt[tid] = 0;
-  }
+  thr_key[tid] = kKeyInf;
+  thr_f[tid] = __builtin_inff();
+  cnt[tid] = 0;
   if (tid < 4) flags[tid] = 0;
 
   const uint32_t tile_begin = chunk * a.tiles_per_chunk;
@@ -126,31 +128,22 @@ __global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a
   const uint32_t ktiles = a.ld / kBK;
   const uint32_t total_steps = my_tiles * ktiles;
 
-  // ---- per-lane constants for the staging loads (8 X + 8 Q glds per wave per stage) ----
-  // instruction `ins` (0..31) covers tile rows ins*8 .. ins*8+7; lane L -> row ins*8+(L>>3),
-  // physical 16-B chunk p = L&7, logical chunk c = p ^ ((row>>1)&7).
+  // ---- per-lane constants for the staging loads ----
+  // One global_load_lds instruction moves 8 tile rows x 128 B: lane L -> row ins*8+(L>>3), physical
+  // 16-B chunk p = L&7, logical chunk c = p ^ ((row>>1)&7).  Per stage a wave issues 4 X
+  // instructions (ins = w*4+u) and 8 Q instructions (ins = w*8+u).
   const float* Qtile = a.Q + (size_t)qt * kTileQ * a.ld;
-  uint32_t st_off[8];  // float offset of this lane's source within a tile (row*ld + c*4)
+  uint32_t stx_off[4], stq_off[8];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t row = ((uint32_t)w * 4 + u) * 8 + (lane >> 3);
+    stx_off[u] = row * a.ld + (((lane & 7) ^ ((row >> 1) & 7)) * 4);
+  }
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    const uint32_t ins = (uint32_t)w * 8 + u;
-    const uint32_t row = ins * 8 + (lane >> 3);
-    const uint32_t c = (lane & 7) ^ ((row >> 1) & 7);
-    st_off[u] = row * a.ld + c * 4;
+    const uint32_t row = ((uint32_t)w * 8 + u) * 8 + (lane >> 3);
+    stq_off[u] = row * a.ld + (((lane & 7) ^ ((row >> 1) & 7)) * 4);
   }
-
-  auto stage = [&](uint32_t step) {
-    const uint32_t t = step / ktiles, kt = step - t * ktiles;
-    const uint32_t buf = step & 1;
-    const float* Xt = a.X + (size_t)(tile_begin + t) * kTileRows * a.ld + kt * kBK;
-    const float* Qt = Qtile + kt * kBK;
-    char* xs = smem + kXOff + buf * kStageBytes + (uint32_t)w * 8192;
-    char* qs = smem + kQOff + buf * kStageBytes + (uint32_t)w * 8192;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) glds16(Xt + st_off[u], xs + u * 1024);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) glds16(Qt + st_off[u], qs + u * 1024);
-  };
 
   // ---- per-lane constants for the fragment reads ----
   // row r = base + i31 ; chunk for group j = (2j+h) ^ ((r>>1)&7) = (2j) ^ hs, hs = h ^ ((i31>>1)&7)
@@ -158,74 +151,180 @@ __global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a
   uint32_t joff[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) joff[j] = (((uint32_t)(2 * j)) ^ hs) * 16;
-  const uint32_t a_row_off = (uint32_t)(wr * 128 + i31) * 128;  // + rb*32*128
-  const uint32_t b_row_off = (uint32_t)(wc * 128 + i31) * 128;  // + cb*32*128
+  const uint32_t a_row_off = (uint32_t)(wr * 64 + i31) * 128;   // + rb*4096
+  const uint32_t b_row_off = (uint32_t)(wc * 128 + i31) * 128;  // + cb*4096
 
-  f32x16 acc[4][4];
+  f32x16 acc[2][4];
 #pragma unroll
-  for (int rb = 0; rb < 4; ++rb)
+  for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
 
-  if (total_steps > 0) stage(0);
+  // ---- software-pipelined main loop -------------------------------------------------------
+  // A stage (one BK=32 slice of both operand tiles) is consumed as 4 groups of 32 MFMAs; the
+  // fragments of group g+1 are read from LDS into the idle register set while group g's MFMAs
+  // issue, and the single workgroup barrier per stage plus the staging loads of stage s+2 sit
+  // inside stage s's last group, so the matrix pipe does not wait for LDS latency or DMA issue.
+  f32x4 fa0[2], fb0[4], fa1[2], fb1[4];
+
+#define EHX_GROUP(A, B, An, Bn, XS, QS)                                   \
+  do {                                                                    \
+    An[0] = *(const f32x4*)((XS));                                        \
+    An[1] = *(const f32x4*)((XS) + 4096);                                 \
+    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                   \
+      acc[0][cb] = EHX_MFMA(A[0][0], B[cb][0], acc[0][cb]);               \
+      acc[1][cb] = EHX_MFMA(A[1][0], B[cb][0], acc[1][cb]);               \
+    }                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    Bn[0] = *(const f32x4*)((QS));                                        \
+    Bn[1] = *(const f32x4*)((QS) + 4096);                                 \
+    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                   \
+      acc[0][cb] = EHX_MFMA(A[0][1], B[cb][1], acc[0][cb]);               \
+      acc[1][cb] = EHX_MFMA(A[1][1], B[cb][1], acc[1][cb]);               \
+    }                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    Bn[2] = *(const f32x4*)((QS) + 2 * 4096);                             \
+    Bn[3] = *(const f32x4*)((QS) + 3 * 4096);                             \
+    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                   \
+      acc[0][cb] = EHX_MFMA(A[0][2], B[cb][2], acc[0][cb]);               \
+      acc[1][cb] = EHX_MFMA(A[1][2], B[cb][2], acc[1][cb]);               \
+    }                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                   \
+      acc[0][cb] = EHX_MFMA(A[0][3], B[cb][3], acc[0][cb]);               \
+      acc[1][cb] = EHX_MFMA(A[1][3], B[cb][3], acc[1][cb]);               \
+    }                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+  } while (0)
+
+  if (total_steps > 0) {
+    {  // stage 0 -> buffer 0
+      const float* Xt = a.X + (size_t)tile_begin * kTileRows * a.ld;
+      char* gxs = smem + kXOff + (uint32_t)w * 4096;
+      char* gqs = smem + kQOff + (uint32_t)w * 8192;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) glds16(Xt + stx_off[u], gxs + u * 1024);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) glds16(Qtile + stq_off[u], gqs + u * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    fa0[0] = *(const f32x4*)(smem + kXOff + a_row_off + joff[0]);
+    fa0[1] = *(const f32x4*)(smem + kXOff + a_row_off + 4096 + joff[0]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) fb0[c] = *(const f32x4*)(smem + kQOff + b_row_off + c * 4096 + joff[0]);
+    if (total_steps > 1) {  // stage 1 -> buffer 1
+      const uint32_t nt = 1u / ktiles, nkt = 1u - nt * ktiles;
+      const float* Xt = a.X + (size_t)(tile_begin + nt) * kTileRows * a.ld + nkt * kBK;
+      const float* Qt = Qtile + nkt * kBK;
+      char* gxs = smem + kXOff + kXStage + (uint32_t)w * 4096;
+      char* gqs = smem + kQOff + kQStage + (uint32_t)w * 8192;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) glds16(Xt + stx_off[u], gxs + u * 1024);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) glds16(Qt + stq_off[u], gqs + u * 1024);
+    }
+  }
 
   uint32_t kt = 0, t = 0;
   for (uint32_t step = 0; step < total_steps; ++step) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (step + 1 < total_steps) stage(step + 1);
-
-    const char* xs = smem + kXOff + (step & 1) * kStageBytes + a_row_off;
-    const char* qs = smem + kQOff + (step & 1) * kStageBytes + b_row_off;
+    const uint32_t buf = step & 1;
+    const char* xs = smem + kXOff + buf * kXStage + a_row_off;
+    const char* qs = smem + kQOff + buf * kQStage + b_row_off;
+    const char* xn = smem + kXOff + (buf ^ 1) * kXStage + a_row_off;
+    const char* qn = smem + kQOff + (buf ^ 1) * kQStage + b_row_off;
+    EHX_GROUP(fa0, fb0, fa1, fb1, xs + joff[1], qs + joff[1]);
+    EHX_GROUP(fa1, fb1, fa0, fb0, xs + joff[2], qs + joff[2]);
+    EHX_GROUP(fa0, fb0, fa1, fb1, xs + joff[3], qs + joff[3]);
+    // ---- last group of the stage (fragments in set 1) with the hand-over inside ----
+    const bool has_next = step + 1 < total_steps;
+    const bool has_next2 = step + 2 < total_steps;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 av[4], bv[4];
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) av[rb] = *(const f32x4*)(xs + rb * 4096 + joff[j]);
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) bv[cb] = *(const f32x4*)(qs + cb * 4096 + joff[j]);
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int cb = 0; cb < 4; ++cb)
-            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rb][tt], bv[cb][tt], acc[rb][cb], 0, 0, 0);
+    for (int cb = 0; cb < 4; ++cb) {
+      acc[0][cb] = EHX_MFMA(fa1[0][0], fb1[cb][0], acc[0][cb]);
+      acc[1][cb] = EHX_MFMA(fa1[1][0], fb1[cb][0], acc[1][cb]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // stage s+1 has landed (issued a whole stage ago) and every wave has finished reading stage s
+    // (its last fragments were fetched during group 2): one barrier, then refill buffer `buf`.
+    if (has_next) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      fa0[0] = *(const f32x4*)(xn + joff[0]);
+      fa0[1] = *(const f32x4*)(xn + 4096 + joff[0]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) fb0[c] = *(const f32x4*)(qn + c * 4096 + joff[0]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      acc[0][cb] = EHX_MFMA(fa1[0][1], fb1[cb][1], acc[0][cb]);
+      acc[1][cb] = EHX_MFMA(fa1[1][1], fb1[cb][1], acc[1][cb]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t nstep = step + 2;
+    const uint32_t nt = has_next2 ? nstep / ktiles : 0u;
+    const uint32_t nkt = has_next2 ? nstep - nt * ktiles : 0u;
+    const float* Xt = a.X + (size_t)(tile_begin + nt) * kTileRows * a.ld + nkt * kBK;
+    const float* Qt = Qtile + nkt * kBK;
+    char* gxs = smem + kXOff + buf * kXStage + (uint32_t)w * 4096;
+    char* gqs = smem + kQOff + buf * kQStage + (uint32_t)w * 8192;
+    if (has_next2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) glds16(Xt + stx_off[u], gxs + u * 1024);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) glds16(Qt + stq_off[u], gqs + u * 1024);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      acc[0][cb] = EHX_MFMA(fa1[0][2], fb1[cb][2], acc[0][cb]);
+      acc[1][cb] = EHX_MFMA(fa1[1][2], fb1[cb][2], acc[1][cb]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next2) {
+#pragma unroll
+      for (int u = 2; u < 4; ++u) glds16(Xt + stx_off[u], gxs + u * 1024);
+#pragma unroll
+      for (int u = 4; u < 8; ++u) glds16(Qt + stq_off[u], gqs + u * 1024);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      acc[0][cb] = EHX_MFMA(fa1[0][3], fb1[cb][3], acc[0][cb]);
+      acc[1][cb] = EHX_MFMA(fa1[1][3], fb1[cb][3], acc[1][cb]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     if (++kt == ktiles) {
       kt = 0;
       // ================= tile epilogue: threshold filter + candidate append =================
-      // Phase 1 (branch-free, fully unrolled): turn every accumulator into its approximate
-      // distance s = dot*a_row + b_row IN PLACE and record "s <= threshold of its query" as one
-      // bit per value (8 words x 32 bits per lane; word = rb*2 + (cb>>1), bit = (cb&1)*16 + reg).
-      // Phase 2 (rare, loops): only lanes with set bits extract the value with a select chain
-      // and append (score,id) keys to the query's candidate slots.
+      // Phase 1 (branch-free, fully unrolled): approximate distance s = dot*a_row + b_row of every
+      // accumulator, recorded only as one bit "s <= threshold of its query" (4 words x 32 bits per
+      // lane; word = rb*2 + (cb>>1), bit = (cb&1)*16 + reg).  The accumulators are left untouched.
+      // Phase 2 (rare, loops): only lanes with set bits extract the dot product with a select
+      // chain, recompute s with the same fma, and append (score,id) keys to the candidate slots.
       const uint32_t tile_row0 = (tile_begin + t) * kTileRows;
       const int qbase = wc * 128 + i31;
-      uint32_t pend[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+      uint32_t pend[4] = {0u, 0u, 0u, 0u};
       {
         float thrf[4];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) thrf[cb] = thr_f[qbase + cb * 32];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
+        for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg) {
-            const uint32_t r = (uint32_t)(wr * 128 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
+            const uint32_t r = (uint32_t)(wr * 64 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
             const float2 ab = a.rowp[tile_row0 + r];
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
               const float sc = __builtin_fmaf(acc[rb][cb][reg], ab.x, ab.y);
-              acc[rb][cb][reg] = sc;
               pend[rb * 2 + (cb >> 1)] |= (sc <= thrf[cb]) ? (1u << ((cb & 1) * 16 + reg)) : 0u;
             }
           }
         }
       }
-      const bool lane_any = (pend[0] | pend[1] | pend[2] | pend[3] | pend[4] | pend[5] | pend[6] | pend[7]) != 0u;
+      const bool lane_any = (pend[0] | pend[1] | pend[2] | pend[3]) != 0u;
       // block-uniform decision (LDS flag) so every wave takes the same barrier path
       if (lane_any) flags[1] = 1;
       __syncthreads();
@@ -233,24 +332,28 @@ __global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a
       __syncthreads();
       if (tile_hot) {
         if (tid == 0) flags[1] = 0;
-        for (;;) {
+        // kprime < kCandSlots guarantees progress (a compacted list has free slots); the round
+        // bound only turns a logic error into an error code instead of a hung GPU
+        for (int round = 0;; ++round) {
 #pragma unroll
-          for (int wd = 0; wd < 8; ++wd) {
+          for (int wd = 0; wd < 4; ++wd) {
             const int rb = wd >> 1, cp = wd & 1;
             uint32_t retry = 0u;
             while (__any(pend[wd] != 0u)) {
               if (pend[wd] != 0u) {
                 const int b = __builtin_ctz(pend[wd]);
                 pend[wd] &= pend[wd] - 1u;
-                float sc = 0.0f;
+                float dot = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sc = (b == i) ? acc[rb][2 * cp][i] : sc;
+                for (int i = 0; i < 16; ++i) dot = (b == i) ? acc[rb][2 * cp][i] : dot;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sc = (b == 16 + i) ? acc[rb][2 * cp + 1][i] : sc;
+                for (int i = 0; i < 16; ++i) dot = (b == 16 + i) ? acc[rb][2 * cp + 1][i] : dot;
                 const int reg = b & 15;
                 const int cb = 2 * cp + (b >> 4);
-                const uint32_t r = (uint32_t)(wr * 128 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
+                const uint32_t r = (uint32_t)(wr * 64 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
                 const uint32_t grow = tile_row0 + r;
+                const float2 ab = a.rowp[grow];
+                const float sc = __builtin_fmaf(dot, ab.x, ab.y);
                 const int q = qbase + cb * 32;
                 const uint64_t key = ((uint64_t)f32_to_ordered(sc) << 32) | grow;
                 if (grow < a.n && key < thr_key[q]) {
@@ -295,12 +398,16 @@ __global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a
           }
           __syncthreads();
           if (!overflow) break;
+          if (round >= 512) {
+            if (tid == 0) atomicAdd(a.err, 1u);
+            break;
+          }
           if (tid == 0) flags[0] = 0;
           __syncthreads();
         }
       }
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
+      for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
@@ -308,6 +415,7 @@ __global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a
       ++t;
     }
   }
+#undef EHX_GROUP
 
   // ---- final: sort every query's slots and publish the top-k' keys of this chunk ----
   __syncthreads();
@@ -378,36 +486,36 @@ __device__ __forceinline__ float canon_dist(int metric, const float* __restrict_
   float part = 0.0f;
   if (metric == 0) {
     for (uint32_t m = sub; m < body; m += 4) {
-      const float xv = scale_x ? __fmul_rn(x[m], xscale) : x[m];
-      const float diff = __fsub_rn(q[m], xv);
-      part = __fadd_rn(part, __fmul_rn(diff, diff));
+      const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
+      const float diff = ex_sub(q[m], xv);
+      part = ex_add(part, ex_mul(diff, diff));
     }
   } else {
     for (uint32_t m = sub; m < body; m += 4) {
-      const float xv = scale_x ? __fmul_rn(x[m], xscale) : x[m];
-      part = __fadd_rn(part, __fmul_rn(q[m], xv));
+      const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
+      part = ex_add(part, ex_mul(q[m], xv));
     }
   }
   // horizontal sum in lane order within the 4-lane group
   const float t1 = __shfl_down(part, 1, 4), t2 = __shfl_down(part, 2, 4), t3 = __shfl_down(part, 3, 4);
-  float res = __fadd_rn(__fadd_rn(__fadd_rn(part, t1), t2), t3);
+  float res = ex_add(ex_add(ex_add(part, t1), t2), t3);
   if (body != dims) {
     float tail = 0.0f;
     if (metric == 0) {
       for (uint32_t m = body; m < dims; ++m) {
-        const float xv = scale_x ? __fmul_rn(x[m], xscale) : x[m];
-        const float diff = __fsub_rn(q[m], xv);
-        tail = __fadd_rn(tail, __fmul_rn(diff, diff));
+        const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
+        const float diff = ex_sub(q[m], xv);
+        tail = ex_add(tail, ex_mul(diff, diff));
       }
     } else {
       for (uint32_t m = body; m < dims; ++m) {
-        const float xv = scale_x ? __fmul_rn(x[m], xscale) : x[m];
-        tail = __fadd_rn(tail, __fmul_rn(q[m], xv));
+        const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
+        tail = ex_add(tail, ex_mul(q[m], xv));
       }
     }
-    res = body ? __fadd_rn(res, tail) : tail;
+    res = body ? ex_add(res, tail) : tail;
   }
-  if (metric != 0) res = __fsub_rn(1.0f, res);
+  if (metric != 0) res = ex_sub(1.0f, res);
   return res;  // valid in sub-lane 0
 }
 }  // namespace
@@ -446,15 +554,24 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
     }
     if (tid == 0) a.out_count[q] = cnt;
     // certification: every row that is NOT a candidate has approx score >= the worst candidate's
-    // approx score A_last.  If A_last - margin > exact k-th distance, no outsider can beat the
-    // k-th result, so the top-k is provably the exhaustive top-k.  (Skipped when all rows of the
-    // space are candidates.)
+    // approx score A_last (for L2 the scan's score omits |q|^2, added back here).  If
+    // A_last - margin > exact k-th distance, no outsider can beat the k-th result, so the top-k is
+    // provably the exhaustive top-k.  margin bounds the fp32 rounding gap between the MFMA-order
+    // score and the canonical-order distance.  (Skipped when every row is a candidate.)
     if (a.n > a.kprime && cnt == a.k && a.k > 0) {
       float worst = -__builtin_inff();
       for (int j = 0; j < 64; ++j)
         if (approx[j] != __builtin_inff() && approx[j] > worst) worst = approx[j];
+      float qn = 0.0f;
+      if (a.metric == 0) {
+        const float* qv = a.Q + (size_t)q * a.ld;
+        for (uint32_t m = tid; m < a.dims; m += 64) qn += qv[m] * qv[m];
+        for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o, 64);
+        worst += qn;
+      }
       const float kth = ordered_to_f32((uint32_t)(__shfl(key, (int)a.k - 1, 64) >> 32));
-      const float margin = 4e-6f * (fabsf(kth) > 1.0f ? fabsf(kth) : 1.0f);
+      const float scale = fmaxf(fmaxf(fabsf(kth), fabsf(worst)), fmaxf(qn, 1.0f));
+      const float margin = 1e-5f * scale;
       if (tid == 0 && !(worst - margin > kth)) atomicAdd(a.n_uncertified, 1ull);
     }
   }

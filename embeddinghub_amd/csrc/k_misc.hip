@@ -13,11 +13,11 @@ namespace {
 // one thread walks one row sequentially: the summation ORDER is the contract here
 __device__ __forceinline__ float seq_sumsq(const float* __restrict__ x, uint32_t dims) {
   float s = 0.0f;
-  for (uint32_t i = 0; i < dims; ++i) s = __fadd_rn(s, __fmul_rn(x[i], x[i]));
+  for (uint32_t i = 0; i < dims; ++i) s = ex_add(s, ex_mul(x[i], x[i]));
   return s;
 }
 __device__ __forceinline__ float inv_norm_of(float sumsq) {
-  return __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(sumsq), 1e-30f));
+  return ex_div(1.0f, ex_add(ex_sqrt(sumsq), 1e-30f));
 }
 }  // namespace
 
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restric
   }
   for (uint32_t i = lane; i < ld; i += 64) {
     float v = i < dims ? in[i] : 0.0f;
-    if (metric == 2) v = __fmul_rn(v, inv);
+    if (metric == 2) v = ex_mul(v, inv);
     out[i] = v;
   }
 }
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void normalize_rows_kernel(uint64_t n_rows, uin
   float v = 0.0f;
   if (lane == 0) v = inv_norm_of(seq_sumsq(row, dims));
   const float inv = __shfl(v, 0, 64);
-  for (uint32_t i = lane; i < dims; i += 64) row[i] = __fmul_rn(row[i], inv);
+  for (uint32_t i = lane; i < dims; i += 64) row[i] = ex_mul(row[i], inv);
 }
 
 // faster variant for big fills: 64 rows per wave, 64x64 tiles transposed through LDS so global
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void normalize_rows_tiled_kernel(uint64_t n_row
     __syncthreads();
     if ((uint64_t)lane < rows) {
       const uint32_t lim = dims - c0 < 64 ? dims - c0 : 64;
-      for (uint32_t c = 0; c < lim; ++c) s = __fadd_rn(s, __fmul_rn(tile[lane][c], tile[lane][c]));
+      for (uint32_t c = 0; c < lim; ++c) s = ex_add(s, ex_mul(tile[lane][c], tile[lane][c]));
     }
     __syncthreads();
   }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64) void normalize_rows_tiled_kernel(uint64_t n_row
     const float rinv = __shfl(inv, (int)rr, 64);
     for (uint32_t c = lane; c < dims; c += 64) {
       float* p = x + (r0 + rr) * ld + c;
-      *p = __fmul_rn(*p, rinv);
+      *p = ex_mul(*p, rinv);
     }
   }
 }

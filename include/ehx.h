@@ -65,7 +65,7 @@ enum {
   EHX_MODE_GRAPH = 1  /* HNSW-style level-0 best-first search over an HBM-resident graph      */
 };
 
-#define EHX_MAX_K 56u /* largest k served by one scan pass (k + slack <= 64 wave lanes) */
+#define EHX_MAX_K 48u /* largest k served by one scan pass (k + 8 slack < 64 candidate slots) */
 
 typedef struct ehx_space ehx_space; /* opaque; owned by the process-global registry */
 

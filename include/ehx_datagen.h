@@ -15,7 +15,9 @@
  *   SINCOS: Taylor polynomials in a^2 (sin to a^15, cos to a^16), Horner with fma
  *
  * Every step is a single IEEE-754 fp32 operation or an explicit fma, so host and device
- * produce bit-identical values (no libm).  Cosine workloads L2-normalise each row with the
+ * produce bit-identical values (no libm).  Translation units that include this header MUST be
+ * compiled with -ffp-contract=off (HIP's __fmul_rn/__fadd_rn are plain * and + and would be
+ * contracted; __fsqrt_rn is the approximate native sqrt — neither is used here).  Cosine workloads L2-normalise each row with the
  * hnswlib-python convention: norm = 1/(sqrt(sum_i x_i^2) + 1e-30f) (sequential fp32 sum,
  * non-fused), x_i *= norm.  Corpus seed 20250211, query seed 20250212.
  *
@@ -72,35 +74,35 @@ EHX_HD u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
 
 EHX_HD float f_fma(float a, float b, float c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __fmaf_rn(a, b, c);
+  return __builtin_fmaf(a, b, c);
 #else
   return fmaf(a, b, c);
 #endif
 }
 EHX_HD float f_mul(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __fmul_rn(a, b);
+  return a * b; /* never contracted: built with -ffp-contract=off */
 #else
   return a * b;
 #endif
 }
 EHX_HD float f_add(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __fadd_rn(a, b);
+  return a + b;
 #else
   return a + b;
 #endif
 }
 EHX_HD float f_sqrt(float a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __fsqrt_rn(a);
+  return __builtin_sqrtf(a); /* correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt) */
 #else
   return sqrtf(a);
 #endif
 }
 EHX_HD float f_div(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __fdiv_rn(a, b);
+  return a / b; /* correctly rounded, same flag */
 #else
   return a / b;
 #endif

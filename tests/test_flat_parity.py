@@ -156,7 +156,7 @@ def test_go_vectorstore_golden(golden_dir):  # vectorstore_test.go:121-166
     (600, 19, 9, 3),         # SIMD16 residual path
     (1200, 20, 11, 7),       # SIMD4 path (d % 4 == 0, d % 16 != 0)
     (3000, 1536, 16, 10),    # config-5 dims
-    (300, 64, 1, 56),        # max k
+    (300, 64, 1, 48),        # max k
     (70000, 32, 64, 10),     # many tiles per chunk, every CU busy
 ])
 @pytest.mark.parametrize("em,om", METRICS)
@@ -201,7 +201,7 @@ def test_fewer_rows_than_k_and_empty_space():
     s.set_batch(_keys(3), X)
     _check(s, X, Q, 5, pyoracle.METRIC_IP)  # count 3 < k
     with pytest.raises(ehx.EhxError) as e:
-        s.knn(Q, 57)
+        s.knn(Q, 49)
     assert e.value.code == ehx._lib.EUNSUPPORTED
 
 
