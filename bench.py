@@ -104,11 +104,9 @@ def main():
     dev = (C.c_int * 1)(local_rank)
     _lib.check(L.ehx_init(dev, 1))
 
+    from embeddinghub_amd.sharded import shard_range
     G = world
-    shard = args.rows // G
-    row0 = rank * shard
-    if rank == G - 1:
-        shard = args.rows - row0
+    row0, shard = shard_range(args.rows, G, rank)
     B, d, k = args.batch, args.dims, args.k
     t_fill = time.time()
     space = ehx.Space("bench-r%d" % rank, d, metric=ehx.METRIC_COSINE, initial_capacity=shard)
@@ -122,28 +120,11 @@ def main():
     for i in range(n_batches):  # distinct query batches, resident in HBM before the timed region
         _lib.check(L.ehx_gen_rows_device(C.c_void_p(stream), ehx.SEED_QUERY, i * B, B, d, 1,
                                          C.c_void_p(queries[i].data_ptr())))
-    ids = torch.empty((B, k), dtype=torch.int64, device="cuda")
-    dst = torch.empty((B, k), dtype=torch.float32, device="cuda")
-    cnt = torch.empty((B,), dtype=torch.int32, device="cuda")
-    if G > 1:
-        g_ids = torch.empty((G, B, k), dtype=torch.int64, device="cuda")
-        g_dst = torch.empty((G, B, k), dtype=torch.float32, device="cuda")
-        g_cnt = torch.empty((G, B), dtype=torch.int32, device="cuda")
-        m_ids = torch.empty((B, k), dtype=torch.int64, device="cuda")
-        m_dst = torch.empty((B, k), dtype=torch.float32, device="cuda")
-        m_cnt = torch.empty((B,), dtype=torch.int32, device="cuda")
+    from embeddinghub_amd.sharded import ShardedSearcher
+    searcher = ShardedSearcher(row0, B, k, "cuda", space=space, stream=stream)
 
     def step(i):
-        space.knn_device(queries[i], k, ids, dst, cnt, stream=stream)
-        if G > 1:
-            ids.add_(row0)  # local row id -> global id
-            dist.all_gather_into_tensor(g_ids, ids)
-            dist.all_gather_into_tensor(g_dst, dst)
-            dist.all_gather_into_tensor(g_cnt, cnt)
-            _lib.check(L.ehx_merge_topk_device(C.c_void_p(stream), B, k, G, C.c_void_p(g_ids.data_ptr()),
-                                               C.c_void_p(g_dst.data_ptr()), C.c_void_p(g_cnt.data_ptr()),
-                                               C.c_void_p(m_ids.data_ptr()), C.c_void_p(m_dst.data_ptr()),
-                                               C.c_void_p(m_cnt.data_ptr())))
+        searcher.knn(queries[i])
 
     def barrier():
         if G > 1:

@@ -216,3 +216,39 @@ def test_nan_and_inf_rows_do_not_poison_results():
     ids, dist, cnt = s.knn(Q, 10)
     assert (cnt == 10).all() and np.isfinite(dist).all()
     assert 5 not in ids and 9 not in ids
+
+
+# ---- BASELINE-size properties (size-independent checks at the bench workload's shape) -------------
+def test_full_size_split_invariance_and_sample_vs_oracle():
+    """1M x 768 cosine, batch 1024 (BASELINE config 2): (a) kNN over the whole index == merge of the
+    kNN over two half indexes (ids are row ids of the same EHX-GAUSS-1 rows); (b) results sorted by
+    (dist, id); (c) a sample of queries against the oracle's exhaustive scan of oracle-generated rows."""
+    n, d, nq, k = 1_000_000, 768, 1024, 10
+    whole = ehx.Space.unique("full", d, metric=ehx.METRIC_COSINE, initial_capacity=n)
+    whole.fill_synthetic(ehx.SEED_CORPUS, 0, n, True)
+    lo = ehx.Space.unique("lo", d, metric=ehx.METRIC_COSINE, initial_capacity=n // 2)
+    lo.fill_synthetic(ehx.SEED_CORPUS, 0, n // 2, True)
+    hi = ehx.Space.unique("hi", d, metric=ehx.METRIC_COSINE, initial_capacity=n // 2)
+    hi.fill_synthetic(ehx.SEED_CORPUS, n // 2, n // 2, True)
+    Q = pyoracle.gen_rows(ehx.SEED_QUERY, 0, nq, d, normalize=True)
+    ids, dist, cnt = whole.knn(Q, k)
+    ids_lo, dist_lo, _ = lo.knn(Q, k)
+    ids_hi, dist_hi, _ = hi.knn(Q, k)
+    assert (cnt == k).all() and whole.stats()["n_uncertified"] == 0
+    for i in range(nq):
+        cand = sorted(zip(dist_lo[i].tolist() + dist_hi[i].tolist(),
+                          ids_lo[i].tolist() + (ids_hi[i] + n // 2).tolist()))[:k]
+        assert [c[1] for c in cand] == ids[i].tolist(), i
+        assert np.array([c[0] for c in cand], dtype=np.float32).tobytes() == dist[i].tobytes()
+        assert all((dist[i, j], ids[i, j]) <= (dist[i, j + 1], ids[i, j + 1]) for j in range(k - 1))
+    # oracle on a sample: 8 queries x the first 200k rows (regenerated on the host, bit-identical)
+    m = 200_000
+    Xs = pyoracle.gen_rows(ehx.SEED_CORPUS, 0, m, d, normalize=True)
+    sub = ehx.Space.unique("sub", d, metric=ehx.METRIC_COSINE, initial_capacity=m)
+    sub.fill_synthetic(ehx.SEED_CORPUS, 0, m, True)
+    sids, sdist, _ = sub.knn(Q[:8], k)
+    oids, odist, _ = pyoracle.exhaustive(Xs, Q[:8], k, pyoracle.METRIC_COSINE)
+    np.testing.assert_array_equal(sids, oids)
+    assert sdist.tobytes() == odist.tobytes()
+    for s in (whole, lo, hi, sub):
+        s.drop()

@@ -1,0 +1,120 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the row-shard / all-gather / merge plumbing
+(embeddinghub_amd/sharded.py) with the two device steps replaced by oracle-backed stand-ins, checked
+against the oracle's exhaustive search over the whole index; plus the GPU merge kernel vs numpy."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from embeddinghub_amd.sharded import ShardedSearcher, shard_range
+from oracle import pyoracle
+
+N, D, B, K = 2003, 24, 37, 10
+
+
+def _data():
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    X[1500] = X[3]  # cross-shard exact tie -> (dist, id) order decides
+    Q = np.concatenate([X[:5], rng.standard_normal((B - 5, D)).astype(np.float32)])
+    return X, Q
+
+
+def _np_merge(g_ids, g_dist, g_count, k, out_ids, out_dist, out_count):
+    G, nq = g_ids.shape[0], g_ids.shape[1]
+    for q in range(nq):
+        items = []
+        for g in range(G):
+            c = int(g_count[g, q])
+            items += [(float(g_dist[g, q, j]), int(g_ids[g, q, j])) for j in range(c)]
+        items.sort()
+        c = min(k, len(items))
+        out_count[q] = c
+        for j in range(c):
+            out_dist[q, j], out_ids[q, j] = items[j]
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X, Q = _data()
+    row0, rows = shard_range(N, world, rank)
+    Xs = X[row0:row0 + rows]
+
+    def local_search(queries, k, ids, dst, cnt):
+        i, d, c = pyoracle.exhaustive(Xs, queries.numpy(), k, pyoracle.METRIC_L2, threads=1)
+        ids.copy_(torch.from_numpy(i.astype(np.int64)))
+        dst.copy_(torch.from_numpy(d))
+        cnt.copy_(torch.from_numpy(c.astype(np.int32)))
+
+    s = ShardedSearcher(row0, B, K, "cpu", local_search=local_search, merge=_np_merge)
+    ids, dst, cnt = s.knn(torch.from_numpy(Q))
+    ret[rank] = (ids.numpy().copy(), dst.numpy().copy(), cnt.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_every_row_once():
+    for n, w in [(10_000_000, 8), (2003, 2), (7, 8), (50_000_000, 8)]:
+        ranges = [shard_range(n, w, r) for r in range(w)]
+        assert ranges[0][0] == 0 and sum(r[1] for r in ranges) == n
+        for (a0, a1), (b0, _) in zip(ranges, ranges[1:]):
+            assert a0 + a1 == b0
+
+
+def test_two_rank_gloo_matches_global_exhaustive():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    X, Q = _data()
+    oids, odist, ocnt = pyoracle.exhaustive(X, Q, K, pyoracle.METRIC_L2)
+    for rank in (0, 1):  # every rank holds the merged result
+        ids, dst, cnt = ret[rank]
+        np.testing.assert_array_equal(cnt, ocnt.astype(np.int32))
+        np.testing.assert_array_equal(ids, oids.astype(np.int64))
+        assert dst.tobytes() == odist.tobytes()
+    assert 3 in ret[0][0][3] and 1500 in ret[0][0][3]  # the cross-shard tie, id order
+
+
+@pytest.mark.gpu
+def test_gpu_merge_kernel_matches_numpy():
+    import ctypes as C
+    from embeddinghub_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(3)
+    G, nq, k = 8, 129, 10
+    g_dist = np.sort(rng.standard_normal((G, nq, k)).astype(np.float32), axis=2)
+    g_dist[:, :, 3] = g_dist[:, :, 2]  # ties inside and across lists
+    g_dist[1, :, :4] = g_dist[0, :, :4]
+    g_ids = rng.permutation(G * nq * k).reshape(G, nq, k).astype(np.int64)
+    # lists must be (dist, id)-sorted, as ehx_knn emits them
+    for g in range(G):
+        for q in range(nq):
+            order = np.lexsort((g_ids[g, q], g_dist[g, q]))
+            g_dist[g, q], g_ids[g, q] = g_dist[g, q][order], g_ids[g, q][order]
+    g_cnt = rng.integers(0, k + 1, size=(G, nq)).astype(np.int32)
+    g_cnt[:, 0] = 0  # a query nobody has results for
+    e_ids, e_dist, e_cnt = np.full((nq, k), -1, np.int64), np.full((nq, k), np.inf, np.float32), np.zeros(nq, np.int32)
+    _np_merge(g_ids, g_dist, g_cnt, k, e_ids, e_dist, e_cnt)
+    t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    d_ids, d_dist, d_cnt = t(g_ids), t(g_dist), t(g_cnt)
+    o_ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    o_dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    o_cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    _lib.check(L.ehx_merge_topk_device(C.c_void_p(torch.cuda.current_stream().cuda_stream), nq, k, G,
+                                       C.c_void_p(d_ids.data_ptr()), C.c_void_p(d_dist.data_ptr()),
+                                       C.c_void_p(d_cnt.data_ptr()), C.c_void_p(o_ids.data_ptr()),
+                                       C.c_void_p(o_dist.data_ptr()), C.c_void_p(o_cnt.data_ptr())))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(o_cnt.cpu().numpy(), e_cnt)
+    for q in range(nq):
+        c = e_cnt[q]
+        np.testing.assert_array_equal(o_ids.cpu().numpy()[q, :c], e_ids[q, :c])
+        np.testing.assert_array_equal(o_dist.cpu().numpy()[q, :c], e_dist[q, :c])
