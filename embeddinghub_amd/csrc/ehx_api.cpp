@@ -96,6 +96,16 @@ struct ehx_space {
   float* dInv = nullptr;     // [cap] (cosine)
   uint64_t cap = 0, n = 0;
 
+  // graph (graph mode): imported adjacency, re-laid-out for the GPU (k_graph.hip)
+  uint32_t* dAdj0 = nullptr;     // [g_n][2M]
+  uint32_t* dUpStart = nullptr;  // [g_n]
+  uint32_t* dUpLists = nullptr;  // [*][M]
+  uint64_t g_n = 0;              // rows covered by the graph (0 = no graph)
+  uint32_t g_entry = 0;
+  int g_maxlevel = -1;
+  DevBuf<uint32_t> dVisited;
+  unsigned long long* dGraphCounters = nullptr;  // n_dist, n_hops0, n_hops_up
+
   // key map (explicit keys only)
   std::unordered_map<std::string, uint64_t> key_to_id;
   std::vector<std::string> id_to_key;
@@ -124,6 +134,11 @@ struct ehx_space {
     if (dX) (void)hipFree(dX);
     if (dRowp) (void)hipFree(dRowp);
     if (dInv) (void)hipFree(dInv);
+    if (dAdj0) (void)hipFree(dAdj0);
+    if (dUpStart) (void)hipFree(dUpStart);
+    if (dUpLists) (void)hipFree(dUpLists);
+    if (dGraphCounters) (void)hipFree(dGraphCounters);
+    dVisited.release();
     dQraw.release();
     dQ.release();
     dCand.release();
@@ -225,14 +240,74 @@ ScanPlan plan_scan(uint32_t nq, uint64_t n, uint32_t k, int n_cus) {
   return p;
 }
 
+// graph pipeline: prepared queries -> zero visited bitmaps -> one-wave-per-query search
+int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k, uint64_t* d_ids,
+                     float* d_dist, uint32_t* d_count) {
+  if (s->g_n != s->n)
+    return fail(EHX_EUNSUPPORTED,
+                "graph mode: the graph covers %llu of %llu rows (import a graph with ehx_graph_import; "
+                "GPU-side insertion is not built yet)",
+                (unsigned long long)s->g_n, (unsigned long long)s->n);
+  uint32_t ef = s->params.ef > k ? s->params.ef : k;  // searchKnn: max(ef_, k)
+  if (ef > 4096) return fail(EHX_EUNSUPPORTED, "ef=%u exceeds 4096", ef);
+  const uint32_t q_rows = (uint32_t)nq;
+  int rc;
+  if ((rc = s->dQ.ensure((size_t)q_rows * s->ld))) return rc;
+  const uint32_t vis_words = (uint32_t)((s->n + 31) / 32);
+  if ((rc = s->dVisited.ensure((size_t)nq * vis_words))) return rc;
+  if (!s->dGraphCounters) {
+    HIP_TRY(hipMalloc((void**)&s->dGraphCounters, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(s->dGraphCounters, 0, 3 * sizeof(unsigned long long)));
+  }
+  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
+  HIP_TRY(hipEventRecord(s->ev[0], st));
+  HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, q_rows, s->metric, s->dQ.p, st));
+  HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, (size_t)nq * vis_words * sizeof(uint32_t), st));
+  GraphArgs a;
+  a.Q = s->dQ.p;
+  a.X = s->dX;
+  a.inv_norm = s->dInv;
+  a.adj0 = s->dAdj0;
+  a.up_start = s->dUpStart;
+  a.up_lists = s->dUpLists;
+  a.visited = s->dVisited.p;
+  a.out_ids = d_ids;
+  a.out_dist = d_dist;
+  a.out_count = d_count;
+  a.counters = s->dGraphCounters;
+  a.nq = (uint32_t)nq;
+  a.k = k;
+  a.ef = ef;
+  a.ef_cap = ef;
+  a.n = (uint32_t)s->n;
+  a.dims = s->dims;
+  a.ld = s->ld;
+  a.M = s->params.M;
+  a.M0 = 2 * s->params.M;
+  a.vis_words = vis_words;
+  a.entry_point = s->g_entry;
+  a.max_level = s->g_maxlevel;
+  a.metric = s->metric;
+  hipEvent_t* pr = s->ring[s->ring_count % ehx_space::kRing];
+  HIP_TRY(hipEventRecord(s->ev[1], st));
+  HIP_TRY(hipEventRecord(pr[0], st));
+  HIP_TRY(launch_graph_search(a, st));
+  HIP_TRY(hipEventRecord(pr[1], st));
+  HIP_TRY(hipEventRecord(s->ev[2], st));
+  s->ring_count++;
+  HIP_TRY(hipEventRecord(s->ev[3], st));
+  s->ev_valid = true;
+  s->n_queries += nq;
+  return EHX_OK;
+}
+
 // device pipeline: prepared queries -> scan -> merge -> canonical re-rank
 int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k,
                       uint64_t* d_ids, float* d_dist, uint32_t* d_count) {
   if (k == 0 || nq == 0) return EHX_OK;
   if (k > EHX_MAX_K) return fail(EHX_EUNSUPPORTED, "k=%u exceeds EHX_MAX_K=%u", k, EHX_MAX_K);
   if (nq > (1u << 24)) return fail(EHX_EINVAL, "too many queries in one call: %zu", nq);
-  if (s->params.mode != EHX_MODE_FLAT)
-    return fail(EHX_EUNSUPPORTED, "graph-mode search is not available in this build");
+  if (s->params.mode == EHX_MODE_GRAPH) return knn_graph_locked(s, st, nq, d_queries, k, d_ids, d_dist, d_count);
   Engine& E = engine();
   const ScanPlan p = plan_scan((uint32_t)nq, s->n, k, E.n_cus);
   int rc;
@@ -712,10 +787,70 @@ int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_ro
   return EHX_OK;
 }
 
-int ehx_graph_import(ehx_space* s, uint64_t, const uint32_t*, const int32_t*, uint64_t, const uint32_t*,
-                     const int32_t*, const uint64_t*, const uint32_t*, uint32_t, int32_t) {
+int ehx_graph_import(ehx_space* s, uint64_t n, const uint32_t* level0, const int32_t* levels, uint64_t n_upper,
+                     const uint32_t* upper_node, const int32_t* upper_level, const uint64_t* upper_off,
+                     const uint32_t* upper_ids, uint32_t entry_point, int32_t max_level) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
-  return fail(EHX_EUNSUPPORTED, "graph mode is not available in this build");
+  std::unique_lock<std::shared_mutex> wl(s->mu);
+  if (s->params.mode != EHX_MODE_GRAPH) return fail(EHX_EINVAL, "space '%s' is not in graph mode", s->name.c_str());
+  if (n != s->n) return fail(EHX_EINVAL, "graph has %llu nodes but the space holds %llu rows", (unsigned long long)n,
+                             (unsigned long long)s->n);
+  if (n == 0) return EHX_OK;
+  if (!level0 || !levels || (n_upper && (!upper_node || !upper_level || !upper_off || !upper_ids)))
+    return fail(EHX_EINVAL, "NULL argument");
+  if (entry_point >= n || max_level < 0) return fail(EHX_EINVAL, "bad entry point / max level");
+  const uint32_t M = s->params.M, M0 = 2 * M;
+  if (M0 > 64) return fail(EHX_EUNSUPPORTED, "M=%u: level-0 degree exceeds one wave", M);
+  HIP_TRY(hipSetDevice(engine().device));
+  // host-side re-layout (pure index shuffling, no vector arithmetic)
+  std::vector<uint32_t> adj((size_t)n * M0, 0xFFFFFFFFu), up_start(n, 0xFFFFFFFFu);
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint32_t* row = level0 + i * (1 + M0);
+    const uint32_t c = row[0];
+    if (c > M0) return fail(EHX_EINVAL, "node %llu: level-0 degree %u > %u", (unsigned long long)i, c, M0);
+    for (uint32_t j = 0; j < c; ++j) {
+      if (row[1 + j] >= n) return fail(EHX_EINVAL, "node %llu: neighbour id out of range", (unsigned long long)i);
+      adj[i * M0 + j] = row[1 + j];
+    }
+  }
+  uint64_t total_lists = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (levels[i] < 0 || levels[i] > max_level) return fail(EHX_EINVAL, "node %llu: bad level", (unsigned long long)i);
+    if (levels[i] > 0) {
+      up_start[i] = (uint32_t)total_lists;
+      total_lists += (uint64_t)levels[i];
+    }
+  }
+  std::vector<uint32_t> lists((size_t)(total_lists ? total_lists : 1) * M, 0xFFFFFFFFu);
+  for (uint64_t u = 0; u < n_upper; ++u) {
+    const uint32_t node = upper_node[u];
+    const int32_t lv = upper_level[u];
+    if (node >= n || lv < 1 || lv > levels[node]) return fail(EHX_EINVAL, "upper list %llu: bad node/level", (unsigned long long)u);
+    const uint64_t c = upper_off[u + 1] - upper_off[u];
+    if (c > M) return fail(EHX_EINVAL, "upper list %llu: degree %llu > %u", (unsigned long long)u, (unsigned long long)c, M);
+    uint32_t* dst = &lists[((size_t)up_start[node] + (uint32_t)(lv - 1)) * M];
+    for (uint64_t j = 0; j < c; ++j) {
+      const uint32_t v = upper_ids[upper_off[u] + j];
+      if (v >= n) return fail(EHX_EINVAL, "upper list %llu: neighbour id out of range", (unsigned long long)u);
+      dst[j] = v;
+    }
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  if (s->dAdj0) (void)hipFree(s->dAdj0);
+  if (s->dUpStart) (void)hipFree(s->dUpStart);
+  if (s->dUpLists) (void)hipFree(s->dUpLists);
+  s->dAdj0 = s->dUpStart = s->dUpLists = nullptr;
+  s->g_n = 0;
+  HIP_TRY(hipMalloc((void**)&s->dAdj0, adj.size() * 4));
+  HIP_TRY(hipMalloc((void**)&s->dUpStart, up_start.size() * 4));
+  HIP_TRY(hipMalloc((void**)&s->dUpLists, lists.size() * 4));
+  HIP_TRY(hipMemcpy(s->dAdj0, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->dUpStart, up_start.data(), up_start.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->dUpLists, lists.data(), lists.size() * 4, hipMemcpyHostToDevice));
+  s->g_n = n;
+  s->g_entry = entry_point;
+  s->g_maxlevel = max_level;
+  return EHX_OK;
 }
 
 int ehx_stats(ehx_space* s, ehx_stats_t* out) {
@@ -729,6 +864,14 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
   out->n_dist = s->n_dist;
   out->n_rerank = s->n_rerank;
   out->bytes_algorithmic = s->bytes_algo;
+  if (s->dGraphCounters) {
+    unsigned long long g[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpy(g, s->dGraphCounters, sizeof(g), hipMemcpyDeviceToHost));
+    out->n_dist += g[0];
+    out->n_hops = g[1] + g[2];
+    // n_dist*d*4 + n_hops0*(4+4*2M) + n_hops_up*(4+4*M)
+    out->bytes_algorithmic += g[0] * s->dims * 4ull + g[1] * (4ull + 8ull * s->params.M) + g[2] * (4ull + 4ull * s->params.M);
+  }
   if (s->dUncert) {
     unsigned long long u[2] = {0, 0};
     HIP_TRY(hipMemcpy(u, s->dUncert, sizeof(u), hipMemcpyDeviceToHost));
@@ -764,6 +907,7 @@ int ehx_stats_reset(ehx_space* s) {
   s->bytes_algo = 0;
   s->ring_count = 0;
   if (s->dUncert) HIP_TRY(hipMemset(s->dUncert, 0, 2 * sizeof(unsigned long long)));
+  if (s->dGraphCounters) HIP_TRY(hipMemset(s->dGraphCounters, 0, 3 * sizeof(unsigned long long)));
   return EHX_OK;
 }
 

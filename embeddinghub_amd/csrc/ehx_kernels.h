@@ -44,6 +44,57 @@ __device__ __forceinline__ float ex_mul(float a, float b) { return a * b; }
 __device__ __forceinline__ float ex_div(float a, float b) { return a / b; }
 __device__ __forceinline__ float ex_sqrt(float a) { return __builtin_sqrtf(a); }
 
+// Canonical distance between a prepared query and a stored row, in exactly the order of hnswlib's SSE
+// kernels (space_l2.h / space_ip.h; oracle/hnsw_oracle.hpp restates them): 4 strided partial sums
+// over the multiple-of-4 body (multiply and add NOT fused), horizontal sum t0+t1+t2+t3 left to
+// right, scalar tail added afterwards.  Executed by a 4-lane group: lane `sub` plays SSE lane `sub`;
+// all 4 lanes of the group must be active.  metric01: 0 = L2^2, 1 = 1 - inner product.  For cosine
+// the stored row is normalised on the fly (x * inv_norm, one rounding — hnswlib-python's
+// normalize_vector) and the query arrives normalised.  Result valid in sub-lane 0.
+__device__ __forceinline__ float canon_dist(int metric, const float* __restrict__ q,
+                                            const float* __restrict__ x, float xscale, bool scale_x,
+                                            uint32_t dims, int sub) {
+  uint32_t body;
+  if ((dims & 15u) == 0 || (dims & 3u) == 0) body = dims;
+  else if (dims > 16) body = dims & ~15u;
+  else if (dims > 4) body = dims & ~3u;
+  else body = 0;
+  float part = 0.0f;
+  if (metric == 0) {
+    for (uint32_t m = sub; m < body; m += 4) {
+      const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
+      const float diff = ex_sub(q[m], xv);
+      part = ex_add(part, ex_mul(diff, diff));
+    }
+  } else {
+    for (uint32_t m = sub; m < body; m += 4) {
+      const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
+      part = ex_add(part, ex_mul(q[m], xv));
+    }
+  }
+  // horizontal sum in lane order within the 4-lane group
+  const float t1 = __shfl_down(part, 1, 4), t2 = __shfl_down(part, 2, 4), t3 = __shfl_down(part, 3, 4);
+  float res = ex_add(ex_add(ex_add(part, t1), t2), t3);
+  if (body != dims) {
+    float tail = 0.0f;
+    if (metric == 0) {
+      for (uint32_t m = body; m < dims; ++m) {
+        const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
+        const float diff = ex_sub(q[m], xv);
+        tail = ex_add(tail, ex_mul(diff, diff));
+      }
+    } else {
+      for (uint32_t m = body; m < dims; ++m) {
+        const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
+        tail = ex_add(tail, ex_mul(q[m], xv));
+      }
+    }
+    res = body ? ex_add(res, tail) : tail;
+  }
+  if (metric != 0) res = ex_sub(1.0f, res);
+  return res;  // valid in sub-lane 0
+}
+
 struct ScanArgs {
   const float* Q;        // [q_tiles*256][ld] prepared queries (zero padded)
   const float* X;        // [cap][ld] stored rows, cap % 256 == 0 (>= n_tiles*128), pad columns zero
@@ -96,6 +147,25 @@ hipError_t launch_rowp_pad(float2* rowp, uint64_t row0, uint64_t n, hipStream_t 
 // EHX-GAUSS-1 rows generated straight into a [*, ld] matrix (optionally L2-normalised)
 hipError_t launch_gen_rows(uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims, uint32_t ld,
                            int normalize, float* out, hipStream_t st);
+
+// graph-mode search (k_graph.hip): one wave per query
+struct GraphArgs {
+  const float* Q;           // prepared queries [nq][ld]
+  const float* X;           // rows [cap][ld]
+  const float* inv_norm;    // cosine
+  const uint32_t* adj0;     // [n][M0], pad 0xFFFFFFFF, stored order
+  const uint32_t* up_start; // [n]: first upper list of the node (levels 1..L consecutive) or ~0
+  const uint32_t* up_lists; // [*][M], pad 0xFFFFFFFF
+  uint32_t* visited;        // [nq][vis_words], zeroed before the launch
+  uint64_t* out_ids;        // [nq][k]
+  float* out_dist;
+  uint32_t* out_count;
+  unsigned long long* counters;  // n_dist, n_hops0, n_hops_up
+  uint32_t nq, k, ef, ef_cap, n, dims, ld, M, M0, vis_words, entry_point;
+  int max_level, metric;
+};
+size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap);
+hipError_t launch_graph_search(const GraphArgs& a, hipStream_t st);
 
 // k-way merge of per-shard (dist, id) result lists [n_lists][nq][k] -> [nq][k]
 hipError_t launch_merge_lists(const uint64_t* ids, const float* dist, const uint32_t* count,

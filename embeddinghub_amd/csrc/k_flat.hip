@@ -474,52 +474,6 @@ hipError_t launch_flat_merge(const uint64_t* part, uint32_t nq, uint32_t n_chunk
 // and add NOT fused), horizontal sum t0+t1+t2+t3 left to right, scalar tail added afterwards.
 // One 4-lane group per candidate; lane j of the group plays SSE lane j.
 // ---------------------------------------------------------------------------------------------
-namespace {
-__device__ __forceinline__ float canon_dist(int metric, const float* __restrict__ q,
-                                            const float* __restrict__ x, float xscale, bool scale_x,
-                                            uint32_t dims, int sub) {
-  uint32_t body;
-  if ((dims & 15u) == 0 || (dims & 3u) == 0) body = dims;
-  else if (dims > 16) body = dims & ~15u;
-  else if (dims > 4) body = dims & ~3u;
-  else body = 0;
-  float part = 0.0f;
-  if (metric == 0) {
-    for (uint32_t m = sub; m < body; m += 4) {
-      const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
-      const float diff = ex_sub(q[m], xv);
-      part = ex_add(part, ex_mul(diff, diff));
-    }
-  } else {
-    for (uint32_t m = sub; m < body; m += 4) {
-      const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
-      part = ex_add(part, ex_mul(q[m], xv));
-    }
-  }
-  // horizontal sum in lane order within the 4-lane group
-  const float t1 = __shfl_down(part, 1, 4), t2 = __shfl_down(part, 2, 4), t3 = __shfl_down(part, 3, 4);
-  float res = ex_add(ex_add(ex_add(part, t1), t2), t3);
-  if (body != dims) {
-    float tail = 0.0f;
-    if (metric == 0) {
-      for (uint32_t m = body; m < dims; ++m) {
-        const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
-        const float diff = ex_sub(q[m], xv);
-        tail = ex_add(tail, ex_mul(diff, diff));
-      }
-    } else {
-      for (uint32_t m = body; m < dims; ++m) {
-        const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
-        tail = ex_add(tail, ex_mul(q[m], xv));
-      }
-    }
-    res = body ? ex_add(res, tail) : tail;
-  }
-  if (metric != 0) res = ex_sub(1.0f, res);
-  return res;  // valid in sub-lane 0
-}
-}  // namespace
-
 __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
   __shared__ uint64_t keys[64];
   __shared__ float approx[64];

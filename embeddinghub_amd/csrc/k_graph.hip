@@ -1,4 +1,241 @@
-// Graph-mode kernels (HNSW-style level-0 best-first search over an HBM-resident graph).
-// Placeholder translation unit: the flat (exhaustive) path is built first; see DESIGN.md.
+// Graph-mode search: HNSW-style greedy descent + level-0 best-first search over an HBM-resident
+// graph, one wavefront per query.
+//
+// Replaces hnswlib::HierarchicalNSW::searchKnn / searchBaseLayerST (call site
+// embeddinghub/embeddingstore/index.cc:41; algorithm restated in oracle/hnsw_oracle.hpp):
+//   * upper levels maxlevel..1: greedy descent — scan the current node's list in stored order and
+//     move to the FIRST strictly-closest neighbour, repeat until no improvement;
+//   * level 0: best-first search bounded by ef.  hnswlib keeps two heaps (candidates, results) and a
+//     lowerBound; here ONE sorted list R of at most ef (distance, id, expanded) keys lives in LDS:
+//     the next node to expand is the closest unexpanded entry of R, the search ends when R has no
+//     unexpanded entry.  This is equivalent to the two-heap formulation whenever distances are
+//     distinct: every candidate is inserted into the result heap at the same moment, a candidate
+//     evicted from the results has distance >= lowerBound and can never be expanded, and processing a
+//     node's neighbours as one batch (R <- ef smallest of R u batch) keeps exactly the elements the
+//     one-by-one insertion keeps.
+//
+// Layout re-designed for the GPU (SURVEY Appendix A.3 describes hnswlib's AoS element block):
+//   * adj0[n][2M] u32, padded with 0xFFFFFFFF, stored order preserved: one 128-B line per expansion;
+//   * upper levels: up_start[n] (index of the node's first upper list or ~0), up_lists[*][M];
+//   * vectors stay in the space's row-major X; distances use the canonical (oracle-order)
+//     arithmetic of canon_dist, 16 neighbours per pass (one 4-lane group each), so on an imported
+//     graph the traversal, the returned ids and the distances are bit-identical to the oracle;
+//   * visited set: one bit per row per in-flight query in HBM (n/8 bytes per query — 1.25 MB at 10 M
+//     rows, 1.3 GB for a 1024-query batch out of 288 GB), test-and-set with atomicOr;
+//   * work counters as SURVEY §8d: n_dist = rows actually fetched, n_hops0 / n_hops_up = expansions.
 #include "ehx_kernels.h"
-namespace ehx {}
+
+namespace ehx {
+
+namespace {
+
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint64_t wave_sort64g(uint64_t key, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint64_t other = __shfl_xor(key, j, 64);
+      const bool up = (lane & k) == 0;
+      const bool lower = (lane & j) == 0;
+      const uint64_t mn = key < other ? key : other;
+      const uint64_t mx = key < other ? other : key;
+      key = (lower == up) ? mn : mx;
+    }
+  }
+  return key;
+}
+
+// number of entries of the ascending array a[0..n) that are < key
+__device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* a, uint32_t n, uint64_t key) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+}  // namespace
+
+// LDS: q[ld] floats | R[ef_cap] u64 | R2[ef_cap] u64 | batch[64] u64 | ids[64] u32
+size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap) { return (size_t)ld * 4 + (size_t)ef_cap * 16 + 64 * 8 + 64 * 4; }
+
+__global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const uint32_t qi = blockIdx.x;
+  float* qs = (float*)smem;
+  uint64_t* R = (uint64_t*)(smem + (size_t)a.ld * 4);
+  uint64_t* R2 = R + a.ef_cap;
+  uint64_t* batch = R2 + a.ef_cap;
+  uint32_t* ids_l = (uint32_t*)(batch + 64);
+  uint32_t* vis = a.visited + (size_t)qi * a.vis_words;
+
+  for (uint32_t i = lane; i < a.ld; i += 64) qs[i] = a.Q[(size_t)qi * a.ld + i];
+  __syncthreads();
+
+  const int g = lane >> 2, sub = lane & 3;
+  const int metric01 = a.metric == 0 ? 0 : 1;
+  const bool scale_x = a.metric == 2;
+  unsigned long long n_dist = 0, n_hops0 = 0, n_hops_up = 0;
+
+  // distance of up to 16 rows (ids_l[base + g]) per pass; result for group g in every lane of g
+  auto pass_dist = [&](uint32_t base, uint32_t count) -> float {
+    const bool act = base + (uint32_t)g < count;
+    const uint32_t id = act ? ids_l[base + g] : 0u;
+    const float* xv = a.X + (size_t)id * a.ld;
+    const float xs = scale_x ? a.inv_norm[id] : 1.0f;
+    float d = canon_dist(metric01, qs, xv, xs, scale_x, a.dims, sub);
+    d = __shfl(d, lane & ~3, 64);
+    return act ? d : __builtin_inff();
+  };
+
+  // ---- entry point ----
+  uint32_t cur = a.entry_point;
+  if (lane == 0) ids_l[0] = cur;
+  __syncthreads();
+  float curdist = __shfl(pass_dist(0, 1), 0, 64);
+  n_dist += 1;
+
+  // ---- upper levels: greedy descent ----
+  for (int level = a.max_level; level >= 1; --level) {
+    bool changed = true;
+    while (changed) {
+      changed = false;
+      const uint32_t us = a.up_start[cur];
+      const uint32_t* lst = a.up_lists + ((size_t)us + (uint32_t)(level - 1)) * a.M;
+      uint32_t nb = kNoNode;
+      if (lane < (int)a.M) nb = lst[lane];
+      const uint64_t vmask = __ballot(nb != kNoNode);
+      const uint32_t cnt = __builtin_popcountll(vmask);  // lists are packed from slot 0
+      n_hops_up += 1;
+      if (lane < (int)cnt) ids_l[lane] = nb;
+      __syncthreads();
+      n_dist += cnt;
+      uint32_t best_i = kNoNode;
+      float best_d = curdist;
+      for (uint32_t base = 0; base < cnt; base += 16) {
+        const float d = pass_dist(base, cnt);
+        // first strictly-smaller minimum in stored order
+        float m = d;
+        uint32_t mi = base + g;
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) {
+          const float od = __shfl_xor(m, o, 64);
+          const uint32_t oi = __shfl_xor(mi, o, 64);
+          if (od < m || (od == m && oi < mi)) {
+            m = od;
+            mi = oi;
+          }
+        }
+        if (m < best_d) {
+          best_d = m;
+          best_i = mi;
+        }
+      }
+      if (best_i != kNoNode) {
+        curdist = best_d;
+        cur = ids_l[best_i];
+        changed = true;
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- level 0: best-first, ef bounded ----
+  const uint32_t ef = a.ef;
+  uint32_t nR = 1;
+  if (lane == 0) {
+    R[0] = ((uint64_t)f32_to_ordered(curdist) << 32) | ((uint64_t)cur << 1);
+    atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+  }
+  __syncthreads();
+  for (;;) {
+    // closest unexpanded entry
+    uint32_t idx = kNoNode;
+    for (uint32_t base = 0; base < nR && idx == kNoNode; base += 64) {
+      const uint32_t i = base + lane;
+      const bool un = i < nR && !(R[i] & 1ull);
+      const uint64_t m = __ballot(un);
+      if (m) idx = base + (uint32_t)__builtin_ctzll(m);
+    }
+    if (idx == kNoNode) break;
+    const uint32_t c = (uint32_t)(R[idx] & 0xFFFFFFFFull) >> 1;
+    __syncthreads();
+    if (lane == 0) R[idx] |= 1ull;
+    n_hops0 += 1;
+    // neighbours (stored order), visited test-and-set
+    uint32_t nb = kNoNode;
+    if (lane < (int)a.M0) nb = a.adj0[(size_t)c * a.M0 + lane];
+    bool fresh = false;
+    if (nb != kNoNode) {
+      const uint32_t bit = 1u << (nb & 31);
+      fresh = !(atomicOr(&vis[nb >> 5], bit) & bit);
+    }
+    const uint64_t fmask = __ballot(fresh);
+    const uint32_t nfresh = __builtin_popcountll(fmask);
+    if (fresh) ids_l[__builtin_popcountll(fmask & ((1ull << lane) - 1ull))] = nb;
+    __syncthreads();
+    if (nfresh == 0) continue;
+    n_dist += nfresh;
+    // distances, 16 rows per pass; lane p (< nfresh) ends up owning key p
+    uint64_t mykey = kKeyInf;
+    for (uint32_t base = 0; base < nfresh; base += 16) {
+      const float d = pass_dist(base, nfresh);
+      // group g's distance -> lane base+g
+      const float dg = __shfl(d, ((lane - (int)base) & 15) << 2, 64);
+      if ((uint32_t)lane >= base && (uint32_t)lane < base + 16 && (uint32_t)lane < nfresh)
+        mykey = ((uint64_t)f32_to_ordered(dg) << 32) | ((uint64_t)ids_l[lane] << 1);
+    }
+    mykey = wave_sort64g(mykey, lane);  // ascending; INF padding at the end
+    batch[lane] = mykey;
+    __syncthreads();
+    // merge: R2 <- ef smallest of R u batch
+    if ((uint32_t)lane < nfresh) {
+      const uint32_t pos = lower_bound_lds(R, nR, mykey) + lane;
+      if (pos < ef) R2[pos] = mykey;
+    }
+    for (uint32_t j = lane; j < nR; j += 64) {
+      const uint64_t kj = R[j];
+      const uint32_t pos = j + lower_bound_lds(batch, nfresh, kj);
+      if (pos < ef) R2[pos] = kj;
+    }
+    __syncthreads();
+    nR = nR + nfresh < ef ? nR + nfresh : ef;
+    uint64_t* t = R;
+    R = R2;
+    R2 = t;
+  }
+
+  // ---- results: the k closest of R (already sorted by (dist, id)) ----
+  const uint32_t cnt = nR < a.k ? nR : a.k;
+  for (uint32_t j = lane; j < a.k; j += 64) {
+    const bool ok = j < cnt;
+    a.out_ids[(size_t)qi * a.k + j] = ok ? (uint64_t)((uint32_t)(R[j] & 0xFFFFFFFFull) >> 1) : ~0ull;
+    a.out_dist[(size_t)qi * a.k + j] = ok ? ordered_to_f32((uint32_t)(R[j] >> 32)) : __builtin_inff();
+  }
+  if (lane == 0) {
+    a.out_count[qi] = cnt;
+    atomicAdd(&a.counters[0], n_dist);
+    atomicAdd(&a.counters[1], n_hops0);
+    atomicAdd(&a.counters[2], n_hops_up);
+  }
+}
+
+hipError_t launch_graph_search(const GraphArgs& a, hipStream_t st) {
+  const size_t lds = graph_lds_bytes(a.ld, a.ef_cap);
+  static size_t attr_set = 0;
+  if (lds > 64 * 1024 && lds > attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)graph_search_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = lds;
+  }
+  hipLaunchKernelGGL(graph_search_kernel, dim3(a.nq), dim3(64), lds, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace ehx

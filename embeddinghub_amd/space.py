@@ -83,6 +83,30 @@ class Space:
         lens = (C.c_size_t * len(ks))(*[len(k) for k in ks])
         check(self._L.ehx_set_batch(self._h, len(ks), arr, lens, pv))
 
+    def graph_import(self, level0, levels, upper, entry_point, max_level):
+        """Attach an HNSW graph over the rows already Set (graph mode).
+
+        level0: [n, 1+2M] u32 rows = (count, ids...); levels: [n] i32; upper: {(node, level>=1): ids}.
+        """
+        l0 = np.ascontiguousarray(level0, dtype=np.uint32)
+        lv = np.ascontiguousarray(levels, dtype=np.int32)
+        items = sorted(upper.items())
+        un = np.array([key[0] for key, _ in items], dtype=np.uint32)
+        ul = np.array([key[1] for key, _ in items], dtype=np.int32)
+        off = np.zeros(len(items) + 1, dtype=np.uint64)
+        if items:
+            off[1:] = np.cumsum([len(v) for _, v in items])
+            ids = np.concatenate([np.asarray(v, dtype=np.uint32) for _, v in items]).astype(np.uint32)
+        else:
+            ids = np.zeros(1, dtype=np.uint32)
+        P = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
+        check(self._L.ehx_graph_import(self._h, l0.shape[0], P(l0, C.c_uint32), P(lv, C.c_int32), len(items),
+                                       P(un, C.c_uint32), P(ul, C.c_int32), P(off, C.c_uint64),
+                                       P(ids, C.c_uint32), int(entry_point), int(max_level)))
+
+    def set_ef(self, ef):
+        check(self._L.ehx_space_set_ef(self._h, ef))
+
     def fill_synthetic(self, seed, row0, n_rows, normalize):
         check(self._L.ehx_fill_synthetic(self._h, seed, row0, n_rows, int(bool(normalize))))
 
