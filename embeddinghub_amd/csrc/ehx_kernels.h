@@ -95,6 +95,68 @@ __device__ __forceinline__ float canon_dist(int metric, const float* __restrict_
   return res;  // valid in sub-lane 0
 }
 
+// Same canonical arithmetic executed by ONE lane: the lane keeps the 4 SSE partial sums itself and
+// walks its row with 16-byte loads (q may live in LDS).  Used by the graph search, where every lane
+// owns one neighbour row.  Requires 16-byte aligned q and x (row stride ld % 4 == 0).
+__device__ __forceinline__ float canon_dist_lane(int metric, const float* __restrict__ q,
+                                                 const float* __restrict__ x, float xscale, bool scale_x,
+                                                 uint32_t dims) {
+  uint32_t body;
+  if ((dims & 15u) == 0 || (dims & 3u) == 0) body = dims;
+  else if (dims > 16) body = dims & ~15u;
+  else if (dims > 4) body = dims & ~3u;
+  else body = 0;
+  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+  if (metric == 0) {
+    for (uint32_t m = 0; m < body; m += 4) {
+      float4 xv = *(const float4*)(x + m);
+      const float4 qv = *(const float4*)(q + m);
+      if (scale_x) {
+        xv.x = ex_mul(xv.x, xscale);
+        xv.y = ex_mul(xv.y, xscale);
+        xv.z = ex_mul(xv.z, xscale);
+        xv.w = ex_mul(xv.w, xscale);
+      }
+      const float d0 = ex_sub(qv.x, xv.x), d1 = ex_sub(qv.y, xv.y), d2 = ex_sub(qv.z, xv.z), d3 = ex_sub(qv.w, xv.w);
+      p0 = ex_add(p0, ex_mul(d0, d0));
+      p1 = ex_add(p1, ex_mul(d1, d1));
+      p2 = ex_add(p2, ex_mul(d2, d2));
+      p3 = ex_add(p3, ex_mul(d3, d3));
+    }
+  } else {
+    for (uint32_t m = 0; m < body; m += 4) {
+      float4 xv = *(const float4*)(x + m);
+      const float4 qv = *(const float4*)(q + m);
+      if (scale_x) {
+        xv.x = ex_mul(xv.x, xscale);
+        xv.y = ex_mul(xv.y, xscale);
+        xv.z = ex_mul(xv.z, xscale);
+        xv.w = ex_mul(xv.w, xscale);
+      }
+      p0 = ex_add(p0, ex_mul(qv.x, xv.x));
+      p1 = ex_add(p1, ex_mul(qv.y, xv.y));
+      p2 = ex_add(p2, ex_mul(qv.z, xv.z));
+      p3 = ex_add(p3, ex_mul(qv.w, xv.w));
+    }
+  }
+  float res = ex_add(ex_add(ex_add(p0, p1), p2), p3);
+  if (body != dims) {
+    float tail = 0.0f;
+    for (uint32_t m = body; m < dims; ++m) {
+      const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
+      if (metric == 0) {
+        const float diff = ex_sub(q[m], xv);
+        tail = ex_add(tail, ex_mul(diff, diff));
+      } else {
+        tail = ex_add(tail, ex_mul(q[m], xv));
+      }
+    }
+    res = body ? ex_add(res, tail) : tail;
+  }
+  if (metric != 0) res = ex_sub(1.0f, res);
+  return res;
+}
+
 struct ScanArgs {
   const float* Q;        // [q_tiles*256][ld] prepared queries (zero padded)
   const float* X;        // [cap][ld] stored rows, cap % 256 == 0 (>= n_tiles*128), pad columns zero

@@ -18,7 +18,7 @@
 //   * adj0[n][2M] u32, padded with 0xFFFFFFFF, stored order preserved: one 128-B line per expansion;
 //   * upper levels: up_start[n] (index of the node's first upper list or ~0), up_lists[*][M];
 //   * vectors stay in the space's row-major X; distances use the canonical (oracle-order)
-//     arithmetic of canon_dist, 16 neighbours per pass (one 4-lane group each), so on an imported
+//     arithmetic (canon_dist_lane: one lane per neighbour row, 16-byte loads), so on an imported
 //     graph the traversal, the returned ids and the distances are bit-identical to the oracle;
 //   * visited set: one bit per row per in-flight query in HBM (n/8 bytes per query — 1.25 MB at 10 M
 //     rows, 1.3 GB for a 1024-query batch out of 288 GB), test-and-set with atomicOr;
@@ -77,27 +77,24 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   for (uint32_t i = lane; i < a.ld; i += 64) qs[i] = a.Q[(size_t)qi * a.ld + i];
   __syncthreads();
 
-  const int g = lane >> 2, sub = lane & 3;
   const int metric01 = a.metric == 0 ? 0 : 1;
   const bool scale_x = a.metric == 2;
   unsigned long long n_dist = 0, n_hops0 = 0, n_hops_up = 0;
 
-  // distance of up to 16 rows (ids_l[base + g]) per pass; result for group g in every lane of g
-  auto pass_dist = [&](uint32_t base, uint32_t count) -> float {
-    const bool act = base + (uint32_t)g < count;
-    const uint32_t id = act ? ids_l[base + g] : 0u;
-    const float* xv = a.X + (size_t)id * a.ld;
+  // canonical distance of row ids_l[lane] for lane < count: every lane owns one neighbour row and
+  // keeps the 4 SSE partial sums itself (16-byte loads; the query is an LDS broadcast read)
+  auto lane_dist = [&](uint32_t count) -> float {
+    if ((uint32_t)lane >= count) return __builtin_inff();
+    const uint32_t id = ids_l[lane];
     const float xs = scale_x ? a.inv_norm[id] : 1.0f;
-    float d = canon_dist(metric01, qs, xv, xs, scale_x, a.dims, sub);
-    d = __shfl(d, lane & ~3, 64);
-    return act ? d : __builtin_inff();
+    return canon_dist_lane(metric01, qs, a.X + (size_t)id * a.ld, xs, scale_x, a.dims);
   };
 
   // ---- entry point ----
   uint32_t cur = a.entry_point;
   if (lane == 0) ids_l[0] = cur;
   __syncthreads();
-  float curdist = __shfl(pass_dist(0, 1), 0, 64);
+  float curdist = __shfl(lane_dist(1), 0, 64);
   n_dist += 1;
 
   // ---- upper levels: greedy descent ----
@@ -117,13 +114,12 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
       n_dist += cnt;
       uint32_t best_i = kNoNode;
       float best_d = curdist;
-      for (uint32_t base = 0; base < cnt; base += 16) {
-        const float d = pass_dist(base, cnt);
+      {
         // first strictly-smaller minimum in stored order
-        float m = d;
-        uint32_t mi = base + g;
+        float m = lane_dist(cnt);
+        uint32_t mi = (uint32_t)lane;
 #pragma unroll
-        for (int o = 4; o < 64; o <<= 1) {
+        for (int o = 1; o < 64; o <<= 1) {
           const float od = __shfl_xor(m, o, 64);
           const uint32_t oi = __shfl_xor(mi, o, 64);
           if (od < m || (od == m && oi < mi)) {
@@ -181,14 +177,11 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     __syncthreads();
     if (nfresh == 0) continue;
     n_dist += nfresh;
-    // distances, 16 rows per pass; lane p (< nfresh) ends up owning key p
+    // distances: lane p (< nfresh) owns fresh neighbour p
     uint64_t mykey = kKeyInf;
-    for (uint32_t base = 0; base < nfresh; base += 16) {
-      const float d = pass_dist(base, nfresh);
-      // group g's distance -> lane base+g
-      const float dg = __shfl(d, ((lane - (int)base) & 15) << 2, 64);
-      if ((uint32_t)lane >= base && (uint32_t)lane < base + 16 && (uint32_t)lane < nfresh)
-        mykey = ((uint64_t)f32_to_ordered(dg) << 32) | ((uint64_t)ids_l[lane] << 1);
+    {
+      const float d = lane_dist(nfresh);
+      if ((uint32_t)lane < nfresh) mykey = ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)ids_l[lane] << 1);
     }
     mykey = wave_sort64g(mykey, lane);  // ascending; INF padding at the end
     batch[lane] = mykey;

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Graph-path measurement (SURVEY §8d graph rows): the oracle builds the HNSW graph on the host
+(reference defaults M=16, efC=200, sequential), the engine imports it and serves batches of queries;
+reports QPS, recall@k vs the engine's exact flat path, n_dist / n_hops per query, algorithmic bytes
+per query and achieved HBM GB/s (= algorithmic bytes / kernel time), next to the oracle's CPU QPS on
+all host cores at the same ef.  One JSON line per (dataset, ef)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=100_000)
+    ap.add_argument("--dims", type=int, default=128)
+    ap.add_argument("--metric", default="l2")
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--efs", default="10,50,200")
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    import torch  # noqa: F401  (same HIP runtime instance as the engine)
+    import embeddinghub_amd as ehx
+    from oracle import pyoracle
+    em, om = {"l2": (ehx.METRIC_L2SQ, pyoracle.METRIC_L2), "cosine": (ehx.METRIC_COSINE, pyoracle.METRIC_COSINE),
+              "ip": (ehx.METRIC_IP, pyoracle.METRIC_IP)}[args.metric]
+    n, d, B, k = args.rows, args.dims, args.batch, args.k
+    norm = args.metric == "cosine"
+    X = pyoracle.gen_rows(ehx.SEED_CORPUS, 0, n, d, normalize=norm)
+    Q = pyoracle.gen_rows(ehx.SEED_QUERY, 0, B, d, normalize=norm)
+    h = pyoracle.Hnsw(d, om, n)
+    build_s = h.add_rows(X)
+    g = ehx.Space.unique("gbench", d, metric=em, mode=ehx.MODE_GRAPH, initial_capacity=n)
+    g.fill_synthetic(ehx.SEED_CORPUS, 0, n, norm)
+    l0, lv, upper = h.export_graph()
+    g.graph_import(l0, lv, upper, h.enterpoint, h.maxlevel)
+    flat = ehx.Space.unique("gbench-flat", d, metric=em, initial_capacity=n)
+    flat.fill_synthetic(ehx.SEED_CORPUS, 0, n, norm)
+    truth, _, _ = flat.knn(Q, k)
+    cores = os.cpu_count() or 1
+    for ef in [int(x) for x in args.efs.split(",")]:
+        g.set_ef(ef)
+        h.set_ef(ef)
+        ids, dist, cnt = g.knn(Q, k)  # warm-up
+        g.stats_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            ids, dist, cnt = g.knn(Q, k)
+        wall = (time.perf_counter() - t0) / args.reps
+        st = g.stats()
+        recall = float(np.mean([len(set(ids[i]) & set(truth[i])) / k for i in range(B)]))
+        labels, _, _, _, _ = h.search_batch(Q, k, threads=cores)
+        best = 0.0
+        for _ in range(3):
+            _, _, _, sec, ost = h.search_batch(Q, k, threads=cores)
+            best = max(best, B / sec)
+        same = float(np.mean([np.array_equal(labels[i], ids[i]) for i in range(B)]))
+        orecall = float(np.mean([len(set(labels[i]) & set(truth[i])) / k for i in range(B)]))
+        bytes_q = st["bytes_algorithmic"] / (args.reps * B)
+        kern_ms = st["scan_ms_mean"]
+        print(json.dumps({
+            "workload": "%dx%d %s, graph (oracle-built HNSW M=16 efC=200, build %.1fs), batch=%d k=%d ef=%d" % (
+                n, d, args.metric, build_s, B, k, ef),
+            "qps_host_pointers": round(B / wall, 1), "qps_kernel": round(B / (kern_ms * 1e-3), 1),
+            "kernel_ms": round(kern_ms, 4), "recall_at_k": round(recall, 4), "oracle_recall_at_k": round(orecall, 4),
+            "queries_identical_to_oracle": round(same, 4),
+            "n_dist_per_query": round(st["n_dist"] / (args.reps * B), 1),
+            "n_hops_per_query": round(st["n_hops"] / (args.reps * B), 1),
+            "bytes_per_query": round(bytes_q, 1),
+            "roofline": {"bound": "hbm", "achieved": round(bytes_q * B / (kern_ms * 1e-3) / 1e9, 2), "peak": 8000.0,
+                         "unit": "GB/s", "frac": round(bytes_q * B / (kern_ms * 1e-3) / 8e12, 5)},
+            "cpu_oracle_qps": round(best, 1), "cpu_cores": cores,
+        }), flush=True)
+
+
+if __name__ == "__main__":
+    main()
