@@ -84,6 +84,14 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise OSError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64: when both live in one
+        # process they must be ONE runtime instance, and that only works if torch's copy is loaded
+        # first (ours then resolves to it by SONAME).  Loading libehx first makes a later
+        # `import torch` fail with "No HIP GPUs are available".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol

@@ -175,7 +175,9 @@ struct ScanArgs {
 };
 
 size_t scan_lds_bytes();
-hipError_t launch_flat_scan(const ScanArgs& a, hipStream_t st);
+hipError_t launch_flat_scan(const ScanArgs& a, hipStream_t st);   // dispatches on EHX_SCAN_VARIANT (default 8)
+hipError_t launch_flat_scan4(const ScanArgs& a, hipStream_t st);  // k_flat.hip: 4 waves, one per SIMD
+hipError_t launch_flat_scan8(const ScanArgs& a, hipStream_t st);  // k_flat8.hip: 8 waves, two per SIMD
 
 // one wave per query: k-way merge of the per-chunk sorted key lists -> top-kprime keys
 hipError_t launch_flat_merge(const uint64_t* part, uint32_t nq, uint32_t n_chunks, uint32_t kprime,

@@ -28,6 +28,8 @@
 //     candidate slots per query in a per-block global scratch (L2 resident).  With grid % 8 == 0
 //     the q_tiles blocks that stream the same rows are placed on the same XCD so the rows are
 //     fetched from HBM once and hit in that XCD's L2 for the other query tiles.
+#include <cstdlib>
+
 #include "ehx_kernels.h"
 
 namespace ehx {
@@ -431,6 +433,14 @@ __global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a
 }
 
 hipError_t launch_flat_scan(const ScanArgs& a, hipStream_t st) {
+  static const int variant = [] {
+    const char* v = getenv("EHX_SCAN_VARIANT");
+    return v ? atoi(v) : 8;
+  }();
+  return variant == 4 ? launch_flat_scan4(a, st) : launch_flat_scan8(a, st);
+}
+
+hipError_t launch_flat_scan4(const ScanArgs& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)flat_scan_kernel,

@@ -1,0 +1,455 @@
+// flat_scan8_kernel — the exhaustive scan of k_flat.hip re-mapped to 8 waves (two per SIMD).
+//
+// Why a second mapping: rocprofv3 on the 4-wave kernel (one wave per SIMD, profiles/r01_a) showed the
+// matrix pipe busy only 80 % of the time; the rest is the compute waves' own global->LDS DMA issue
+// (a 1-KiB piece blocks its issuing wave for 60-180 cycles, 12 pieces per wave per stage) plus the
+// per-stage barrier and the tile epilogue — with a single wave per SIMD nothing else can issue MFMAs
+// meanwhile.  Here every SIMD hosts two waves whose DMA duty is staggered half a stage apart
+// (waves 0-3 issue right after the stage barrier, waves 4-7 one group later), so one wave's DMA issue
+// always runs beside its sibling's MFMA issue.
+//
+//   * workgroup = 512 threads = 8 waves, 1 workgroup per CU; wave (wr, wc) = (w>>2, w&3) owns
+//     64 rows x 64 queries = 2x2 MFMA 32x32 blocks (64 accumulator registers); workgroup tile
+//     128 rows x 256 queries, BK = 32 (same tile, same LDS image, same swizzle as k_flat.hip);
+//   * LDS: 3-deep ring of stages (3 x 48 KiB) so a stage has two full stages to land;
+//   * every wave DMA-copies its share of a stage (2 X pieces + 4 Q pieces; wave 0 also the tile's
+//     row-parameter piece) and accounts for it with a counted s_waitcnt vmcnt before the single
+//     workgroup barrier per stage (raw s_barrier: __syncthreads() would drain the DMA queue);
+//   * fragments of group g+1 are read from LDS while group g's 16 MFMAs issue.
+// Epilogue, candidate slots, key packing, output format: identical to flat_scan_kernel.
+#include "ehx_kernels.h"
+
+namespace ehx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kThreads8 = 512;
+constexpr uint32_t kRing8 = 3;
+constexpr uint32_t kXStage8 = kTileRows * kBK * 4;                 // 16 KiB
+constexpr uint32_t kQStage8 = kTileQ * kBK * 4;                    // 32 KiB
+constexpr uint32_t kXOff8 = 0;
+constexpr uint32_t kQOff8 = kRing8 * kXStage8;
+constexpr uint32_t kThrKeyOff8 = kQOff8 + kRing8 * kQStage8;       // u64 thr_key[256]
+constexpr uint32_t kThrFOff8 = kThrKeyOff8 + 256 * 8;              // f32 thr_f[256]
+constexpr uint32_t kCntOff8 = kThrFOff8 + 256 * 4;                 // i32 cnt[256]
+constexpr uint32_t kFlagOff8 = kCntOff8 + 256 * 4;                 // i32 flags[4]
+constexpr uint32_t kRowpOff8 = kFlagOff8 + 16;                     // float2 rowp_lds[4][128]
+constexpr uint32_t kLdsBytes8 = kRowpOff8 + 4 * 128 * 8;
+static_assert(kLdsBytes8 <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ void glds16_8(const void* gsrc, void* lds_dst_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+
+__device__ __forceinline__ uint64_t wave_sort64_8(uint64_t key, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint64_t other = __shfl_xor(key, j, 64);
+      const bool up = (lane & k) == 0;
+      const bool lower = (lane & j) == 0;
+      const uint64_t mn = key < other ? key : other;
+      const uint64_t mx = key < other ? other : key;
+      key = (lower == up) ? mn : mx;
+    }
+  }
+  return key;
+}
+
+// hot-path barrier: LDS traffic only, the DMA queue keeps flowing
+__device__ __forceinline__ void hot_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// cold-path barrier: also publishes this wave's global stores (candidate slots) to the workgroup
+__device__ __forceinline__ void cold_barrier() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__device__ __attribute__((noinline)) bool scan8_push(float sc, uint32_t grow, int q, uint32_t n, uint64_t* cand,
+                                                     int* cnt, const uint64_t* thr_key) {
+  const uint64_t key = ((uint64_t)f32_to_ordered(sc) << 32) | grow;
+  if (grow < n && key < thr_key[q]) {
+    const int pos = atomicAdd(&cnt[q], 1);
+    if (pos < (int)kCandSlots) {
+      cand[q * kCandSlots + pos] = key;
+      return false;
+    }
+    return true;
+  }
+  return false;
+}
+
+// compaction of the 32 queries owned by wave w
+__device__ __attribute__((noinline)) void scan8_compact(int w, int lane, int overflow, int kprime, uint64_t* cand,
+                                                        int* cnt, uint64_t* thr_key, float* thr_f) {
+  const int trigger = kprime + ((int)kCandSlots - kprime) / 2;
+  const int c = cnt[w * 32 + (lane & 31)];
+  const bool need = lane < 32 && (c >= trigger || (overflow && c > (int)kCandSlots));
+  uint64_t mask = __ballot(need);
+  while (mask) {
+    const int qq = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    const int q = w * 32 + qq;
+    const int cq = cnt[q];
+    const int nv = cq < (int)kCandSlots ? cq : (int)kCandSlots;
+    uint64_t key = lane < nv ? cand[q * kCandSlots + lane] : kKeyInf;
+    key = wave_sort64_8(key, lane);
+    if (lane < kprime) cand[q * kCandSlots + lane] = key;
+    const uint64_t kth = __shfl(key, kprime - 1, 64);
+    if (lane == 0) {
+      cnt[q] = nv < kprime ? nv : kprime;
+      if (nv >= kprime) {
+        thr_key[q] = kth;
+        thr_f[q] = ordered_to_f32((uint32_t)(kth >> 32));
+      }
+    }
+  }
+}
+
+#define EHX_MFMA8(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
+
+}  // namespace
+
+size_t scan8_lds_bytes() { return kLdsBytes8; }
+
+__global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const bool late = w >= 4;  // DMA duty half a stage after the sibling wave on the same SIMD
+  const int h = lane >> 5, i31 = lane & 31;
+
+  uint32_t qt, chunk;
+  {
+    const uint32_t b = blockIdx.x;
+    if (a.xcd_map) {
+      const uint32_t xcd = b & 7u, slot = b >> 3;
+      qt = slot % a.q_tiles;
+      chunk = xcd * (a.n_chunks >> 3) + slot / a.q_tiles;
+    } else {
+      qt = b % a.q_tiles;
+      chunk = b / a.q_tiles;
+    }
+  }
+  uint64_t* thr_key = (uint64_t*)(smem + kThrKeyOff8);
+  float* thr_f = (float*)(smem + kThrFOff8);
+  int* cnt = (int*)(smem + kCntOff8);
+  int* flags = (int*)(smem + kFlagOff8);
+  const float2* rowp_lds = (const float2*)(smem + kRowpOff8);
+  uint64_t* cand = a.cand + (size_t)blockIdx.x * (256u * kCandSlots);
+
+  if (tid < 256) {
+    thr_key[tid] = kKeyInf;
+    thr_f[tid] = __builtin_inff();
+    cnt[tid] = 0;
+  }
+  if (tid < 4) flags[tid] = 0;
+
+  const uint32_t tile_begin = chunk * a.tiles_per_chunk;
+  uint32_t tile_end = tile_begin + a.tiles_per_chunk;
+  if (tile_end > a.n_tiles) tile_end = a.n_tiles;
+  const uint32_t my_tiles = tile_end > tile_begin ? tile_end - tile_begin : 0u;
+  const uint32_t ktiles = a.ld / kBK;
+  const uint32_t total_steps = my_tiles * ktiles;
+
+  // ---- DMA duty of this wave: X pieces 2w, 2w+1; Q pieces 4w..4w+3; wave 0 also the row parameters.
+  // piece `ins` = 8 tile rows x 128 B; lane L -> row 8*ins + (L>>3), physical chunk p = L&7, logical
+  // chunk c = p ^ ((4*ins + (L>>4)) & 7): only the parity of ins matters -> two lane offsets.
+  const float* Qtile = a.Q + (size_t)qt * kTileQ * a.ld;
+  const float* Xbase = a.X + (size_t)tile_begin * kTileRows * a.ld;
+  const float2* Rbase = a.rowp + (size_t)tile_begin * kTileRows;
+  const size_t tile_stride = (size_t)kTileRows * a.ld;
+  const uint32_t c0 = (uint32_t)(lane & 7) ^ (uint32_t)(lane >> 4);
+  const uint32_t lane_row = (uint32_t)(lane >> 3) * a.ld;
+  const uint32_t l_even = (lane_row + c0 * 4u) * 4u;  // bytes
+  const uint32_t l_odd = (lane_row + (c0 ^ 4u) * 4u) * 4u;
+  const uint32_t piece_stride = 8u * a.ld * 4u;
+  uint32_t pre_t = 0, pre_kt = 0, pre_buf = 0, issued = 0;
+
+  // piece u of this wave's duty for the stage (pre_t, pre_kt) -> ring slot pre_buf; u in 0..5 (+6)
+#define EHX_PIECE(U)                                                                                    \
+  do {                                                                                                  \
+    if ((U) < 2) {                                                                                      \
+      const char* Xt = (const char*)(Xbase + pre_t * tile_stride + pre_kt * kBK);                       \
+      glds16_8(Xt + (size_t)((2 * w + (U)) * piece_stride) + (((U) & 1) ? l_odd : l_even),              \
+               smem + kXOff8 + pre_buf * kXStage8 + (2 * w + (U)) * 1024);                              \
+    } else if ((U) < 6) {                                                                               \
+      const char* Qt = (const char*)(Qtile + pre_kt * kBK);                                             \
+      glds16_8(Qt + (size_t)((4 * w + (U) - 2) * piece_stride) + ((((U) - 2) & 1) ? l_odd : l_even),    \
+               smem + kQOff8 + pre_buf * kQStage8 + (4 * w + (U) - 2) * 1024);                          \
+    } else if (w == 0) {                                                                                \
+      glds16_8((const char*)(Rbase + pre_t * kTileRows) + lane * 16,                                    \
+               smem + kRowpOff8 + (pre_t & 3u) * 1024u);                                                \
+    }                                                                                                   \
+  } while (0)
+#define EHX_STAGE_ADVANCE()                         \
+  do {                                              \
+    if (++pre_kt == ktiles) {                       \
+      pre_kt = 0;                                   \
+      ++pre_t;                                      \
+    }                                               \
+    pre_buf = pre_buf == kRing8 - 1 ? 0u : pre_buf + 1; \
+    ++issued;                                       \
+  } while (0)
+
+  // ---- fragment read constants ----
+  const uint32_t hs = (uint32_t)h ^ ((uint32_t)(i31 >> 1) & 7u);
+  uint32_t joff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) joff[j] = (((uint32_t)(2 * j)) ^ hs) * 16;
+  const uint32_t a_row_off = (uint32_t)(wr * 64 + i31) * 128;  // + rb*4096
+  const uint32_t b_row_off = (uint32_t)(wc * 64 + i31) * 128;  // + cb*4096
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
+
+  // =============================== tile epilogue ===============================
+  auto epilogue = [&](uint32_t t) {
+    const uint32_t tile_row0 = (tile_begin + t) * kTileRows;
+    const float2* rp = rowp_lds + (t & 3u) * 128u;
+    const int qbase = wc * 64 + i31;
+    uint32_t pend[2] = {0u, 0u};  // word = rb, bit = cb*16 + reg
+    {
+      const float thrf0 = thr_f[qbase], thrf1 = thr_f[qbase + 32];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const uint32_t r = (uint32_t)(wr * 64 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
+          const float2 ab = rp[r];
+          const float s0 = __builtin_fmaf(acc[rb][0][reg], ab.x, ab.y);
+          const float s1 = __builtin_fmaf(acc[rb][1][reg], ab.x, ab.y);
+          pend[rb] |= (s0 <= thrf0) ? (1u << reg) : 0u;
+          pend[rb] |= (s1 <= thrf1) ? (1u << (16 + reg)) : 0u;
+        }
+      }
+    }
+    const bool lane_any = (pend[0] | pend[1]) != 0u;
+    int* hotf = &flags[1 + (t & 1)];
+    if (lane_any) *hotf = 1;
+    if (tid == 0) flags[1 + ((t + 1) & 1)] = 0;
+    hot_barrier();
+    const int tile_hot = *hotf;
+    if (!tile_hot) return;
+    for (int round = 0;; ++round) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        uint32_t retry = 0u;
+        while (__any(pend[rb] != 0u)) {
+          if (pend[rb] != 0u) {
+            const int b = __builtin_ctz(pend[rb]);
+            pend[rb] &= pend[rb] - 1u;
+            float dot = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dot = (b == i) ? acc[rb][0][i] : dot;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dot = (b == 16 + i) ? acc[rb][1][i] : dot;
+            const int reg = b & 15;
+            const int cb = b >> 4;
+            const uint32_t r = (uint32_t)(wr * 64 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
+            const float2 ab = rp[r];
+            const float sc = __builtin_fmaf(dot, ab.x, ab.y);
+            if (scan8_push(sc, tile_row0 + r, qbase + cb * 32, a.n, cand, cnt, thr_key)) {
+              flags[0] = 1;
+              retry |= 1u << b;
+            }
+          }
+        }
+        pend[rb] = retry;
+      }
+      cold_barrier();
+      const int overflow = flags[0];
+      scan8_compact(w, lane, overflow, (int)a.kprime, cand, cnt, thr_key, thr_f);
+      cold_barrier();
+      if (!overflow) break;
+      if (round >= 512) {
+        if (tid == 0) atomicAdd(a.err, 1u);
+        break;
+      }
+      if (tid == 0) flags[0] = 0;
+      cold_barrier();
+    }
+  };
+
+  // ---- prologue: every wave issues its share of the first (up to) three stages ----
+  while (issued < total_steps && issued < kRing8) {
+#pragma unroll
+    for (int u = 0; u < 7; ++u) EHX_PIECE(u);
+    EHX_STAGE_ADVANCE();
+  }
+  // stage 0 landed <=> at most the pieces of the younger stages are still in flight
+  if (w == 0) {
+    if (issued >= 3) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if (issued == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    if (issued >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (issued == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  hot_barrier();  // B_0 (also publishes the state init)
+
+  f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
+  if (total_steps > 0) {
+    fa0[0] = *(const f32x4*)(smem + kXOff8 + a_row_off + joff[0]);
+    fa0[1] = *(const f32x4*)(smem + kXOff8 + a_row_off + 4096 + joff[0]);
+    fb0[0] = *(const f32x4*)(smem + kQOff8 + b_row_off + joff[0]);
+    fb0[1] = *(const f32x4*)(smem + kQOff8 + b_row_off + 4096 + joff[0]);
+  }
+
+  // one group: 16 MFMAs on (A,B); the 4 fragment reads of the next group in their shadow
+#define EHX_GROUP8(A, B, An, Bn, XS, QS)                                  \
+  do {                                                                    \
+    An[0] = *(const f32x4*)((XS));                                        \
+    An[1] = *(const f32x4*)((XS) + 4096);                                 \
+    _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                   \
+      acc[0][0] = EHX_MFMA8(A[0][tt], B[0][tt], acc[0][0]);               \
+      acc[1][0] = EHX_MFMA8(A[1][tt], B[0][tt], acc[1][0]);               \
+      acc[0][1] = EHX_MFMA8(A[0][tt], B[1][tt], acc[0][1]);               \
+      acc[1][1] = EHX_MFMA8(A[1][tt], B[1][tt], acc[1][1]);               \
+    }                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    Bn[0] = *(const f32x4*)((QS));                                        \
+    Bn[1] = *(const f32x4*)((QS) + 4096);                                 \
+    _Pragma("unroll") for (int tt = 2; tt < 4; ++tt) {                   \
+      acc[0][0] = EHX_MFMA8(A[0][tt], B[0][tt], acc[0][0]);               \
+      acc[1][0] = EHX_MFMA8(A[1][tt], B[0][tt], acc[1][0]);               \
+      acc[0][1] = EHX_MFMA8(A[0][tt], B[1][tt], acc[0][1]);               \
+      acc[1][1] = EHX_MFMA8(A[1][tt], B[1][tt], acc[1][1]);               \
+    }                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+  } while (0)
+
+  // MFMA number m (0..15) of a group on fragment set (A,B): tt = m>>2, block = m&3
+#define EHX_ONE8(A, B, M)                                                                         \
+  acc[(M) & 1][((M) >> 1) & 1] =                                                                  \
+      EHX_MFMA8(A[(M) & 1][(M) >> 2], B[((M) >> 1) & 1][(M) >> 2], acc[(M) & 1][((M) >> 1) & 1])
+
+  uint32_t kt = 0, t = 0, buf = 0;
+  for (uint32_t step = 0; step < total_steps; ++step) {
+    const uint32_t nbuf = buf == kRing8 - 1 ? 0u : buf + 1;
+    const char* xs = smem + kXOff8 + buf * kXStage8 + a_row_off;
+    const char* qs = smem + kQOff8 + buf * kQStage8 + b_row_off;
+    const char* xn = smem + kXOff8 + nbuf * kXStage8 + a_row_off;
+    const char* qn = smem + kQOff8 + nbuf * kQStage8 + b_row_off;
+    const bool has_next = step + 1 < total_steps;
+
+    // ---- group 0 (set 0): the late waves do their DMA duty here, one piece per MFMA ----
+    if (late && step >= 1 && issued < total_steps) {
+      fa1[0] = *(const f32x4*)(xs + joff[1]);
+      fa1[1] = *(const f32x4*)(xs + 4096 + joff[1]);
+      fb1[0] = *(const f32x4*)(qs + joff[1]);
+      fb1[1] = *(const f32x4*)(qs + 4096 + joff[1]);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        EHX_ONE8(fa0, fb0, m);
+        if (m < 6) EHX_PIECE(m);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      EHX_STAGE_ADVANCE();
+    } else {
+      EHX_GROUP8(fa0, fb0, fa1, fb1, xs + joff[1], qs + joff[1]);
+    }
+    EHX_GROUP8(fa1, fb1, fa0, fb0, xs + joff[2], qs + joff[2]);
+    EHX_GROUP8(fa0, fb0, fa1, fb1, xs + joff[3], qs + joff[3]);
+
+    // ---- group 3 (set 1): 4 MFMAs, the stage barrier, then 12 MFMAs with the next stage's first
+    // fragment reads and (early waves) the DMA pieces of stage step+3 in their shadow ----
+#pragma unroll
+    for (int m = 0; m < 4; ++m) EHX_ONE8(fa1, fb1, m);
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) {
+      // own pieces of stage step+1 landed?  Only stage step+2's may still be in flight.
+      if (step + 2 < total_steps) {
+        if (w == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      hot_barrier();  // B_{step+1}: stage step+1 visible; ring slot `buf` is free again
+      if (!late && issued < total_steps) {
+#pragma unroll
+        for (int m = 4; m < 16; ++m) {
+          EHX_ONE8(fa1, fb1, m);
+          if (m == 4) fa0[0] = *(const f32x4*)(xn + joff[0]);
+          if (m == 5) fa0[1] = *(const f32x4*)(xn + 4096 + joff[0]);
+          if (m == 6) fb0[0] = *(const f32x4*)(qn + joff[0]);
+          if (m == 7) fb0[1] = *(const f32x4*)(qn + 4096 + joff[0]);
+          if (m >= 8 && m < 15) EHX_PIECE(m - 8);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        EHX_STAGE_ADVANCE();
+      } else {
+        fa0[0] = *(const f32x4*)(xn + joff[0]);
+        fa0[1] = *(const f32x4*)(xn + 4096 + joff[0]);
+        fb0[0] = *(const f32x4*)(qn + joff[0]);
+        fb0[1] = *(const f32x4*)(qn + 4096 + joff[0]);
+#pragma unroll
+        for (int m = 4; m < 16; ++m) EHX_ONE8(fa1, fb1, m);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int m = 4; m < 16; ++m) EHX_ONE8(fa1, fb1, m);
+    }
+    buf = nbuf;
+    if (++kt == ktiles) {
+      kt = 0;
+      epilogue(t);
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
+      ++t;
+    }
+  }
+#undef EHX_GROUP8
+#undef EHX_ONE8
+#undef EHX_PIECE
+#undef EHX_STAGE_ADVANCE
+
+  // ---- final: sort every query's slots and publish the top-k' keys of this chunk ----
+  cold_barrier();
+  for (int qq = 0; qq < 32; ++qq) {
+    const int q = w * 32 + qq;
+    const int cq = cnt[q];
+    const int nv = cq < (int)kCandSlots ? cq : (int)kCandSlots;
+    uint64_t key = lane < nv ? cand[q * kCandSlots + lane] : kKeyInf;
+    key = wave_sort64_8(key, lane);
+    if (lane < (int)a.kprime)
+      a.part[((size_t)(qt * kTileQ + q) * a.n_chunks + chunk) * a.kprime + lane] = key;
+  }
+}
+
+hipError_t launch_flat_scan8(const ScanArgs& a, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)flat_scan8_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes8);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const uint32_t grid = a.q_tiles * a.n_chunks;
+  hipLaunchKernelGGL(flat_scan8_kernel, dim3(grid), dim3(kThreads8), kLdsBytes8, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace ehx
