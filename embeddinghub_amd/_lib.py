@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libehx.so")
+LIB_PATH = os.environ.get("EHX_LIB") or os.path.join(HERE, "lib", "libehx.so")  # EHX_LIB: ablation builds
 
 OK, EINVAL, ENOTFOUND, EEXISTS, EIMMUTABLE, ENODEVICE, ENOMEM, ERANGE, EUNSUPPORTED, EINTERNAL = (
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9)

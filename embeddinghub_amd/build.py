@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIB_DIR, "libehx.so")
+LIB = os.path.join(LIB_DIR, "libehx%s.so" % os.environ.get("EHX_LIB_SUFFIX", ""))  # suffix: ablation builds
 SOURCES = ["ehx_api.cpp", "k_flat.hip", "k_flat8.hip", "k_misc.hip", "k_graph.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
@@ -29,7 +29,7 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [HIPCC] + FLAGS + ["-x", "hip"] + srcs + ["-o", LIB]
+    cmd = [HIPCC] + FLAGS + os.environ.get("EHX_DEFS", "").split() + ["-x", "hip"] + srcs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

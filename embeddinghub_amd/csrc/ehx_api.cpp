@@ -114,7 +114,7 @@ struct ehx_space {
   std::mutex scratch_mu;
   hipStream_t stream = nullptr;
   DevBuf<float> dQraw, dQ;
-  DevBuf<uint64_t> dCand, dPart, dMerged, dOutIds;
+  DevBuf<uint64_t> dCand, dPart, dMerged, dOutIds, dGthr;
   DevBuf<float> dOutDist;
   DevBuf<uint32_t> dOutCount;
   unsigned long long* dUncert = nullptr;
@@ -144,6 +144,7 @@ struct ehx_space {
     dCand.release();
     dPart.release();
     dMerged.release();
+    dGthr.release();
     dOutIds.release();
     dOutDist.release();
     dOutCount.release();
@@ -222,11 +223,12 @@ struct ScanPlan {
   uint32_t q_tiles, q_rows, n_tiles, n_chunks, tiles_per_chunk, kprime, xcd_map, grid;
 };
 
-ScanPlan plan_scan(uint32_t nq, uint64_t n, uint32_t k, int n_cus) {
+// plan one scan pass over `n_tiles` row tiles
+ScanPlan plan_scan(uint32_t nq, uint32_t n_tiles, uint32_t k, int n_cus) {
   ScanPlan p;
   p.q_tiles = (nq + kTileQ - 1) / kTileQ;
   p.q_rows = p.q_tiles * kTileQ;
-  p.n_tiles = (uint32_t)((n + kTileRows - 1) / kTileRows);
+  p.n_tiles = n_tiles;
   p.kprime = k + 8;  // EHX_MAX_K + 8 = 56 < kCandSlots: a compacted candidate list always has free slots
   // one persistent workgroup per CU: grid ~= n_cus, split as q_tiles x n_chunks
   uint32_t chunks = (uint32_t)n_cus / p.q_tiles;
@@ -309,12 +311,25 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   if (nq > (1u << 24)) return fail(EHX_EINVAL, "too many queries in one call: %zu", nq);
   if (s->params.mode == EHX_MODE_GRAPH) return knn_graph_locked(s, st, nq, d_queries, k, d_ids, d_dist, d_count);
   Engine& E = engine();
-  const ScanPlan p = plan_scan((uint32_t)nq, s->n, k, E.n_cus);
+  // Two passes (8-wave kernel): a SAMPLE pass over the first ~1/32 of the row tiles produces, per
+  // query, the k'-th best key of the sample — an upper bound of the global k'-th best — and the main
+  // pass over the remaining tiles starts from that threshold, so its slow path (candidate appends)
+  // runs ~10x less often than when every workgroup has to warm its thresholds up from +inf.
+  const uint32_t n_tiles = (uint32_t)((s->n + kTileRows - 1) / kTileRows);
+  const uint32_t lpc = scan_lists_per_chunk();
+  uint32_t sample_tiles = 0;
+  if (lpc == 2 && n_tiles >= 16384) sample_tiles = (n_tiles / 32 + 255) / 256 * 256;
+  const ScanPlan p = plan_scan((uint32_t)nq, n_tiles - sample_tiles, k, E.n_cus);   // main pass
+  const ScanPlan ps = plan_scan((uint32_t)nq, sample_tiles, k, E.n_cus);            // sample pass
+  const uint32_t lists_main = p.n_chunks * lpc, lists_sample = sample_tiles ? ps.n_chunks * lpc : 0;
+  const uint32_t lists_total = lists_main + lists_sample;
+  const uint32_t grid_max = p.grid > ps.grid ? p.grid : ps.grid;
   int rc;
   if ((rc = s->dQ.ensure((size_t)p.q_rows * s->ld))) return rc;
-  if ((rc = s->dCand.ensure((size_t)p.grid * 256 * kCandSlots))) return rc;
-  if ((rc = s->dPart.ensure((size_t)p.q_rows * p.n_chunks * p.kprime))) return rc;
+  if ((rc = s->dCand.ensure((size_t)grid_max * 512 * kCandSlots))) return rc;
+  if ((rc = s->dPart.ensure((size_t)p.q_rows * lists_total * p.kprime))) return rc;
   if ((rc = s->dMerged.ensure((size_t)p.q_rows * 64))) return rc;
+  if ((rc = s->dGthr.ensure((size_t)p.q_rows + 8))) return rc;  // +8: instrumentation slots of profiling builds
   if (!s->dUncert) {
     HIP_TRY(hipMalloc((void**)&s->dUncert, 2 * sizeof(unsigned long long)));  // [0] uncertified, [1] scan error
     HIP_TRY(hipMemset(s->dUncert, 0, 2 * sizeof(unsigned long long)));
@@ -338,21 +353,39 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     a.part = s->dPart.p;
     a.n = (uint32_t)s->n;
     a.ld = s->ld;
-    a.n_tiles = p.n_tiles;
     a.q_tiles = p.q_tiles;
-    a.n_chunks = p.n_chunks;
-    a.tiles_per_chunk = p.tiles_per_chunk;
     a.kprime = p.kprime;
-    a.xcd_map = p.xcd_map;
+    a.lists_total = lists_total;
     a.err = (uint32_t*)(s->dUncert + 1);
+    a.gthr = (unsigned long long*)s->dGthr.p;
+    HIP_TRY(hipMemsetAsync(s->dGthr.p, 0xFF, (size_t)p.q_rows * sizeof(uint64_t), st));
     hipEvent_t* pr = s->ring[s->ring_count % ehx_space::kRing];
     HIP_TRY(hipEventRecord(s->ev[1], st));
     HIP_TRY(hipEventRecord(pr[0], st));
+    if (sample_tiles) {
+      a.tile0 = 0;
+      a.n_tiles = ps.n_tiles;
+      a.n_chunks = ps.n_chunks;
+      a.tiles_per_chunk = ps.tiles_per_chunk;
+      a.xcd_map = ps.xcd_map;
+      a.list0 = lists_main;
+      HIP_TRY(launch_flat_scan(a, st));
+      // threshold = k'-th best of the merged sample lists
+      HIP_TRY(launch_flat_merge(s->dPart.p + (size_t)lists_main * p.kprime, (uint32_t)nq, lists_sample, p.kprime,
+                                s->dMerged.p, st, lists_total));
+      HIP_TRY(launch_set_gthr(s->dMerged.p, (uint32_t)nq, p.kprime, (unsigned long long*)s->dGthr.p, st));
+    }
+    a.tile0 = sample_tiles;
+    a.n_tiles = p.n_tiles;
+    a.n_chunks = p.n_chunks;
+    a.tiles_per_chunk = p.tiles_per_chunk;
+    a.xcd_map = p.xcd_map;
+    a.list0 = 0;
     HIP_TRY(launch_flat_scan(a, st));
     HIP_TRY(hipEventRecord(pr[1], st));
     HIP_TRY(hipEventRecord(s->ev[2], st));
     s->ring_count++;
-    HIP_TRY(launch_flat_merge(s->dPart.p, (uint32_t)nq, p.n_chunks, p.kprime, s->dMerged.p, st));
+    HIP_TRY(launch_flat_merge(s->dPart.p, (uint32_t)nq, lists_total, p.kprime, s->dMerged.p, st, lists_total));
   }
   RerankArgs r;
   r.Q = s->dQ.p;

@@ -162,26 +162,34 @@ struct ScanArgs {
   const float* X;        // [cap][ld] stored rows, cap % 256 == 0 (>= n_tiles*128), pad columns zero
   const float2* rowp;    // [cap] epilogue (a, b): approx distance = dot*a + b
   uint64_t* cand;        // [grid][256][64] per-block candidate slots (scratch)
-  uint64_t* part;        // [q_tiles*256][n_chunks][kprime] sorted partial top-k' keys
+  uint64_t* part;        // [q_tiles*256][n_chunks][lists_per_chunk][kprime] sorted partial top-k' keys
   uint32_t n;            // valid rows
   uint32_t ld;           // row stride in floats, % 32 == 0
-  uint32_t n_tiles;      // ceil(n / 128)
+  uint32_t tile0;        // first tile of this pass
+  uint32_t n_tiles;      // tiles of this pass (tile = 128 rows)
+  uint32_t list0;        // first sorted-list slot of this pass in `part`
+  uint32_t lists_total;  // sorted lists per query in `part` (all passes)
   uint32_t q_tiles;
   uint32_t n_chunks;
   uint32_t tiles_per_chunk;
   uint32_t kprime;       // <= 64
   uint32_t* err;         // device error counter (bounded-retry guard tripped)
+  unsigned long long* gthr;  // [q_tiles*256] global per-query threshold keys (init ~0 per launch; 8-wave kernel)
   uint32_t xcd_map;      // 1: blocks of one chunk share an XCD (grid % 8 == 0, n_chunks % 8 == 0)
 };
 
 size_t scan_lds_bytes();
+uint32_t scan_lists_per_chunk();  // sorted key lists each (query, chunk) publishes: 1 (4-wave kernel) or 2 (8-wave)
 hipError_t launch_flat_scan(const ScanArgs& a, hipStream_t st);   // dispatches on EHX_SCAN_VARIANT (default 8)
 hipError_t launch_flat_scan4(const ScanArgs& a, hipStream_t st);  // k_flat.hip: 4 waves, one per SIMD
 hipError_t launch_flat_scan8(const ScanArgs& a, hipStream_t st);  // k_flat8.hip: 8 waves, two per SIMD
 
+hipError_t launch_set_gthr(const uint64_t* merged, uint32_t nq, uint32_t kprime, unsigned long long* gthr, hipStream_t st);
+
 // one wave per query: k-way merge of the per-chunk sorted key lists -> top-kprime keys
+// (merges `n_chunks` consecutive lists of each query; a query's lists are `lists_stride` apart)
 hipError_t launch_flat_merge(const uint64_t* part, uint32_t nq, uint32_t n_chunks, uint32_t kprime,
-                             uint64_t* merged /*[nq][64]*/, hipStream_t st);
+                             uint64_t* merged /*[nq][64]*/, hipStream_t st, uint32_t lists_stride);
 
 // canonical (oracle-order) distances of the merged candidates, sort by (dist, id), emit top-k.
 struct RerankArgs {

@@ -123,9 +123,9 @@ __global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a
   cnt[tid] = 0;
   if (tid < 4) flags[tid] = 0;
 
-  const uint32_t tile_begin = chunk * a.tiles_per_chunk;
+  const uint32_t tile_begin = a.tile0 + chunk * a.tiles_per_chunk;
   uint32_t tile_end = tile_begin + a.tiles_per_chunk;
-  if (tile_end > a.n_tiles) tile_end = a.n_tiles;
+  if (tile_end > a.tile0 + a.n_tiles) tile_end = a.tile0 + a.n_tiles;
   const uint32_t my_tiles = tile_end > tile_begin ? tile_end - tile_begin : 0u;
   const uint32_t ktiles = a.ld / kBK;
   const uint32_t total_steps = my_tiles * ktiles;
@@ -428,15 +428,21 @@ __global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a
     uint64_t key = lane < nv ? cand[q * kCandSlots + lane] : kKeyInf;
     key = wave_sort64(key, lane);
     if (lane < (int)a.kprime)
-      a.part[((size_t)(qt * kTileQ + q) * a.n_chunks + chunk) * a.kprime + lane] = key;
+      a.part[((size_t)(qt * kTileQ + q) * a.lists_total + a.list0 + chunk) * a.kprime + lane] = key;
   }
 }
 
-hipError_t launch_flat_scan(const ScanArgs& a, hipStream_t st) {
+static int scan_variant() {
   static const int variant = [] {
     const char* v = getenv("EHX_SCAN_VARIANT");
     return v ? atoi(v) : 8;
   }();
+  return variant;
+}
+uint32_t scan_lists_per_chunk() { return scan_variant() == 4 ? 1u : 2u; }
+
+hipError_t launch_flat_scan(const ScanArgs& a, hipStream_t st) {
+  const int variant = scan_variant();
   return variant == 4 ? launch_flat_scan4(a, st) : launch_flat_scan8(a, st);
 }
 
@@ -457,10 +463,11 @@ hipError_t launch_flat_scan4(const ScanArgs& a, hipStream_t st) {
 // merge of the per-chunk sorted key lists: one wave per query
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void flat_merge_kernel(const uint64_t* __restrict__ part, uint32_t n_chunks,
-                                                        uint32_t kprime, uint64_t* __restrict__ merged) {
+                                                        uint32_t kprime, uint64_t* __restrict__ merged,
+                                                        uint32_t lists_stride) {
   const int lane = threadIdx.x;
   const uint32_t q = blockIdx.x;
-  const uint64_t* p = part + (size_t)q * n_chunks * kprime;
+  const uint64_t* p = part + (size_t)q * lists_stride * kprime;
   uint64_t best = kKeyInf;
   for (uint32_t c = 0; c < n_chunks; ++c) {
     const uint64_t v = lane < (int)kprime ? p[(size_t)c * kprime + lane] : kKeyInf;  // ascending
@@ -471,9 +478,22 @@ __global__ __launch_bounds__(64) void flat_merge_kernel(const uint64_t* __restri
   merged[(size_t)q * 64 + lane] = best;
 }
 
+// after the sample pass: the k'-th best key of the merged sample lists is an upper bound of the
+// query's global k'-th best -> initial threshold of the main pass
+__global__ __launch_bounds__(256) void set_gthr_kernel(const uint64_t* __restrict__ merged, uint32_t nq, uint32_t kprime,
+                                                       unsigned long long* __restrict__ gthr) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nq) gthr[q] = merged[(size_t)q * 64 + kprime - 1];
+}
+
+hipError_t launch_set_gthr(const uint64_t* merged, uint32_t nq, uint32_t kprime, unsigned long long* gthr, hipStream_t st) {
+  hipLaunchKernelGGL(set_gthr_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, merged, nq, kprime, gthr);
+  return hipGetLastError();
+}
+
 hipError_t launch_flat_merge(const uint64_t* part, uint32_t nq, uint32_t n_chunks, uint32_t kprime,
-                             uint64_t* merged, hipStream_t st) {
-  hipLaunchKernelGGL(flat_merge_kernel, dim3(nq), dim3(64), 0, st, part, n_chunks, kprime, merged);
+                             uint64_t* merged, hipStream_t st, uint32_t lists_stride) {
+  hipLaunchKernelGGL(flat_merge_kernel, dim3(nq), dim3(64), 0, st, part, n_chunks, kprime, merged, lists_stride);
   return hipGetLastError();
 }
 

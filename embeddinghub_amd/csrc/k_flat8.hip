@@ -32,13 +32,24 @@ constexpr uint32_t kXStage8 = kTileRows * kBK * 4;                 // 16 KiB
 constexpr uint32_t kQStage8 = kTileQ * kBK * 4;                    // 32 KiB
 constexpr uint32_t kXOff8 = 0;
 constexpr uint32_t kQOff8 = kRing8 * kXStage8;
-constexpr uint32_t kThrKeyOff8 = kQOff8 + kRing8 * kQStage8;       // u64 thr_key[256]
-constexpr uint32_t kThrFOff8 = kThrKeyOff8 + 256 * 8;              // f32 thr_f[256]
-constexpr uint32_t kCntOff8 = kThrFOff8 + 256 * 4;                 // i32 cnt[256]
-constexpr uint32_t kFlagOff8 = kCntOff8 + 256 * 4;                 // i32 flags[4]
+constexpr uint32_t kLists8 = 512;  // candidate lists per workgroup: one per (wave, query of the wave)
+constexpr uint32_t kThrKeyOff8 = kQOff8 + kRing8 * kQStage8;       // u64 thr_key[512]
+constexpr uint32_t kThrFOff8 = kThrKeyOff8 + kLists8 * 8;          // f32 thr_f[512]
+constexpr uint32_t kCntOff8 = kThrFOff8 + kLists8 * 4;             // i32 cnt[512]
+constexpr uint32_t kFlagOff8 = kCntOff8 + kLists8 * 4;             // i32 flags[4]
 constexpr uint32_t kRowpOff8 = kFlagOff8 + 16;                     // float2 rowp_lds[4][128]
 constexpr uint32_t kLdsBytes8 = kRowpOff8 + 4 * 128 * 8;
 static_assert(kLdsBytes8 <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ f32x4 frag_read(const char* p) {
+#if (EHX_ABL & 4)
+  f32x4 v = {1.0f, 2.0f, 3.0f, 4.0f};
+  asm volatile("" : "+v"(v));
+  return v;
+#else
+  return *(const f32x4*)p;
+#endif
+}
 
 __device__ __forceinline__ void glds16_8(const void* gsrc, void* lds_dst_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -74,48 +85,70 @@ __device__ __forceinline__ void cold_barrier() {
   asm volatile("" ::: "memory");
 }
 
-__device__ __attribute__((noinline)) bool scan8_push(float sc, uint32_t grow, int q, uint32_t n, uint64_t* cand,
-                                                     int* cnt, const uint64_t* thr_key) {
+// append (score,id) to query q's candidate slots.  Returns the slot position (>= kCandSlots: the list
+// was full and nothing was stored) or -1 when the key does not beat the query's threshold.
+__device__ __attribute__((noinline)) int scan8_push(float sc, uint32_t grow, int list, uint32_t n, uint64_t* cand,
+                                                    int* cnt, const uint64_t* thr_key) {
   const uint64_t key = ((uint64_t)f32_to_ordered(sc) << 32) | grow;
-  if (grow < n && key < thr_key[q]) {
-    const int pos = atomicAdd(&cnt[q], 1);
-    if (pos < (int)kCandSlots) {
-      cand[q * kCandSlots + pos] = key;
-      return false;
-    }
-    return true;
+  if (grow < n && key < thr_key[list]) {
+    const int pos = atomicAdd(&cnt[list], 1);
+    if (pos < (int)kCandSlots) cand[list * kCandSlots + pos] = key;
+    return pos;
   }
-  return false;
+  return -1;
 }
 
-// compaction of the 32 queries owned by wave w
-__device__ __attribute__((noinline)) void scan8_compact(int w, int lane, int overflow, int kprime, uint64_t* cand,
-                                                        int* cnt, uint64_t* thr_key, float* thr_f) {
+// Wave-local compaction of this wave's own 64 candidate lists (list = w*64 + local query): sort the
+// slots, keep the best kprime, tighten the list's threshold and share it with the other chunks'
+// workgroups.  Only the owning wave ever touches a list, so no workgroup barrier is involved; the
+// wave's own slot stores are made visible to itself with vmcnt(0) (this also drains its DMA pieces —
+// rare, and the sibling wave keeps the SIMD's matrix pipe busy meanwhile).
+__device__ __attribute__((noinline)) void scan8_compact(int w, int wc, int lane, int kprime, bool force,
+                                                        uint64_t* cand, int* cnt, uint64_t* thr_key, float* thr_f,
+                                                        unsigned long long* gthr_tile) {
   const int trigger = kprime + ((int)kCandSlots - kprime) / 2;
-  const int c = cnt[w * 32 + (lane & 31)];
-  const bool need = lane < 32 && (c >= trigger || (overflow && c > (int)kCandSlots));
-  uint64_t mask = __ballot(need);
+  const int c = cnt[w * 64 + lane];
+  uint64_t mask = __ballot(force ? c > 0 : c >= trigger);
+  if (!mask) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   while (mask) {
-    const int qq = __builtin_ctzll(mask);
+    const int ql = __builtin_ctzll(mask);
     mask &= mask - 1;
-    const int q = w * 32 + qq;
-    const int cq = cnt[q];
+    const int list = w * 64 + ql;
+    const int cq = cnt[list];
     const int nv = cq < (int)kCandSlots ? cq : (int)kCandSlots;
-    uint64_t key = lane < nv ? cand[q * kCandSlots + lane] : kKeyInf;
+    uint64_t key = lane < nv ? cand[list * kCandSlots + lane] : kKeyInf;
     key = wave_sort64_8(key, lane);
-    if (lane < kprime) cand[q * kCandSlots + lane] = key;
+    if (lane < kprime) cand[list * kCandSlots + lane] = key;
     const uint64_t kth = __shfl(key, kprime - 1, 64);
     if (lane == 0) {
-      cnt[q] = nv < kprime ? nv : kprime;
+      cnt[list] = nv < kprime ? nv : kprime;
       if (nv >= kprime) {
-        thr_key[q] = kth;
-        thr_f[q] = ordered_to_f32((uint32_t)(kth >> 32));
+        // this list's k'-th best bounds the GLOBAL k'-th best of the query from above: share it
+        // (monotone atomicMin; any stale value is safe to filter with)
+        const int q = wc * 64 + ql;
+        const unsigned long long old = atomicMin(&gthr_tile[q], (unsigned long long)kth);
+        const uint64_t best = old < kth ? old : kth;
+        thr_key[list] = best;
+        thr_f[list] = ordered_to_f32((uint32_t)(best >> 32));
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
 #define EHX_MFMA8(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
+// Ablation hooks for profiling builds only (scripts/ablate_scan.sh); the shipped library defines none.
+#ifndef EHX_ABL
+#define EHX_ABL 0
+#endif
+#define ABL_NO_EPILOGUE (EHX_ABL & 1)
+#define ABL_NO_DMA (EHX_ABL & 2)
+#define ABL_NO_LDSREAD (EHX_ABL & 4)
+#define ABL_NO_BARRIER (EHX_ABL & 8)
+#define ABL_EPI_PHASE1_ONLY (EHX_ABL & 16)
+#define ABL_EPI_NO_PHASE1 (EHX_ABL & 32)
+#define ABL_COUNT (EHX_ABL & 64)  // instrumentation: a.gthr[q_rows + 0..3] = hot tiles, push iterations, pushes, compactions
 
 }  // namespace
 
@@ -147,18 +180,21 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
   int* cnt = (int*)(smem + kCntOff8);
   int* flags = (int*)(smem + kFlagOff8);
   const float2* rowp_lds = (const float2*)(smem + kRowpOff8);
-  uint64_t* cand = a.cand + (size_t)blockIdx.x * (256u * kCandSlots);
+  uint64_t* cand = a.cand + (size_t)blockIdx.x * ((size_t)kLists8 * kCandSlots);
+  unsigned long long* gthr = a.gthr + (size_t)qt * kTileQ;  // global per-query thresholds of this query tile
 
-  if (tid < 256) {
-    thr_key[tid] = kKeyInf;
-    thr_f[tid] = __builtin_inff();
+  {  // 512 threads, 512 lists; start from the query's global threshold (the sample pass set it)
+    const int wq = ((tid >> 6) & 3) * 64 + (tid & 63);  // list tid belongs to wave tid>>6, query wc*64 + ql
+    const unsigned long long g = gthr[wq];
+    thr_key[tid] = g;
+    thr_f[tid] = g == kKeyInf ? __builtin_inff() : ordered_to_f32((uint32_t)(g >> 32));
     cnt[tid] = 0;
   }
   if (tid < 4) flags[tid] = 0;
 
-  const uint32_t tile_begin = chunk * a.tiles_per_chunk;
+  const uint32_t tile_begin = a.tile0 + chunk * a.tiles_per_chunk;
   uint32_t tile_end = tile_begin + a.tiles_per_chunk;
-  if (tile_end > a.n_tiles) tile_end = a.n_tiles;
+  if (tile_end > a.tile0 + a.n_tiles) tile_end = a.tile0 + a.n_tiles;
   const uint32_t my_tiles = tile_end > tile_begin ? tile_end - tile_begin : 0u;
   const uint32_t ktiles = a.ld / kBK;
   const uint32_t total_steps = my_tiles * ktiles;
@@ -180,6 +216,7 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
   // piece u of this wave's duty for the stage (pre_t, pre_kt) -> ring slot pre_buf; u in 0..5 (+6)
 #define EHX_PIECE(U)                                                                                    \
   do {                                                                                                  \
+    if (ABL_NO_DMA) break;                                                                              \
     if ((U) < 2) {                                                                                      \
       const char* Xt = (const char*)(Xbase + pre_t * tile_stride + pre_kt * kBK);                       \
       glds16_8(Xt + (size_t)((2 * w + (U)) * piece_stride) + (((U) & 1) ? l_odd : l_even),              \
@@ -220,13 +257,20 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
       for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
 
   // =============================== tile epilogue ===============================
+  // Entirely wave-local (no workgroup barrier): every wave owns the candidate lists of ITS 64 queries
+  // for ITS 64 rows of the tile.
+  // Phase 1 (branch-free, unrolled): approximate distance s = dot*a_row + b_row of every accumulator,
+  // recorded as one bit "s <= threshold of its list" (word = rb, bit = cb*16 + reg).
+  // Phase 2 (rare): lanes with set bits extract the dot product with a select chain, recompute s
+  // with the same fma and append the (score,id) key to the list (LDS atomic slot + 8-byte store);
+  // a list that reaches the trigger is compacted on the spot by the wave.
   auto epilogue = [&](uint32_t t) {
     const uint32_t tile_row0 = (tile_begin + t) * kTileRows;
     const float2* rp = rowp_lds + (t & 3u) * 128u;
-    const int qbase = wc * 64 + i31;
+    const int lbase = w * 64 + i31;  // + cb*32
     uint32_t pend[2] = {0u, 0u};  // word = rb, bit = cb*16 + reg
-    {
-      const float thrf0 = thr_f[qbase], thrf1 = thr_f[qbase + 32];
+    if (!ABL_EPI_NO_PHASE1) {
+      const float thrf0 = thr_f[lbase], thrf1 = thr_f[lbase + 32];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
@@ -240,19 +284,22 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
         }
       }
     }
-    const bool lane_any = (pend[0] | pend[1]) != 0u;
-    int* hotf = &flags[1 + (t & 1)];
-    if (lane_any) *hotf = 1;
-    if (tid == 0) flags[1 + ((t + 1) & 1)] = 0;
-    hot_barrier();
-    const int tile_hot = *hotf;
-    if (!tile_hot) return;
-    for (int round = 0;; ++round) {
+    if (ABL_EPI_PHASE1_ONLY) {
+      asm volatile("" ::"v"(pend[0]), "v"(pend[1]));
+      return;
+    }
+    if (!__any((pend[0] | pend[1]) != 0u)) return;  // common case once the thresholds are warm
+    if (ABL_COUNT && lane == 0) atomicAdd(&a.gthr[a.q_tiles * 256 + 0], 1ull);
+    const int trigger = (int)a.kprime + ((int)kCandSlots - (int)a.kprime) / 2;
+    for (int round = 0; round < 1024; ++round) {
+      bool hit_trigger = false;
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         uint32_t retry = 0u;
         while (__any(pend[rb] != 0u)) {
+          if (ABL_COUNT && lane == 0) atomicAdd(&a.gthr[a.q_tiles * 256 + 1], 1ull);
           if (pend[rb] != 0u) {
+            if (ABL_COUNT) atomicAdd(&a.gthr[a.q_tiles * 256 + 2], 1ull);
             const int b = __builtin_ctz(pend[rb]);
             pend[rb] &= pend[rb] - 1u;
             float dot = 0.0f;
@@ -265,26 +312,19 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
             const uint32_t r = (uint32_t)(wr * 64 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
             const float2 ab = rp[r];
             const float sc = __builtin_fmaf(dot, ab.x, ab.y);
-            if (scan8_push(sc, tile_row0 + r, qbase + cb * 32, a.n, cand, cnt, thr_key)) {
-              flags[0] = 1;
-              retry |= 1u << b;
-            }
+            const int pos = scan8_push(sc, tile_row0 + r, lbase + cb * 32, a.n, cand, cnt, thr_key);
+            if (pos >= (int)kCandSlots) retry |= 1u << b;  // list full: compact, then try again
+            hit_trigger |= pos + 1 >= trigger;
           }
         }
         pend[rb] = retry;
       }
-      cold_barrier();
-      const int overflow = flags[0];
-      scan8_compact(w, lane, overflow, (int)a.kprime, cand, cnt, thr_key, thr_f);
-      cold_barrier();
-      if (!overflow) break;
-      if (round >= 512) {
-        if (tid == 0) atomicAdd(a.err, 1u);
-        break;
-      }
-      if (tid == 0) flags[0] = 0;
-      cold_barrier();
+      if (!__any(hit_trigger)) return;
+      if (ABL_COUNT && lane == 0) atomicAdd(&a.gthr[a.q_tiles * 256 + 3], 1ull);
+      scan8_compact(w, wc, lane, (int)a.kprime, false, cand, cnt, thr_key, thr_f, gthr);
+      if (!__any((pend[0] | pend[1]) != 0u)) return;
     }
+    if (lane == 0) atomicAdd(a.err, 1u);  // never reached: a compacted list has free slots
   };
 
   // ---- prologue: every wave issues its share of the first (up to) three stages ----
@@ -307,17 +347,17 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
 
   f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
   if (total_steps > 0) {
-    fa0[0] = *(const f32x4*)(smem + kXOff8 + a_row_off + joff[0]);
-    fa0[1] = *(const f32x4*)(smem + kXOff8 + a_row_off + 4096 + joff[0]);
-    fb0[0] = *(const f32x4*)(smem + kQOff8 + b_row_off + joff[0]);
-    fb0[1] = *(const f32x4*)(smem + kQOff8 + b_row_off + 4096 + joff[0]);
+    fa0[0] = frag_read((const char*)(smem + kXOff8 + a_row_off + joff[0]));
+    fa0[1] = frag_read((const char*)(smem + kXOff8 + a_row_off + 4096 + joff[0]));
+    fb0[0] = frag_read((const char*)(smem + kQOff8 + b_row_off + joff[0]));
+    fb0[1] = frag_read((const char*)(smem + kQOff8 + b_row_off + 4096 + joff[0]));
   }
 
   // one group: 16 MFMAs on (A,B); the 4 fragment reads of the next group in their shadow
 #define EHX_GROUP8(A, B, An, Bn, XS, QS)                                  \
   do {                                                                    \
-    An[0] = *(const f32x4*)((XS));                                        \
-    An[1] = *(const f32x4*)((XS) + 4096);                                 \
+    An[0] = frag_read((const char*)((XS)));                                        \
+    An[1] = frag_read((const char*)((XS) + 4096));                                 \
     _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                   \
       acc[0][0] = EHX_MFMA8(A[0][tt], B[0][tt], acc[0][0]);               \
       acc[1][0] = EHX_MFMA8(A[1][tt], B[0][tt], acc[1][0]);               \
@@ -325,8 +365,8 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
       acc[1][1] = EHX_MFMA8(A[1][tt], B[1][tt], acc[1][1]);               \
     }                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                    \
-    Bn[0] = *(const f32x4*)((QS));                                        \
-    Bn[1] = *(const f32x4*)((QS) + 4096);                                 \
+    Bn[0] = frag_read((const char*)((QS)));                                        \
+    Bn[1] = frag_read((const char*)((QS) + 4096));                                 \
     _Pragma("unroll") for (int tt = 2; tt < 4; ++tt) {                   \
       acc[0][0] = EHX_MFMA8(A[0][tt], B[0][tt], acc[0][0]);               \
       acc[1][0] = EHX_MFMA8(A[1][tt], B[0][tt], acc[1][0]);               \
@@ -352,10 +392,10 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
 
     // ---- group 0 (set 0): the late waves do their DMA duty here, one piece per MFMA ----
     if (late && step >= 1 && issued < total_steps) {
-      fa1[0] = *(const f32x4*)(xs + joff[1]);
-      fa1[1] = *(const f32x4*)(xs + 4096 + joff[1]);
-      fb1[0] = *(const f32x4*)(qs + joff[1]);
-      fb1[1] = *(const f32x4*)(qs + 4096 + joff[1]);
+      fa1[0] = frag_read((const char*)(xs + joff[1]));
+      fa1[1] = frag_read((const char*)(xs + 4096 + joff[1]));
+      fb1[0] = frag_read((const char*)(qs + joff[1]));
+      fb1[1] = frag_read((const char*)(qs + 4096 + joff[1]));
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         EHX_ONE8(fa0, fb0, m);
@@ -382,24 +422,24 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      hot_barrier();  // B_{step+1}: stage step+1 visible; ring slot `buf` is free again
+      if (!ABL_NO_BARRIER) hot_barrier();  // B_{step+1}: stage step+1 visible; ring slot `buf` is free again
       if (!late && issued < total_steps) {
 #pragma unroll
         for (int m = 4; m < 16; ++m) {
           EHX_ONE8(fa1, fb1, m);
-          if (m == 4) fa0[0] = *(const f32x4*)(xn + joff[0]);
-          if (m == 5) fa0[1] = *(const f32x4*)(xn + 4096 + joff[0]);
-          if (m == 6) fb0[0] = *(const f32x4*)(qn + joff[0]);
-          if (m == 7) fb0[1] = *(const f32x4*)(qn + 4096 + joff[0]);
+          if (m == 4) fa0[0] = frag_read((const char*)(xn + joff[0]));
+          if (m == 5) fa0[1] = frag_read((const char*)(xn + 4096 + joff[0]));
+          if (m == 6) fb0[0] = frag_read((const char*)(qn + joff[0]));
+          if (m == 7) fb0[1] = frag_read((const char*)(qn + 4096 + joff[0]));
           if (m >= 8 && m < 15) EHX_PIECE(m - 8);
           __builtin_amdgcn_sched_barrier(0);
         }
         EHX_STAGE_ADVANCE();
       } else {
-        fa0[0] = *(const f32x4*)(xn + joff[0]);
-        fa0[1] = *(const f32x4*)(xn + 4096 + joff[0]);
-        fb0[0] = *(const f32x4*)(qn + joff[0]);
-        fb0[1] = *(const f32x4*)(qn + 4096 + joff[0]);
+        fa0[0] = frag_read((const char*)(xn + joff[0]));
+        fa0[1] = frag_read((const char*)(xn + 4096 + joff[0]));
+        fb0[0] = frag_read((const char*)(qn + joff[0]));
+        fb0[1] = frag_read((const char*)(qn + 4096 + joff[0]));
 #pragma unroll
         for (int m = 4; m < 16; ++m) EHX_ONE8(fa1, fb1, m);
         __builtin_amdgcn_sched_barrier(0);
@@ -411,7 +451,11 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
     buf = nbuf;
     if (++kt == ktiles) {
       kt = 0;
-      epilogue(t);
+      if (!ABL_NO_EPILOGUE) epilogue(t);
+      else {
+        for (int rb = 0; rb < 2; ++rb)
+          for (int cb = 0; cb < 2; ++cb) asm volatile("" ::"v"(acc[rb][cb]));
+      }
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -426,16 +470,16 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
 #undef EHX_PIECE
 #undef EHX_STAGE_ADVANCE
 
-  // ---- final: sort every query's slots and publish the top-k' keys of this chunk ----
-  cold_barrier();
-  for (int qq = 0; qq < 32; ++qq) {
-    const int q = w * 32 + qq;
-    const int cq = cnt[q];
+  // ---- final: sort this wave's 64 lists and publish them: part[q][chunk*2 + wr][k'] ----
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  for (int ql = 0; ql < 64; ++ql) {
+    const int list = w * 64 + ql;
+    const int cq = cnt[list];
     const int nv = cq < (int)kCandSlots ? cq : (int)kCandSlots;
-    uint64_t key = lane < nv ? cand[q * kCandSlots + lane] : kKeyInf;
+    uint64_t key = lane < nv ? cand[list * kCandSlots + lane] : kKeyInf;
     key = wave_sort64_8(key, lane);
     if (lane < (int)a.kprime)
-      a.part[((size_t)(qt * kTileQ + q) * a.n_chunks + chunk) * a.kprime + lane] = key;
+      a.part[((size_t)(qt * kTileQ + wc * 64 + ql) * a.lists_total + a.list0 + chunk * 2 + wr) * a.kprime + lane] = key;
   }
 }
 
