@@ -26,7 +26,7 @@ class EhxError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("M", C.c_uint32), ("ef_construction", C.c_uint32),
                 ("ef", C.c_uint32), ("seed", C.c_uint64), ("initial_capacity", C.c_uint64),
-                ("reserved", C.c_uint32 * 8)]
+                ("build_batch", C.c_uint32), ("reserved", C.c_uint32 * 7)]
 
 
 class Stats(C.Structure):
@@ -70,6 +70,7 @@ SYMBOLS = {
     "ehx_gen_rows_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, _vp]),
     "ehx_graph_import": (C.c_int, [_vp, C.c_uint64, _u32p, _i32p, C.c_uint64, _u32p, _i32p, _u64p, _u32p,
                                    C.c_uint32, C.c_int32]),
+    "ehx_graph_export": (C.c_int, [_vp, _u32p, _i32p, _u32p, _u32p, C.c_uint64, _u64p, _u32p, _i32p]),
     "ehx_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "ehx_stats_reset": (C.c_int, [_vp]),
 }

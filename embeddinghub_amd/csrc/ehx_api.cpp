@@ -5,7 +5,10 @@
 // entry point fails with EHX_ENODEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
+#include <map>
+#include <random>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -104,6 +107,15 @@ struct ehx_space {
   uint32_t g_entry = 0;
   int g_maxlevel = -1;
   DevBuf<uint32_t> dVisited;
+  // GPU-side insertion state
+  uint64_t g_cap_rows = 0;       // rows the adjacency arrays are sized for
+  uint64_t g_lists_cap = 0, g_lists_used = 0;  // upper-level lists (M ids each)
+  std::vector<int32_t> h_levels;  // level of every node in the graph
+  std::default_random_engine level_rng;  // hnswlib: level_generator_ (libstdc++ minstd_rand0)
+  bool level_rng_seeded = false;
+  uint64_t g_stale_updates = 0;  // rows overwritten in place after their insertion (no graph repair)
+  DevBuf<uint32_t> dInsIds, dInsSel, dInsVislog, dItemTgt, dItemKind, dItemOff, dItemIds;
+  DevBuf<int32_t> dInsLevels, dItemLevel;
   unsigned long long* dGraphCounters = nullptr;  // n_dist, n_hops0, n_hops_up
 
   // key map (explicit keys only)
@@ -139,6 +151,15 @@ struct ehx_space {
     if (dUpLists) (void)hipFree(dUpLists);
     if (dGraphCounters) (void)hipFree(dGraphCounters);
     dVisited.release();
+    dInsIds.release();
+    dInsSel.release();
+    dInsVislog.release();
+    dItemTgt.release();
+    dItemKind.release();
+    dItemOff.release();
+    dItemIds.release();
+    dInsLevels.release();
+    dItemLevel.release();
     dQraw.release();
     dQ.release();
     dCand.release();
@@ -218,6 +239,206 @@ int ensure_rows(ehx_space* s, uint64_t rows) {
 }
 
 bool valid_space(ehx_space* s) { return s != nullptr; }
+
+// ---- graph mode: GPU-side insertion of rows [id0, id0+count) (already in HBM, stats computed) ----
+// hnswlib addPoint semantics (index.cc:36).  batch == 1: strictly sequential (the reference's
+// mutex-serialised order); batch > 1: rounds of concurrent inserts against the graph as it was before
+// the round (the analogue of hnswlib's multi-threaded add_items).
+int graph_ensure_arrays(ehx_space* s) {
+  const uint32_t M0 = 2 * s->params.M;
+  if (s->g_cap_rows >= s->cap && s->dAdj0) return EHX_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  uint32_t* na = nullptr;
+  uint32_t* nu = nullptr;
+  HIP_TRY(hipMalloc((void**)&na, s->cap * M0 * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc((void**)&nu, s->cap * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(na, 0xFF, s->cap * M0 * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(nu, 0xFF, s->cap * sizeof(uint32_t)));
+  if (s->dAdj0 && s->g_n) {
+    HIP_TRY(hipMemcpy(na, s->dAdj0, s->g_n * M0 * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(nu, s->dUpStart, s->g_n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+  }
+  if (s->dAdj0) (void)hipFree(s->dAdj0);
+  if (s->dUpStart) (void)hipFree(s->dUpStart);
+  s->dAdj0 = na;
+  s->dUpStart = nu;
+  s->g_cap_rows = s->cap;
+  return EHX_OK;
+}
+
+int graph_ensure_lists(ehx_space* s, uint64_t lists) {
+  if (lists <= s->g_lists_cap && s->dUpLists) return EHX_OK;
+  uint64_t want = s->g_lists_cap ? s->g_lists_cap : 1024;
+  while (want < lists) want *= 2;
+  HIP_TRY(hipDeviceSynchronize());
+  uint32_t* nl = nullptr;
+  HIP_TRY(hipMalloc((void**)&nl, want * s->params.M * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(nl, 0xFF, want * s->params.M * sizeof(uint32_t)));
+  if (s->dUpLists && s->g_lists_used)
+    HIP_TRY(hipMemcpy(nl, s->dUpLists, s->g_lists_used * s->params.M * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+  if (s->dUpLists) (void)hipFree(s->dUpLists);
+  s->dUpLists = nl;
+  s->g_lists_cap = want;
+  return EHX_OK;
+}
+
+int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
+  if (count == 0) return EHX_OK;
+  if (id0 != s->g_n)
+    return fail(EHX_EUNSUPPORTED, "graph mode: rows must be inserted in id order (graph covers %llu, next row %llu)",
+                (unsigned long long)s->g_n, (unsigned long long)id0);
+  const uint32_t M = s->params.M, M0 = 2 * M;
+  if (M0 > 64 || M < 2) return fail(EHX_EUNSUPPORTED, "M=%u not supported by the insertion kernels", M);
+  uint32_t efc = s->params.ef_construction > M ? s->params.ef_construction : M;  // max(efC, M)
+  if (efc > 2048) return fail(EHX_EUNSUPPORTED, "ef_construction=%u exceeds 2048", efc);
+  int rc;
+  if ((rc = graph_ensure_arrays(s))) return rc;
+  if (!s->level_rng_seeded) {
+    s->level_rng.seed((unsigned)s->params.seed);
+    s->level_rng_seeded = true;
+  }
+  const double mult = 1.0 / log(1.0 * M);
+  hipStream_t st = s->stream;
+  const uint32_t vis_words = (uint32_t)((s->cap + 31) / 32);
+  const uint32_t vislog_cap = 32768;
+  uint64_t pos = id0;
+  const uint64_t end = id0 + count;
+  std::vector<uint32_t> h_ids, h_sel, h_tgt, h_kind, h_off, h_inc, h_upstart;
+  std::vector<int32_t> h_lv, h_tlevel;
+  while (pos < end) {
+    // round size
+    uint64_t P = 1;
+    if (batch != 1 && s->g_n >= 64) {
+      P = s->g_n / 16;
+      const uint64_t cap = batch > 1 ? batch : 4096;
+      if (P > cap) P = cap;
+      if (P < 1) P = 1;
+    }
+    if (P > end - pos) P = end - pos;
+    // levels (getRandomLevel: -log(U(0,1)) * mult, a fresh distribution object per draw)
+    h_ids.resize(P);
+    h_lv.resize(P);
+    h_upstart.resize(P);
+    uint64_t new_lists = 0;
+    for (uint64_t i = 0; i < P; ++i) {
+      std::uniform_real_distribution<double> distribution(0.0, 1.0);
+      const int level = (int)(-log(distribution(s->level_rng)) * mult);
+      h_ids[i] = (uint32_t)(pos + i);
+      h_lv[i] = level;
+      h_upstart[i] = level > 0 ? (uint32_t)(s->g_lists_used + new_lists) : 0xFFFFFFFFu;
+      new_lists += (uint64_t)level;
+    }
+    if ((rc = graph_ensure_lists(s, s->g_lists_used + new_lists))) return rc;
+    s->g_lists_used += new_lists;
+    // the new nodes' own up_start entries (their adjacency rows are still all-0xFF)
+    HIP_TRY(hipMemcpyAsync(s->dUpStart + pos, h_upstart.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < P; ++i) s->h_levels.push_back(h_lv[i]);
+    if (s->g_n == 0) {  // very first node: becomes the entry point, nothing to link
+      s->g_entry = h_ids[0];
+      s->g_maxlevel = h_lv[0];
+      s->g_n = 1;
+      pos += 1;
+      if (P > 1) {  // keep the remaining draws: re-run them as their own round
+        // (P is 1 whenever the graph is empty, see the round-size rule above)
+      }
+      continue;
+    }
+    // ---- search + select on the device ----
+    const uint32_t max_sel_levels = (uint32_t)s->g_maxlevel + 1;
+    if ((rc = s->dInsIds.ensure(P))) return rc;
+    if ((rc = s->dInsLevels.ensure(P))) return rc;
+    if ((rc = s->dInsSel.ensure(P * max_sel_levels * (1 + M)))) return rc;
+    if ((rc = s->dVisited.ensure(P * vis_words))) return rc;
+    if ((rc = s->dInsVislog.ensure(P * (uint64_t)vislog_cap))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->dInsIds.p, h_ids.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->dInsLevels.p, h_lv.data(), P * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, P * vis_words * sizeof(uint32_t), st));
+    InsertArgs a;
+    a.X = s->dX;
+    a.inv_norm = s->dInv;
+    a.adj0 = s->dAdj0;
+    a.up_start = s->dUpStart;
+    a.up_lists = s->dUpLists;
+    a.visited = s->dVisited.p;
+    a.vislog = s->dInsVislog.p;
+    a.new_ids = s->dInsIds.p;
+    a.new_levels = s->dInsLevels.p;
+    a.sel = s->dInsSel.p;
+    a.ef = efc;
+    a.dims = s->dims;
+    a.ld = s->ld;
+    a.M = M;
+    a.M0 = M0;
+    a.vis_words = vis_words;
+    a.vislog_cap = vislog_cap;
+    a.max_sel_levels = max_sel_levels;
+    a.entry_point = s->g_entry;
+    a.max_level = s->g_maxlevel;
+    a.metric = s->metric;
+    HIP_TRY(launch_insert_search(a, (uint32_t)P, st));
+    h_sel.resize(P * max_sel_levels * (1 + M));
+    HIP_TRY(hipMemcpyAsync(h_sel.data(), s->dInsSel.p, h_sel.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // ---- work items for the link kernel (pure index shuffling) ----
+    h_tgt.clear();
+    h_tlevel.clear();
+    h_kind.clear();
+    h_off.clear();
+    h_inc.clear();
+    std::map<std::pair<int, uint32_t>, std::vector<uint32_t>> rev;  // (level, target) -> new ids in insertion order
+    for (uint64_t i = 0; i < P; ++i) {
+      const int top = std::min(h_lv[i], s->g_maxlevel);
+      for (int l = 0; l <= top; ++l) {
+        const uint32_t* o = &h_sel[(i * max_sel_levels + (uint32_t)l) * (1 + M)];
+        const uint32_t c = o[0];
+        h_tgt.push_back(h_ids[i]);
+        h_tlevel.push_back(l);
+        h_kind.push_back(1u);
+        h_off.push_back((uint32_t)h_inc.size());
+        for (uint32_t j = 0; j < c; ++j) {
+          h_inc.push_back(o[1 + j]);
+          rev[{l, o[1 + j]}].push_back(h_ids[i]);
+        }
+      }
+    }
+    for (auto& kv : rev) {
+      h_tgt.push_back(kv.first.second);
+      h_tlevel.push_back(kv.first.first);
+      h_kind.push_back(0u);
+      h_off.push_back((uint32_t)h_inc.size());
+      for (uint32_t v : kv.second) h_inc.push_back(v);
+    }
+    h_off.push_back((uint32_t)h_inc.size());
+    const uint32_t n_items = (uint32_t)h_tgt.size();
+    if (n_items) {
+      if ((rc = s->dItemTgt.ensure(n_items))) return rc;
+      if ((rc = s->dItemLevel.ensure(n_items))) return rc;
+      if ((rc = s->dItemKind.ensure(n_items))) return rc;
+      if ((rc = s->dItemOff.ensure(n_items + 1))) return rc;
+      if ((rc = s->dItemIds.ensure(h_inc.size() ? h_inc.size() : 1))) return rc;
+      HIP_TRY(hipMemcpyAsync(s->dItemTgt.p, h_tgt.data(), n_items * 4, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(s->dItemLevel.p, h_tlevel.data(), n_items * 4, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(s->dItemKind.p, h_kind.data(), n_items * 4, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(s->dItemOff.p, h_off.data(), (n_items + 1) * 4, hipMemcpyHostToDevice, st));
+      if (!h_inc.empty())
+        HIP_TRY(hipMemcpyAsync(s->dItemIds.p, h_inc.data(), h_inc.size() * 4, hipMemcpyHostToDevice, st));
+      HIP_TRY(launch_insert_link(a, n_items, s->dItemTgt.p, s->dItemLevel.p, s->dItemKind.p, s->dItemOff.p,
+                                 s->dItemIds.p, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    // entry point / top level (hnswlib: a node with a higher level becomes the entry point)
+    for (uint64_t i = 0; i < P; ++i) {
+      if (h_lv[i] > s->g_maxlevel) {
+        s->g_entry = h_ids[i];
+        s->g_maxlevel = h_lv[i];
+      }
+    }
+    s->g_n += P;
+    pos += P;
+  }
+  return EHX_OK;
+}
 
 struct ScanPlan {
   uint32_t q_tiles, q_rows, n_tiles, n_chunks, tiles_per_chunk, kprime, xcd_map, grid;
@@ -590,6 +811,7 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
   // resolve ids (upsert: an existing key keeps its label, index.cc:21-35); a key repeated inside the
   // batch resolves to one row and the LAST vector wins, as sequential Sets would leave it.
   std::vector<uint64_t> ids(n);
+  const uint64_t old_n = s->n;
   uint64_t next = s->n;
   std::vector<std::string> new_keys;
   for (size_t i = 0; i < n; ++i) {
@@ -641,6 +863,15 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
   HIP_TRY(launch_row_stats(s->dX, min_id, max_id - min_id + 1, s->dims, s->ld, s->metric, s->dInv, s->dRowp,
                            s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->params.mode == EHX_MODE_GRAPH) {
+    // new rows join the graph one at a time, in id order (ANNIndex::set -> addPoint, index.cc:36);
+    // rows overwritten in place keep their links (hnswlib's updatePoint repair is not built yet)
+    const uint64_t fresh = next - old_n;
+    s->g_stale_updates += n - fresh;
+    if (fresh && s->g_n == old_n && s->params.build_batch != 0xFFFFFFFFu) {
+      if ((rc = graph_insert(s, old_n, fresh, 1))) return rc;
+    }
+  }
   return EHX_OK;
 }
 
@@ -816,7 +1047,11 @@ int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_ro
   HIP_TRY(launch_gen_rows(seed, row0, n_rows, s->dims, s->ld, normalize, s->dX + s->n * s->ld, s->stream));
   HIP_TRY(launch_row_stats(s->dX, s->n, n_rows, s->dims, s->ld, s->metric, s->dInv, s->dRowp, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  const uint64_t old_n = s->n;
   s->n += n_rows;
+  if (s->params.mode == EHX_MODE_GRAPH && s->g_n == old_n && s->params.build_batch != 0xFFFFFFFFu) {
+    if ((rc = graph_insert(s, old_n, n_rows, s->params.build_batch))) return rc;
+  }
   return EHX_OK;
 }
 
@@ -883,6 +1118,53 @@ int ehx_graph_import(ehx_space* s, uint64_t n, const uint32_t* level0, const int
   s->g_n = n;
   s->g_entry = entry_point;
   s->g_maxlevel = max_level;
+  s->g_cap_rows = n;  // imported arrays are exactly n rows: re-grown on the next insert
+  s->g_lists_cap = total_lists ? total_lists : 1;
+  s->g_lists_used = total_lists;
+  s->h_levels.assign(levels, levels + n);
+  // continue the level sequence where a sequential build of these n nodes would have left it
+  s->level_rng.seed((unsigned)s->params.seed);
+  s->level_rng_seeded = true;
+  for (uint64_t i = 0; i < n; ++i) {
+    std::uniform_real_distribution<double> distribution(0.0, 1.0);
+    (void)distribution(s->level_rng);
+  }
+  return EHX_OK;
+}
+
+int ehx_graph_export(ehx_space* s, uint32_t* level0, int32_t* levels, uint32_t* up_start, uint32_t* up_lists,
+                     uint64_t up_lists_cap, uint64_t* n_lists, uint32_t* entry_point, int32_t* max_level) {
+  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  std::shared_lock<std::shared_mutex> rl(s->mu);
+  if (s->params.mode != EHX_MODE_GRAPH) return fail(EHX_EINVAL, "space '%s' is not in graph mode", s->name.c_str());
+  const uint64_t n = s->g_n;
+  const uint32_t M = s->params.M, M0 = 2 * M;
+  if (n_lists) *n_lists = s->g_lists_used;
+  if (entry_point) *entry_point = s->g_entry;
+  if (max_level) *max_level = s->g_maxlevel;
+  if (n == 0) return EHX_OK;
+  HIP_TRY(hipSetDevice(engine().device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (level0) {
+    std::vector<uint32_t> adj(n * M0);
+    HIP_TRY(hipMemcpy(adj.data(), s->dAdj0, adj.size() * 4, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) {
+      uint32_t c = 0;
+      for (uint32_t j = 0; j < M0; ++j) {
+        const uint32_t v = adj[i * M0 + j];
+        level0[i * (1 + M0) + 1 + j] = v == 0xFFFFFFFFu ? 0u : v;
+        if (v != 0xFFFFFFFFu) c = j + 1;
+      }
+      level0[i * (1 + M0)] = c;
+    }
+  }
+  if (levels) memcpy(levels, s->h_levels.data(), n * sizeof(int32_t));
+  if (up_start) HIP_TRY(hipMemcpy(up_start, s->dUpStart, n * 4, hipMemcpyDeviceToHost));
+  if (up_lists) {
+    if (up_lists_cap < s->g_lists_used) return fail(EHX_ERANGE, "upper-list buffer too small");
+    if (s->g_lists_used)
+      HIP_TRY(hipMemcpy(up_lists, s->dUpLists, s->g_lists_used * M * 4, hipMemcpyDeviceToHost));
+  }
   return EHX_OK;
 }
 

@@ -239,6 +239,26 @@ struct GraphArgs {
 size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap);
 hipError_t launch_graph_search(const GraphArgs& a, hipStream_t st);
 
+// graph-mode insertion (k_insert.hip)
+struct InsertArgs {
+  const float* X;
+  const float* inv_norm;
+  uint32_t* adj0;          // [cap][M0]
+  uint32_t* up_start;      // [cap]
+  uint32_t* up_lists;      // [*][M]
+  uint32_t* visited;       // [P][vis_words], zero on entry (and on exit)
+  uint32_t* vislog;        // [P][vislog_cap]
+  const uint32_t* new_ids; // [P]
+  const int32_t* new_levels;
+  uint32_t* sel;           // [P][max_sel_levels][1+M]: per level (count, ids farthest first)
+  uint32_t ef, dims, ld, M, M0, vis_words, vislog_cap, max_sel_levels, entry_point;
+  int max_level, metric;
+};
+size_t insert_lds_bytes(uint32_t ld, uint32_t ef);
+hipError_t launch_insert_search(const InsertArgs& a, uint32_t n_new, hipStream_t st);
+hipError_t launch_insert_link(const InsertArgs& a, uint32_t n_items, const uint32_t* tgt, const int32_t* tlevel,
+                              const uint32_t* kind, const uint32_t* inc_off, const uint32_t* inc_ids, hipStream_t st);
+
 // k-way merge of per-shard (dist, id) result lists [n_lists][nq][k] -> [nq][k]
 hipError_t launch_merge_lists(const uint64_t* ids, const float* dist, const uint32_t* count,
                               uint32_t nq, uint32_t k, uint32_t n_lists, uint64_t* out_ids,

@@ -1,0 +1,387 @@
+// Graph-mode insertion on the GPU: hnswlib's addPoint (call site
+// embeddinghub/embeddingstore/index.cc:36; algorithm restated in oracle/hnsw_oracle.hpp:
+// addPoint / searchBaseLayer / getNeighborsByHeuristic2 / mutuallyConnectNewElement) for a batch of
+// P new rows whose vectors are already in HBM.
+//
+//   insert_search_kernel — one wavefront per new node: greedy descent through the levels above the
+//     node's level, then per level L..0 a best-first search bounded by ef_construction over the
+//     graph AS IT IS BEFORE THE BATCH, followed by hnswlib's neighbour-selection heuristic; emits the
+//     selected neighbours per level (<= M each) and uses the closest one as the next level's entry.
+//   insert_link_kernel — one wavefront per (existing node, level) that gained new neighbours:
+//     appends the new ids while the list has room, otherwise re-selects with the heuristic over
+//     {new id} u old list exactly as mutuallyConnectNewElement does; also writes the new nodes' own
+//     lists (farthest first, hnswlib's pop order).
+//
+// With P = 1 this is hnswlib's sequential insertion: the graph is identical to the oracle's
+// whenever the distances that get compared are distinct (ties are ordered by id here and by heap
+// layout in libstdc++).  With P > 1 it is the analogue of hnswlib's multi-threaded add_items: new
+// nodes of one batch do not see each other, the result depends on the batch size, and parity is
+// recall parity, not graph identity.
+//
+// All distances use the canonical (oracle-order) arithmetic; for cosine spaces rows are normalised on
+// the fly (x * inv_norm), i.e. exactly the vectors hnswlib would have stored.
+#include "ehx_kernels.h"
+
+namespace ehx {
+
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint64_t wsort64(uint64_t key, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint64_t other = __shfl_xor(key, j, 64);
+      const bool up = (lane & k) == 0;
+      const bool lower = (lane & j) == 0;
+      const uint64_t mn = key < other ? key : other;
+      const uint64_t mx = key < other ? other : key;
+      key = (lower == up) ? mn : mx;
+    }
+  }
+  return key;
+}
+
+__device__ __forceinline__ uint32_t lb_lds(const uint64_t* a, uint32_t n, uint64_t key) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// canonical distance between two STORED rows (both normalised on the fly for cosine), one lane
+__device__ __forceinline__ float row_row_dist(int metric01, bool scale, const float* __restrict__ xa, float sa,
+                                              const float* __restrict__ xb, float sb, uint32_t dims) {
+  uint32_t body;
+  if ((dims & 15u) == 0 || (dims & 3u) == 0) body = dims;
+  else if (dims > 16) body = dims & ~15u;
+  else if (dims > 4) body = dims & ~3u;
+  else body = 0;
+  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+  for (uint32_t m = 0; m < body; m += 4) {
+    float4 a = *(const float4*)(xa + m);
+    float4 b = *(const float4*)(xb + m);
+    if (scale) {
+      a.x = ex_mul(a.x, sa); a.y = ex_mul(a.y, sa); a.z = ex_mul(a.z, sa); a.w = ex_mul(a.w, sa);
+      b.x = ex_mul(b.x, sb); b.y = ex_mul(b.y, sb); b.z = ex_mul(b.z, sb); b.w = ex_mul(b.w, sb);
+    }
+    if (metric01 == 0) {
+      const float d0 = ex_sub(a.x, b.x), d1 = ex_sub(a.y, b.y), d2 = ex_sub(a.z, b.z), d3 = ex_sub(a.w, b.w);
+      p0 = ex_add(p0, ex_mul(d0, d0)); p1 = ex_add(p1, ex_mul(d1, d1));
+      p2 = ex_add(p2, ex_mul(d2, d2)); p3 = ex_add(p3, ex_mul(d3, d3));
+    } else {
+      p0 = ex_add(p0, ex_mul(a.x, b.x)); p1 = ex_add(p1, ex_mul(a.y, b.y));
+      p2 = ex_add(p2, ex_mul(a.z, b.z)); p3 = ex_add(p3, ex_mul(a.w, b.w));
+    }
+  }
+  float res = ex_add(ex_add(ex_add(p0, p1), p2), p3);
+  if (body != dims) {
+    float tail = 0.0f;
+    for (uint32_t m = body; m < dims; ++m) {
+      const float a = scale ? ex_mul(xa[m], sa) : xa[m];
+      const float b = scale ? ex_mul(xb[m], sb) : xb[m];
+      if (metric01 == 0) {
+        const float d = ex_sub(a, b);
+        tail = ex_add(tail, ex_mul(d, d));
+      } else {
+        tail = ex_add(tail, ex_mul(a, b));
+      }
+    }
+    res = body ? ex_add(res, tail) : tail;
+  }
+  if (metric01 != 0) res = ex_sub(1.0f, res);
+  return res;
+}
+
+// hnswlib getNeighborsByHeuristic2 on one wave.  cand[0..nc): (dist-to-base, id<<1|flag) keys sorted
+// ascending; if nc < Msel all are kept.  Otherwise candidates are visited closest first and kept iff
+// no already-kept r has dist(r, c) < dist(c, base).  kept ids/keys go to kept[0..nk) in visiting
+// order (closest first).  Returns nk (uniform).
+__device__ __forceinline__ uint32_t select_heuristic(const InsertArgs& a, const uint64_t* cand, uint32_t nc,
+                                                     uint32_t Msel, uint64_t* kept, int lane) {
+  const int metric01 = a.metric == 0 ? 0 : 1;
+  const bool scale = a.metric == 2;
+  if (nc < Msel) {
+    for (uint32_t i = lane; i < nc; i += 64) kept[i] = cand[i];
+    __syncthreads();
+    return nc;
+  }
+  uint32_t nk = 0;
+  for (uint32_t i = 0; i < nc && nk < Msel; ++i) {
+    const uint64_t ck = cand[i];
+    const uint32_t cid = (uint32_t)(ck & 0xFFFFFFFFull) >> 1;
+    const float dq = ordered_to_f32((uint32_t)(ck >> 32));
+    bool bad = false;
+    if ((uint32_t)lane < nk) {
+      const uint32_t rid = (uint32_t)(kept[lane] & 0xFFFFFFFFull) >> 1;
+      const float d = row_row_dist(metric01, scale, a.X + (size_t)rid * a.ld, scale ? a.inv_norm[rid] : 1.0f,
+                                   a.X + (size_t)cid * a.ld, scale ? a.inv_norm[cid] : 1.0f, a.dims);
+      bad = d < dq;
+    }
+    if (!__any(bad)) {
+      if (lane == 0) kept[nk] = ck;
+      nk += 1;
+    }
+    __syncthreads();
+  }
+  return nk;
+}
+
+}  // namespace
+
+// LDS per wave: q[ld] | R[ef] | R2[ef] | batch[64] | kept[64] (u64) | ids[64] (u32)
+size_t insert_lds_bytes(uint32_t ld, uint32_t ef) { return (size_t)ld * 4 + (size_t)ef * 16 + 64 * 8 * 2 + 64 * 4; }
+
+__global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const uint32_t p = blockIdx.x;
+  float* qs = (float*)smem;
+  uint64_t* R = (uint64_t*)(smem + (size_t)a.ld * 4);
+  uint64_t* R2 = R + a.ef;
+  uint64_t* batch = R2 + a.ef;
+  uint64_t* kept = batch + 64;
+  uint32_t* ids_l = (uint32_t*)(kept + 64);
+  uint32_t* vis = a.visited + (size_t)p * a.vis_words;
+  uint32_t* vlog = a.vislog + (size_t)p * a.vislog_cap;
+
+  const uint32_t me = a.new_ids[p];
+  const int my_level = a.new_levels[p];
+  const int metric01 = a.metric == 0 ? 0 : 1;
+  const bool scale_x = a.metric == 2;
+  {  // the query is the new row itself, prepared the way hnswlib stores it
+    const float s = scale_x ? a.inv_norm[me] : 1.0f;
+    for (uint32_t i = lane; i < a.ld; i += 64) {
+      const float v = a.X[(size_t)me * a.ld + i];
+      qs[i] = scale_x ? ex_mul(v, s) : v;
+    }
+  }
+  __syncthreads();
+
+  auto lane_dist = [&](uint32_t count) -> float {
+    if ((uint32_t)lane >= count) return __builtin_inff();
+    const uint32_t id = ids_l[lane];
+    const float xs = scale_x ? a.inv_norm[id] : 1.0f;
+    return canon_dist_lane(metric01, qs, a.X + (size_t)id * a.ld, xs, scale_x, a.dims);
+  };
+  auto list_of = [&](uint32_t node, int level, uint32_t* width) -> const uint32_t* {
+    if (level == 0) {
+      *width = a.M0;
+      return a.adj0 + (size_t)node * a.M0;
+    }
+    *width = a.M;
+    return a.up_lists + ((size_t)a.up_start[node] + (uint32_t)(level - 1)) * a.M;
+  };
+
+  uint32_t* out = a.sel + (size_t)p * (a.max_sel_levels * (1 + a.M));
+  for (uint32_t i = lane; i < a.max_sel_levels * (1 + a.M); i += 64) out[i] = (i % (1 + a.M)) == 0 ? 0u : kNone;
+
+  // ---- greedy descent through the levels above the node's level (hnswlib addPoint) ----
+  uint32_t cur = a.entry_point;
+  if (lane == 0) ids_l[0] = cur;
+  __syncthreads();
+  float curdist = 0.0f;
+  if (my_level < a.max_level) {
+    curdist = __shfl(lane_dist(1), 0, 64);
+    for (int level = a.max_level; level > my_level; --level) {
+      bool changed = true;
+      while (changed) {
+        changed = false;
+        uint32_t width;
+        const uint32_t* lst = list_of(cur, level, &width);
+        uint32_t nb = kNone;
+        if (lane < (int)width) nb = lst[lane];
+        const uint32_t cnt = __builtin_popcountll(__ballot(nb != kNone));
+        if (lane < (int)cnt) ids_l[lane] = nb;
+        __syncthreads();
+        float m = lane_dist(cnt);
+        uint32_t mi = (uint32_t)lane;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const float od = __shfl_xor(m, o, 64);
+          const uint32_t oi = __shfl_xor(mi, o, 64);
+          if (od < m || (od == m && oi < mi)) {
+            m = od;
+            mi = oi;
+          }
+        }
+        if (m < curdist) {
+          curdist = m;
+          cur = ids_l[mi];
+          changed = true;
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- per level: searchBaseLayer(ef_construction) + heuristic(M) ----
+  const uint32_t ef = a.ef;
+  const int top_level = my_level < a.max_level ? my_level : a.max_level;
+  for (int level = top_level; level >= 0; --level) {
+    uint32_t nlog = 0;
+    if (lane == 0) ids_l[0] = cur;
+    __syncthreads();
+    const float d0 = __shfl(lane_dist(1), 0, 64);
+    uint32_t nR = 1;
+    if (lane == 0) {
+      R[0] = ((uint64_t)f32_to_ordered(d0) << 32) | ((uint64_t)cur << 1);
+      atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+      vlog[0] = cur;
+    }
+    nlog = 1;
+    __syncthreads();
+    for (;;) {
+      uint32_t idx = kNone;
+      for (uint32_t base = 0; base < nR && idx == kNone; base += 64) {
+        const uint32_t i = base + lane;
+        const bool un = i < nR && !(R[i] & 1ull);
+        const uint64_t m = __ballot(un);
+        if (m) idx = base + (uint32_t)__builtin_ctzll(m);
+      }
+      if (idx == kNone) break;
+      const uint32_t c = (uint32_t)(R[idx] & 0xFFFFFFFFull) >> 1;
+      __syncthreads();
+      if (lane == 0) R[idx] |= 1ull;
+      uint32_t width;
+      const uint32_t* lst = list_of(c, level, &width);
+      uint32_t nb = kNone;
+      if (lane < (int)width) nb = lst[lane];
+      bool fresh = false;
+      if (nb != kNone) {
+        const uint32_t bit = 1u << (nb & 31);
+        fresh = !(atomicOr(&vis[nb >> 5], bit) & bit);
+      }
+      const uint64_t fmask = __ballot(fresh);
+      const uint32_t nfresh = __builtin_popcountll(fmask);
+      const uint32_t slot = __builtin_popcountll(fmask & ((1ull << lane) - 1ull));
+      if (fresh) {
+        ids_l[slot] = nb;
+        if (nlog + slot < a.vislog_cap) vlog[nlog + slot] = nb;
+      }
+      nlog += nfresh;
+      __syncthreads();
+      if (nfresh == 0) continue;
+      uint64_t mykey = kKeyInf;
+      {
+        const float d = lane_dist(nfresh);
+        if ((uint32_t)lane < nfresh) mykey = ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)ids_l[lane] << 1);
+      }
+      mykey = wsort64(mykey, lane);
+      batch[lane] = mykey;
+      __syncthreads();
+      if ((uint32_t)lane < nfresh) {
+        const uint32_t pos = lb_lds(R, nR, mykey) + lane;
+        if (pos < ef) R2[pos] = mykey;
+      }
+      for (uint32_t j = lane; j < nR; j += 64) {
+        const uint64_t kj = R[j];
+        const uint32_t pos = j + lb_lds(batch, nfresh, kj);
+        if (pos < ef) R2[pos] = kj;
+      }
+      __syncthreads();
+      nR = nR + nfresh < ef ? nR + nfresh : ef;
+      uint64_t* t = R;
+      R = R2;
+      R2 = t;
+    }
+    // reset the visited bits of this search (hnswlib takes a fresh visited tag per searchBaseLayer)
+    if (nlog <= a.vislog_cap) {
+      for (uint32_t i = lane; i < nlog; i += 64) {
+        const uint32_t v = vlog[i];
+        atomicAnd(&vis[v >> 5], ~(1u << (v & 31)));
+      }
+    } else {
+      for (uint32_t i = lane; i < a.vis_words; i += 64) vis[i] = 0u;
+    }
+    __syncthreads();
+    // heuristic over the (sorted) results; selection is always with M, even at level 0
+    const uint32_t nk = select_heuristic(a, R, nR, a.M, kept, lane);
+    // own list: farthest first (hnswlib pops the max-heap); next entry = the closest selected
+    uint32_t* o = out + (size_t)level * (1 + a.M);
+    if (lane == 0) o[0] = nk;
+    if ((uint32_t)lane < nk) o[1 + lane] = (uint32_t)(kept[nk - 1 - lane] & 0xFFFFFFFFull) >> 1;
+    cur = (uint32_t)(kept[0] & 0xFFFFFFFFull) >> 1;
+    __syncthreads();
+  }
+}
+
+hipError_t launch_insert_search(const InsertArgs& a, uint32_t n_new, hipStream_t st) {
+  const size_t lds = insert_lds_bytes(a.ld, a.ef);
+  static size_t attr_set = 0;
+  if (lds > 64 * 1024 && lds > attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)insert_search_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = lds;
+  }
+  hipLaunchKernelGGL(insert_search_kernel, dim3(n_new), dim3(64), lds, st, a);
+  return hipGetLastError();
+}
+
+// One wave per work item w: target node tgt[w] at level tlevel[w] receives the new ids
+// inc_ids[inc_off[w] .. inc_off[w+1]) in that order.  kind[w] == 1: the target IS a new node and the
+// ids are its own selected list (already farthest first) — plain overwrite.
+__global__ __launch_bounds__(64) void insert_link_kernel(const InsertArgs a, const uint32_t* __restrict__ tgt,
+                                                         const int32_t* __restrict__ tlevel,
+                                                         const uint32_t* __restrict__ kind,
+                                                         const uint32_t* __restrict__ inc_off,
+                                                         const uint32_t* __restrict__ inc_ids) {
+  __shared__ uint64_t cand[64];
+  __shared__ uint64_t kept[64];
+  const int lane = threadIdx.x;
+  const uint32_t w = blockIdx.x;
+  const uint32_t s = tgt[w];
+  const int level = tlevel[w];
+  const uint32_t width = level == 0 ? a.M0 : a.M;
+  uint32_t* lst = level == 0 ? a.adj0 + (size_t)s * a.M0
+                             : a.up_lists + ((size_t)a.up_start[s] + (uint32_t)(level - 1)) * a.M;
+  const uint32_t b0 = inc_off[w], b1 = inc_off[w + 1];
+  if (kind[w] == 1) {
+    if ((uint32_t)lane < width) lst[lane] = (b0 + lane < b1) ? inc_ids[b0 + lane] : kNone;
+    return;
+  }
+  const int metric01 = a.metric == 0 ? 0 : 1;
+  const bool scale = a.metric == 2;
+  const float ss = scale ? a.inv_norm[s] : 1.0f;
+  for (uint32_t b = b0; b < b1; ++b) {
+    const uint32_t nid = inc_ids[b];
+    uint32_t nb = kNone;
+    if ((uint32_t)lane < width) nb = lst[lane];
+    const uint32_t cnt = __builtin_popcountll(__ballot(nb != kNone));
+    if (cnt < width) {
+      if (lane == 0) lst[cnt] = nid;
+      __syncthreads();
+      continue;
+    }
+    // full: candidates = {new} u list with distances to s, heuristic with the level's max degree
+    const uint32_t id = (uint32_t)lane < cnt ? nb : ((uint32_t)lane == cnt ? nid : kNone);
+    uint64_t key = kKeyInf;
+    if (id != kNone) {
+      const float d = row_row_dist(metric01, scale, a.X + (size_t)id * a.ld, scale ? a.inv_norm[id] : 1.0f,
+                                   a.X + (size_t)s * a.ld, ss, a.dims);
+      key = ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)id << 1);
+    }
+    key = wsort64(key, lane);
+    cand[lane] = key;
+    __syncthreads();
+    const uint32_t nk = select_heuristic(a, cand, cnt + 1, width, kept, lane);
+    // rewrite farthest first
+    if ((uint32_t)lane < width) lst[lane] = (uint32_t)lane < nk ? (uint32_t)(kept[nk - 1 - lane] & 0xFFFFFFFFull) >> 1 : kNone;
+    __syncthreads();
+  }
+}
+
+hipError_t launch_insert_link(const InsertArgs& a, uint32_t n_items, const uint32_t* tgt, const int32_t* tlevel,
+                              const uint32_t* kind, const uint32_t* inc_off, const uint32_t* inc_ids, hipStream_t st) {
+  if (n_items == 0) return hipSuccess;
+  hipLaunchKernelGGL(insert_link_kernel, dim3(n_items), dim3(64), 0, st, a, tgt, tlevel, kind, inc_off, inc_ids);
+  return hipGetLastError();
+}
+
+}  // namespace ehx

@@ -22,14 +22,15 @@ def _f32(a):
 
 class Space:
     def __init__(self, name, dims, metric=_lib.METRIC_L2SQ, mode=_lib.MODE_FLAT, M=0, ef_construction=0,
-                 ef=0, seed=0, initial_capacity=0, _handle=None):
+                 ef=0, seed=0, initial_capacity=0, build_batch=0, _handle=None):
         self._L = _lib.load()
         self.name, self.dims, self.metric = name, int(dims), metric
+        self._M = M or 16
         if _handle is not None:
             self._h = _handle
             return
         p = Params(mode=mode, M=M, ef_construction=ef_construction, ef=ef, seed=seed,
-                   initial_capacity=initial_capacity)
+                   initial_capacity=initial_capacity, build_batch=build_batch)
         h = C.c_void_p()
         nm = name.encode()
         check(self._L.ehx_space_create(nm, len(nm), self.dims, metric, 0, C.byref(p), C.byref(h)))
@@ -103,6 +104,26 @@ class Space:
         check(self._L.ehx_graph_import(self._h, l0.shape[0], P(l0, C.c_uint32), P(lv, C.c_int32), len(items),
                                        P(un, C.c_uint32), P(ul, C.c_int32), P(off, C.c_uint64),
                                        P(ids, C.c_uint32), int(entry_point), int(max_level)))
+
+    def graph_export(self):
+        """-> level0 [n, 1+2M] u32, levels [n] i32, upper {(node, level): ids}, entry_point, max_level."""
+        n = len(self)
+        nl, ep, ml = C.c_uint64(), C.c_uint32(), C.c_int32()
+        check(self._L.ehx_graph_export(self._h, None, None, None, None, 0, C.byref(nl), C.byref(ep), C.byref(ml)))
+        M = self._M
+        l0 = np.zeros((n, 1 + 2 * M), dtype=np.uint32)
+        lv = np.zeros(n, dtype=np.int32)
+        us = np.zeros(n, dtype=np.uint32)
+        ul = np.zeros((max(nl.value, 1), M), dtype=np.uint32)
+        P = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
+        check(self._L.ehx_graph_export(self._h, P(l0, C.c_uint32), P(lv, C.c_int32), P(us, C.c_uint32),
+                                       P(ul, C.c_uint32), ul.shape[0], C.byref(nl), C.byref(ep), C.byref(ml)))
+        upper = {}
+        for i in np.nonzero(lv > 0)[0]:
+            for level in range(1, int(lv[i]) + 1):
+                row = ul[int(us[i]) + level - 1]
+                upper[(int(i), level)] = row[row != 0xFFFFFFFF].copy()
+        return l0, lv, upper, ep.value, ml.value
 
     def set_ef(self, ef):
         check(self._L.ehx_space_set_ef(self._h, ef))

@@ -78,7 +78,10 @@ typedef struct ehx_params {
   uint32_t ef;              /* search ef; effective ef = max(ef, k)         */
   uint64_t seed;            /* level generator seed                         */
   uint64_t initial_capacity;/* rows; 0 -> 128 (index.h:21), doubles on fill */
-  uint32_t reserved[8];
+  uint32_t build_batch;     /* graph mode: rows inserted concurrently per round by bulk loads
+                               (ehx_fill_synthetic); 0 = auto, 1 = strictly sequential (hnswlib order).
+                               ehx_set / ehx_set_batch always insert sequentially.                     */
+  uint32_t reserved[7];
 } ehx_params;
 
 /* Work and time counters, same definitions as the oracle. */
@@ -165,7 +168,8 @@ int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_ro
 int ehx_gen_rows_device(void* stream, uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims,
                         int normalize, float* d_out /* n_rows x dims */);
 
-/* ---- graph import/export (graph mode; persistence and strict-parity checks) ----
+/* ---- graph import (graph mode; persistence and strict-parity checks).  Graph spaces also build their
+ * graph on the GPU as rows are Set (hnswlib addPoint semantics, k_insert.hip). ----
  * level0: n x (1 + 2M) u32 rows = [count, ids...]; levels: n ints; upper lists are passed as a CSR
  * over (node, level>=1): upper_off has n_upper+1 entries into upper_ids, upper_node/upper_level
  * name each list. */
@@ -173,6 +177,12 @@ int ehx_graph_import(ehx_space* s, uint64_t n, const uint32_t* level0, const int
                      uint64_t n_upper, const uint32_t* upper_node, const int32_t* upper_level,
                      const uint64_t* upper_off, const uint32_t* upper_ids, uint32_t entry_point,
                      int32_t max_level);
+
+/* Export of the graph built on the GPU (or imported): level0 [n][1+2M] u32 = (count, ids...), levels [n],
+ * up_start [n] (index of a node's first upper list or 0xFFFFFFFF; lists of levels 1..L are consecutive),
+ * up_lists [n_lists][M] padded with 0xFFFFFFFF.  Any output pointer may be NULL. */
+int ehx_graph_export(ehx_space* s, uint32_t* level0, int32_t* levels, uint32_t* up_start, uint32_t* up_lists,
+                     uint64_t up_lists_cap, uint64_t* n_lists, uint32_t* entry_point, int32_t* max_level);
 
 /* ---- stats ---- */
 int ehx_stats(ehx_space* s, ehx_stats_t* out);

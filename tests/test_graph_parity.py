@@ -20,7 +20,8 @@ def _build(n, d, em, om, seed=0, M=16):
     X = rng.standard_normal((n, d)).astype(np.float32)
     h = pyoracle.Hnsw(d, om, n, M=M)
     h.add_rows(X)
-    s = ehx.Space.unique("graph", d, metric=em, mode=ehx.MODE_GRAPH, M=M, initial_capacity=n)
+    s = ehx.Space.unique("graph", d, metric=em, mode=ehx.MODE_GRAPH, M=M, initial_capacity=n,
+                         build_batch=0xFFFFFFFF)  # no GPU build: the oracle's graph is imported
     s.set_batch(["k%d" % i for i in range(n)], X)
     l0, lv, upper = h.export_graph()
     s.graph_import(l0, lv, upper, h.enterpoint, h.maxlevel)
@@ -88,3 +89,62 @@ def test_small_graphs_and_k_larger_than_index():
             np.testing.assert_array_equal(ids[i, :c], labels[i, :c])
             assert dist[i, :c].tobytes() == dists[i, :c].tobytes()
         s.drop()
+
+
+# ---- GPU-side insertion (k_insert.hip): ANNIndex::set -> addPoint, index.cc:20-37 -----------------
+def _same_graph(s, h):
+    l0, lv, upper, ep, ml = s.graph_export()
+    ol0, olv, oupper = h.export_graph()
+    assert (ep, ml) == (h.enterpoint, h.maxlevel)
+    np.testing.assert_array_equal(lv, olv)
+    bad = np.nonzero((l0 != ol0).any(axis=1))[0]
+    assert len(bad) == 0, "level-0 lists differ at nodes %s" % bad[:10]
+    assert sorted(upper) == sorted(oupper)
+    for key in oupper:
+        np.testing.assert_array_equal(upper[key], oupper[key])
+
+
+@pytest.mark.parametrize("em,om", METRICS)
+@pytest.mark.parametrize("n,d", [(700, 32), (1500, 64), (400, 20)])
+def test_sequential_gpu_build_is_the_oracles_graph(n, d, em, om):
+    rng = np.random.default_rng(n * 7 + d)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    h = pyoracle.Hnsw(d, om, n)
+    h.add_rows(X)
+    s = ehx.Space.unique("gbuild", d, metric=em, mode=ehx.MODE_GRAPH, initial_capacity=n)
+    for i in range(40):  # single Sets ...
+        s.set("k%d" % i, X[i])
+    s.set_batch(["k%d" % i for i in range(40, n)], X[40:])  # ... and a batch: both insert sequentially
+    _same_graph(s, h)
+    Q = rng.standard_normal((16, d)).astype(np.float32)
+    for ef in (10, 100):
+        h.set_ef(ef)
+        s.set_ef(ef)
+        labels, dists, counts, _, _ = h.search_batch(Q, 10, threads=1)
+        ids, dist, cnt = s.knn(Q, 10)
+        np.testing.assert_array_equal(ids, labels)
+        assert dist.tobytes() == dists.tobytes()
+    s.drop()
+
+
+def test_batched_gpu_build_recall_parity_with_oracle():
+    n, d, nq, k = 20000, 64, 256, 10
+    X = pyoracle.gen_rows(ehx.SEED_CORPUS, 0, n, d)
+    Q = pyoracle.gen_rows(ehx.SEED_QUERY, 0, nq, d)
+    h = pyoracle.Hnsw(d, pyoracle.METRIC_L2, n)
+    h.add_rows(X)
+    s = ehx.Space.unique("gbulk", d, metric=ehx.METRIC_L2SQ, mode=ehx.MODE_GRAPH, initial_capacity=n)
+    s.fill_synthetic(ehx.SEED_CORPUS, 0, n, False)  # bulk load: rounds of concurrent inserts
+    truth, _, _ = pyoracle.exhaustive(X, Q, k, pyoracle.METRIC_L2)
+    for ef in (50, 200):
+        h.set_ef(ef)
+        s.set_ef(ef)
+        labels, _, _, _, _ = h.search_batch(Q, k, threads=8)
+        ids, _, cnt = s.knn(Q, k)
+        assert (cnt == k).all()
+        r_o = np.mean([len(set(labels[i]) & set(truth[i])) / k for i in range(nq)])
+        r_g = np.mean([len(set(ids[i]) & set(truth[i])) / k for i in range(nq)])
+        assert r_g >= r_o - 0.02, (ef, r_g, r_o)
+    l0, lv, upper, ep, ml = s.graph_export()
+    assert (l0[:, 0] >= 1).all() and (l0[:, 0] <= 32).all()  # every node linked, degree bound respected
+    s.drop()
