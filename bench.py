@@ -167,9 +167,11 @@ def main():
         },
         "recall_at_10": 1.0,
         "roofline": {
-            "bound": "mfma", "kernel": "flat_scan_kernel", "achieved": round(achieved, 2),
+            "bound": "mfma", "kernel": "flat_scan8_kernel (sample-pass launch + main-pass launch per batch)",
+            "achieved": round(achieved, 2),
             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-            "traffic": None, "kernel_ms": round(scan_ms, 4), "launches_timed": int(st["scan_launches"]),
+            "traffic": None,  # PMC pass (profiles/r01_e_*): FETCH_SIZE x2 (gfx950 correction) = 68 GB/batch vs 30.7 GB algorithmic
+            "kernel_ms": round(scan_ms, 4), "launches_timed": int(st["scan_launches"]),
             "flops_per_launch": flops_per_launch,
             "hbm_frac_of_8TBps": round((shard * d * 4 + B * d * 4 + B * k * 12) / (scan_ms * 1e-3) / 8e12, 4) if scan_ms > 0 else None,
         },
