@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <map>
 #include <random>
 #include <cmath>
@@ -138,6 +139,24 @@ struct ehx_space {
   static constexpr int kRing = 64;
   hipEvent_t ring[kRing][2] = {};
   uint64_t ring_count = 0;
+
+  // micro-batcher: concurrent small ehx_knn calls are coalesced into one device batch
+  struct KnnReq {
+    const float* q;
+    size_t nq;
+    uint32_t k;
+    uint64_t* ids;
+    float* dist;
+    uint32_t* cnt;
+    int rc = 0;
+    bool done = false;
+    char err[256] = "";
+  };
+  std::mutex bq_mu;
+  std::condition_variable bq_cv;
+  std::vector<KnnReq*> bq;
+  bool bq_leader = false;
+  std::atomic<uint64_t> n_coalesced_batches{0}, n_coalesced_queries{0};
 
   // stats
   std::atomic<uint64_t> n_queries{0}, n_dist{0}, n_rerank{0}, bytes_algo{0};
@@ -922,8 +941,8 @@ int ehx_knn_device(ehx_space* s, void* stream, size_t n_queries, const float* d_
   return knn_device_locked(s, (hipStream_t)stream, n_queries, d_queries, k, d_out_ids, d_out_dist, d_out_count);
 }
 
-int ehx_knn(ehx_space* s, size_t n_queries, const float* queries, uint32_t k, uint64_t* out_ids,
-            float* out_dist, uint32_t* out_count) {
+static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries, uint32_t k, uint64_t* out_ids,
+                           float* out_dist, uint32_t* out_count) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   if (n_queries == 0) return EHX_OK;
   if (!out_count) return fail(EHX_EINVAL, "out_count is NULL");
@@ -950,6 +969,95 @@ int ehx_knn(ehx_space* s, size_t n_queries, const float* queries, uint32_t k, ui
   HIP_TRY(hipMemcpyAsync(out_count, s->dOutCount.p, n_queries * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return EHX_OK;
+}
+
+// Small calls (the reference's usage: one query per RPC, server.cc:172-210; Go Nearest, online.go:63) are
+// coalesced: the first caller becomes the leader, gathers every request that queued up meanwhile
+// (same k, up to 1024 queries), runs ONE device batch and hands the results back.  An uncontended call
+// runs immediately; under load the batch size grows by itself with the scan time.
+constexpr size_t kCoalesceMaxCall = 64;     // calls above this size already are batches
+constexpr size_t kCoalesceMaxBatch = 1024;
+
+int ehx_knn(ehx_space* s, size_t n_queries, const float* queries, uint32_t k, uint64_t* out_ids,
+            float* out_dist, uint32_t* out_count) {
+  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  if (n_queries == 0) return EHX_OK;
+  if (n_queries > kCoalesceMaxCall || k == 0 || !queries || !out_ids || !out_dist || !out_count)
+    return knn_host_direct(s, n_queries, queries, k, out_ids, out_dist, out_count);
+  ehx_space::KnnReq me;
+  me.q = queries;
+  me.nq = n_queries;
+  me.k = k;
+  me.ids = out_ids;
+  me.dist = out_dist;
+  me.cnt = out_count;
+  std::unique_lock<std::mutex> lk(s->bq_mu);
+  s->bq.push_back(&me);
+  if (s->bq_leader) {
+    s->bq_cv.wait(lk, [&] { return me.done; });
+    if (me.rc) snprintf(g_err, sizeof(g_err), "%s", me.err);
+    return me.rc;
+  }
+  s->bq_leader = true;
+  std::vector<ehx_space::KnnReq*> group;
+  std::vector<float> q;
+  std::vector<uint64_t> ids;
+  std::vector<float> dist;
+  std::vector<uint32_t> cnt;
+  while (!s->bq.empty()) {
+    // one group = the oldest request's k, in arrival order, up to kCoalesceMaxBatch queries
+    group.clear();
+    const uint32_t gk = s->bq.front()->k;
+    size_t total = 0;
+    for (auto it = s->bq.begin(); it != s->bq.end();) {
+      if ((*it)->k == gk && total + (*it)->nq <= kCoalesceMaxBatch) {
+        total += (*it)->nq;
+        group.push_back(*it);
+        it = s->bq.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    lk.unlock();
+    int rc;
+    if (group.size() == 1) {
+      ehx_space::KnnReq* r = group[0];
+      rc = knn_host_direct(s, r->nq, r->q, gk, r->ids, r->dist, r->cnt);
+    } else {
+      q.resize(total * s->dims);
+      ids.resize(total * gk);
+      dist.resize(total * gk);
+      cnt.resize(total);
+      size_t off = 0;
+      for (auto* r : group) {
+        memcpy(q.data() + off * s->dims, r->q, r->nq * s->dims * sizeof(float));
+        off += r->nq;
+      }
+      rc = knn_host_direct(s, total, q.data(), gk, ids.data(), dist.data(), cnt.data());
+      off = 0;
+      for (auto* r : group) {
+        if (rc == EHX_OK) {
+          memcpy(r->ids, ids.data() + off * gk, r->nq * gk * sizeof(uint64_t));
+          memcpy(r->dist, dist.data() + off * gk, r->nq * gk * sizeof(float));
+          memcpy(r->cnt, cnt.data() + off, r->nq * sizeof(uint32_t));
+        }
+        off += r->nq;
+      }
+      s->n_coalesced_batches += 1;
+      s->n_coalesced_queries += total;
+    }
+    lk.lock();
+    for (auto* r : group) {
+      r->rc = rc;
+      if (rc) snprintf(r->err, sizeof(r->err), "%s", g_err);
+      r->done = true;
+    }
+    s->bq_cv.notify_all();
+  }
+  s->bq_leader = false;
+  lk.unlock();
+  if (me.rc) snprintf(g_err, sizeof(g_err), "%s", me.err);
+  return me.rc;
 }
 
 int ehx_knn_keys(ehx_space* s, size_t n_queries, const float* queries, uint32_t k, uint64_t* out_ids,
