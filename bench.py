@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=6000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=16000)
     ap.add_argument("--cpu-sample-queries", type=int, default=256)
     return ap.parse_args()
 
@@ -59,7 +59,7 @@ def cpu_baseline(args):
     h = pyoracle.Hnsw(d, pyoracle.METRIC_COSINE, S)
     build_sec = h.add_rows(X)
     best = None
-    for ef in (10, 20, 40, 80, 160, 320, 640, 1280, 2560):
+    for ef in (40, 160, 640, 1280, 2560, 5120, 10240):
         h.set_ef(ef)
         labels, _, _, sec, st = h.search_batch(Q, k, threads=cores)
         recall = float(np.mean([len(set(labels[i]) & set(truth[i])) / k for i in range(nq)]))
