@@ -390,22 +390,27 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
     const char* qn = smem + kQOff8 + nbuf * kQStage8 + b_row_off;
     const bool has_next = step + 1 < total_steps;
 
+    // Every MFMA of the stage is emitted exactly once (no alternative code paths around them, so the
+    // accumulators stay in place — an earlier version with duplicated MFMA sequences made the
+    // compiler copy all 64 accumulator registers between two register sets every stage); only the
+    // DMA pieces and the next stage's fragment reads sit behind wave-uniform flags.
+    const bool late_dma = late && step >= 1 && issued < total_steps;
+    const bool early_dma = !late && has_next && issued < total_steps;
+
     // ---- group 0 (set 0): the late waves do their DMA duty here, one piece per MFMA ----
-    if (late && step >= 1 && issued < total_steps) {
-      fa1[0] = frag_read((const char*)(xs + joff[1]));
-      fa1[1] = frag_read((const char*)(xs + 4096 + joff[1]));
-      fb1[0] = frag_read((const char*)(qs + joff[1]));
-      fb1[1] = frag_read((const char*)(qs + 4096 + joff[1]));
+    fa1[0] = frag_read((const char*)(xs + joff[1]));
+    fa1[1] = frag_read((const char*)(xs + 4096 + joff[1]));
+    fb1[0] = frag_read((const char*)(qs + joff[1]));
+    fb1[1] = frag_read((const char*)(qs + 4096 + joff[1]));
 #pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        EHX_ONE8(fa0, fb0, m);
-        if (m < 6) EHX_PIECE(m);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int m = 0; m < 16; ++m) {
+      EHX_ONE8(fa0, fb0, m);
+      if (m < 6) {
+        if (late_dma) EHX_PIECE(m);
       }
-      EHX_STAGE_ADVANCE();
-    } else {
-      EHX_GROUP8(fa0, fb0, fa1, fb1, xs + joff[1], qs + joff[1]);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (late_dma) EHX_STAGE_ADVANCE();
     EHX_GROUP8(fa1, fb1, fa0, fb0, xs + joff[2], qs + joff[2]);
     EHX_GROUP8(fa0, fb0, fa1, fb1, xs + joff[3], qs + joff[3]);
 
@@ -423,31 +428,22 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       if (!ABL_NO_BARRIER) hot_barrier();  // B_{step+1}: stage step+1 visible; ring slot `buf` is free again
-      if (!late && issued < total_steps) {
-#pragma unroll
-        for (int m = 4; m < 16; ++m) {
-          EHX_ONE8(fa1, fb1, m);
-          if (m == 4) fa0[0] = frag_read((const char*)(xn + joff[0]));
-          if (m == 5) fa0[1] = frag_read((const char*)(xn + 4096 + joff[0]));
-          if (m == 6) fb0[0] = frag_read((const char*)(qn + joff[0]));
-          if (m == 7) fb0[1] = frag_read((const char*)(qn + 4096 + joff[0]));
-          if (m >= 8 && m < 15) EHX_PIECE(m - 8);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        EHX_STAGE_ADVANCE();
-      } else {
-        fa0[0] = frag_read((const char*)(xn + joff[0]));
-        fa0[1] = frag_read((const char*)(xn + 4096 + joff[0]));
-        fb0[0] = frag_read((const char*)(qn + joff[0]));
-        fb0[1] = frag_read((const char*)(qn + 4096 + joff[0]));
-#pragma unroll
-        for (int m = 4; m < 16; ++m) EHX_ONE8(fa1, fb1, m);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-#pragma unroll
-      for (int m = 4; m < 16; ++m) EHX_ONE8(fa1, fb1, m);
     }
+#pragma unroll
+    for (int m = 4; m < 16; ++m) {
+      EHX_ONE8(fa1, fb1, m);
+      if (has_next) {
+        if (m == 4) fa0[0] = frag_read((const char*)(xn + joff[0]));
+        if (m == 5) fa0[1] = frag_read((const char*)(xn + 4096 + joff[0]));
+        if (m == 6) fb0[0] = frag_read((const char*)(qn + joff[0]));
+        if (m == 7) fb0[1] = frag_read((const char*)(qn + 4096 + joff[0]));
+      }
+      if (m >= 8 && m < 15) {
+        if (early_dma) EHX_PIECE(m - 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (early_dma) EHX_STAGE_ADVANCE();
     buf = nbuf;
     if (++kt == ktiles) {
       kt = 0;
