@@ -558,7 +558,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   const uint32_t n_tiles = (uint32_t)((s->n + kTileRows - 1) / kTileRows);
   const uint32_t lpc = scan_lists_per_chunk();
   uint32_t sample_tiles = 0;
-  if (lpc == 2 && n_tiles >= 16384) sample_tiles = (n_tiles / 32 + 255) / 256 * 256;
+  if (lpc == 2 && n_tiles >= 4096) sample_tiles = (n_tiles / 32 + 255) / 256 * 256;
   const ScanPlan p = plan_scan((uint32_t)nq, n_tiles - sample_tiles, k, E.n_cus);   // main pass
   const ScanPlan ps = plan_scan((uint32_t)nq, sample_tiles, k, E.n_cus);            // sample pass
   const uint32_t lists_main = p.n_chunks * lpc, lists_sample = sample_tiles ? ps.n_chunks * lpc : 0;

@@ -37,7 +37,7 @@ constexpr uint32_t kThrKeyOff8 = kQOff8 + kRing8 * kQStage8;       // u64 thr_ke
 constexpr uint32_t kThrFOff8 = kThrKeyOff8 + kLists8 * 8;          // f32 thr_f[512]
 constexpr uint32_t kCntOff8 = kThrFOff8 + kLists8 * 4;             // i32 cnt[512]
 constexpr uint32_t kFlagOff8 = kCntOff8 + kLists8 * 4;             // i32 flags[4]
-constexpr uint32_t kRowpOff8 = kFlagOff8 + 16;                     // float2 rowp_lds[4][128]
+constexpr uint32_t kRowpOff8 = kFlagOff8 + 32;                     // (flags[4], simd_rank[4]) then float2 rowp_lds[4][128]
 constexpr uint32_t kLdsBytes8 = kRowpOff8 + 4 * 128 * 8;
 static_assert(kLdsBytes8 <= 160 * 1024, "LDS budget");
 
@@ -160,7 +160,6 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 2, wc = w & 3;
-  const bool late = w >= 4;  // DMA duty half a stage after the sibling wave on the same SIMD
   const int h = lane >> 5, i31 = lane & 31;
 
   uint32_t qt, chunk;
@@ -179,6 +178,7 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
   float* thr_f = (float*)(smem + kThrFOff8);
   int* cnt = (int*)(smem + kCntOff8);
   int* flags = (int*)(smem + kFlagOff8);
+  int* simd_rank = flags + 4;
   const float2* rowp_lds = (const float2*)(smem + kRowpOff8);
   uint64_t* cand = a.cand + (size_t)blockIdx.x * ((size_t)kLists8 * kCandSlots);
   unsigned long long* gthr = a.gthr + (size_t)qt * kTileQ;  // global per-query thresholds of this query tile
@@ -191,6 +191,14 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
     cnt[tid] = 0;
   }
   if (tid < 4) flags[tid] = 0;
+  if (tid < 4) simd_rank[tid] = 0;
+  __syncthreads();
+  // Which of the two waves sharing this wave's SIMD am I?  (HW_REG_HW_ID.SIMD_ID, bits 5:4.)  The two
+  // do their DMA duty half a stage apart so that one's DMA issue overlaps the other's MFMA issue.
+  const int simd_id = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+  int my_rank = 0;
+  if (lane == 0) my_rank = atomicAdd(&simd_rank[simd_id & 3], 1);
+  const bool late = (__builtin_amdgcn_readfirstlane(my_rank) & 1) != 0;
 
   const uint32_t tile_begin = a.tile0 + chunk * a.tiles_per_chunk;
   uint32_t tile_end = tile_begin + a.tiles_per_chunk;
