@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <map>
 #include <random>
+#include <set>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -395,6 +396,7 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
     a.entry_point = s->g_entry;
     a.max_level = s->g_maxlevel;
     a.metric = s->metric;
+    a.exclude_self = 0;
     HIP_TRY(launch_insert_search(a, (uint32_t)P, st));
     h_sel.resize(P * max_sel_levels * (1 + M));
     HIP_TRY(hipMemcpyAsync(h_sel.data(), s->dInsSel.p, h_sel.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -455,6 +457,146 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
     }
     s->g_n += P;
     pos += P;
+  }
+  return EHX_OK;
+}
+
+// ---- graph mode: hnswlib updatePoint(data, id, 1.0) for a row overwritten in place (index.cc:21-36:
+// an existing key keeps its label and addPoint takes its update branch) ----
+int graph_update(ehx_space* s, uint32_t id) {
+  if (id >= s->g_n) return EHX_OK;
+  if (s->g_entry == id && s->g_n == 1) return EHX_OK;
+  const uint32_t M = s->params.M, M0 = 2 * M;
+  const uint32_t efc = s->params.ef_construction > M ? s->params.ef_construction : M;
+  hipStream_t st = s->stream;
+  const int level = s->h_levels[id];
+  int rc;
+  InsertArgs a;
+  a.X = s->dX;
+  a.inv_norm = s->dInv;
+  a.adj0 = s->dAdj0;
+  a.up_start = s->dUpStart;
+  a.up_lists = s->dUpLists;
+  a.ef = efc;
+  a.dims = s->dims;
+  a.ld = s->ld;
+  a.M = M;
+  a.M0 = M0;
+  a.metric = s->metric;
+  a.entry_point = s->g_entry;
+  a.max_level = s->g_maxlevel;
+  a.exclude_self = 1;
+  auto read_list = [&](uint32_t node, int layer, std::vector<uint32_t>* out) -> int {
+    const uint32_t width = layer == 0 ? M0 : M;
+    uint32_t buf[64];
+    const uint32_t* src;
+    if (layer == 0) {
+      src = s->dAdj0 + (size_t)node * M0;
+    } else {
+      uint32_t us = 0;
+      HIP_TRY(hipMemcpy(&us, s->dUpStart + node, 4, hipMemcpyDeviceToHost));
+      src = s->dUpLists + ((size_t)us + (uint32_t)(layer - 1)) * M;
+    }
+    HIP_TRY(hipMemcpy(buf, src, width * 4, hipMemcpyDeviceToHost));
+    out->clear();
+    for (uint32_t j = 0; j < width && buf[j] != 0xFFFFFFFFu; ++j) out->push_back(buf[j]);
+    return EHX_OK;
+  };
+  // part 1: the one-hop neighbours re-select their links among {id} u one-hop u two-hop
+  std::vector<uint32_t> one, two, h_neigh, h_off, h_cand;
+  for (int layer = 0; layer <= level; ++layer) {
+    if ((rc = read_list(id, layer, &one))) return rc;
+    if (one.empty()) continue;
+    std::set<uint32_t> sCand;
+    sCand.insert(id);
+    for (uint32_t o : one) {
+      sCand.insert(o);
+      if ((rc = read_list(o, layer, &two))) return rc;
+      for (uint32_t t : two) sCand.insert(t);
+    }
+    h_neigh.assign(one.begin(), one.end());
+    std::sort(h_neigh.begin(), h_neigh.end());
+    h_neigh.erase(std::unique(h_neigh.begin(), h_neigh.end()), h_neigh.end());
+    h_off.clear();
+    h_cand.clear();
+    for (uint32_t ng : h_neigh) {
+      h_off.push_back((uint32_t)h_cand.size());
+      for (uint32_t c : sCand)
+        if (c != ng) h_cand.push_back(c);
+    }
+    h_off.push_back((uint32_t)h_cand.size());
+    const uint32_t n_items = (uint32_t)h_neigh.size();
+    if ((rc = s->dItemTgt.ensure(n_items))) return rc;
+    if ((rc = s->dItemOff.ensure(n_items + 1))) return rc;
+    if ((rc = s->dItemIds.ensure(h_cand.size() ? h_cand.size() : 1))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->dItemTgt.p, h_neigh.data(), n_items * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->dItemOff.p, h_off.data(), (n_items + 1) * 4, hipMemcpyHostToDevice, st));
+    if (!h_cand.empty())
+      HIP_TRY(hipMemcpyAsync(s->dItemIds.p, h_cand.data(), h_cand.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(launch_update_neigh(a, n_items, s->dItemTgt.p, layer, s->dItemOff.p, s->dItemIds.p, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  // part 2: repairConnectionsForUpdate = search from the entry point with the new vector, drop the
+  // node itself from the results, reconnect with isUpdate semantics
+  const uint32_t vis_words = (uint32_t)((s->cap + 31) / 32);
+  const uint32_t vislog_cap = 32768;
+  const uint32_t max_sel_levels = (uint32_t)s->g_maxlevel + 1;
+  if ((rc = s->dInsIds.ensure(1))) return rc;
+  if ((rc = s->dInsLevels.ensure(1))) return rc;
+  if ((rc = s->dInsSel.ensure((size_t)max_sel_levels * (1 + M)))) return rc;
+  if ((rc = s->dVisited.ensure(vis_words))) return rc;
+  if ((rc = s->dInsVislog.ensure(vislog_cap))) return rc;
+  const int32_t lv32 = level;
+  HIP_TRY(hipMemcpyAsync(s->dInsIds.p, &id, 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(s->dInsLevels.p, &lv32, 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, vis_words * sizeof(uint32_t), st));
+  a.visited = s->dVisited.p;
+  a.vislog = s->dInsVislog.p;
+  a.new_ids = s->dInsIds.p;
+  a.new_levels = s->dInsLevels.p;
+  a.sel = s->dInsSel.p;
+  a.vis_words = vis_words;
+  a.vislog_cap = vislog_cap;
+  a.max_sel_levels = max_sel_levels;
+  HIP_TRY(launch_insert_search(a, 1, st));
+  std::vector<uint32_t> h_sel((size_t)max_sel_levels * (1 + M));
+  HIP_TRY(hipMemcpyAsync(h_sel.data(), s->dInsSel.p, h_sel.size() * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<uint32_t> h_tgt, h_kind, h_ioff, h_inc;
+  std::vector<int32_t> h_tlevel;
+  for (int l = 0; l <= level; ++l) {
+    const uint32_t* o = &h_sel[(size_t)l * (1 + M)];
+    const uint32_t c = o[0];
+    if (c == 0) continue;  // level skipped by hnswlib: lists untouched
+    h_tgt.push_back(id);
+    h_tlevel.push_back(l);
+    h_kind.push_back(1u);
+    h_ioff.push_back((uint32_t)h_inc.size());
+    for (uint32_t j = 0; j < c; ++j) h_inc.push_back(o[1 + j]);
+    for (uint32_t j = 0; j < c; ++j) {  // reverse links, in hnswlib's order (selectedNeighbors order)
+      h_tgt.push_back(o[1 + j]);
+      h_tlevel.push_back(l);
+      h_kind.push_back(2u);
+      h_ioff.push_back((uint32_t)h_inc.size());
+      h_inc.push_back(id);
+    }
+  }
+  h_ioff.push_back((uint32_t)h_inc.size());
+  const uint32_t n_items = (uint32_t)h_tgt.size();
+  if (n_items) {
+    if ((rc = s->dItemTgt.ensure(n_items))) return rc;
+    if ((rc = s->dItemLevel.ensure(n_items))) return rc;
+    if ((rc = s->dItemKind.ensure(n_items))) return rc;
+    if ((rc = s->dItemOff.ensure(n_items + 1))) return rc;
+    if ((rc = s->dItemIds.ensure(h_inc.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->dItemTgt.p, h_tgt.data(), n_items * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->dItemLevel.p, h_tlevel.data(), n_items * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->dItemKind.p, h_kind.data(), n_items * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->dItemOff.p, h_ioff.data(), (n_items + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->dItemIds.p, h_inc.data(), h_inc.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(launch_insert_link(a, n_items, s->dItemTgt.p, s->dItemLevel.p, s->dItemKind.p, s->dItemOff.p,
+                               s->dItemIds.p, st));
+    HIP_TRY(hipStreamSynchronize(st));
   }
   return EHX_OK;
 }
@@ -818,11 +960,36 @@ int ehx_space_set_ef(ehx_space* s, uint32_t ef) {
   return EHX_OK;
 }
 
+static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, const size_t* klens, const float* vecs);
+
 int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t* klens, const float* vecs) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   if (n == 0) return EHX_OK;
   if (!keys || !klens || !vecs) return fail(EHX_EINVAL, "NULL argument");
   std::unique_lock<std::shared_mutex> wl(s->mu);
+  if (s->params.mode == EHX_MODE_GRAPH && n > 1 && s->params.build_batch != 0xFFFFFFFFu) {
+    // graph mode replays a batch in call order; when it re-writes keys (known ones, or the same key
+    // twice) every row must be in HBM exactly when its turn comes, so such batches go row by row
+    bool rewrite = false;
+    {
+      std::set<std::string> seen;
+      for (size_t i = 0; i < n && !rewrite; ++i) {
+        std::string k(keys[i], klens[i]);
+        rewrite = s->key_to_id.count(k) != 0 || !seen.insert(std::move(k)).second;
+      }
+    }
+    if (rewrite) {
+      for (size_t i = 0; i < n; ++i) {
+        int rc = set_batch_locked(s, 1, keys + i, klens + i, vecs + i * s->dims);
+        if (rc) return rc;
+      }
+      return EHX_OK;
+    }
+  }
+  return set_batch_locked(s, n, keys, klens, vecs);
+}
+
+static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, const size_t* klens, const float* vecs) {
   if (s->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
   if (s->implicit_keys) return fail(EHX_EINVAL, "space '%s' holds synthetic rows with implicit keys", s->name.c_str());
   HIP_TRY(hipSetDevice(engine().device));
@@ -885,10 +1052,18 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
   if (s->params.mode == EHX_MODE_GRAPH) {
     // new rows join the graph one at a time, in id order (ANNIndex::set -> addPoint, index.cc:36);
     // rows overwritten in place keep their links (hnswlib's updatePoint repair is not built yet)
-    const uint64_t fresh = next - old_n;
-    s->g_stale_updates += n - fresh;
-    if (fresh && s->g_n == old_n && s->params.build_batch != 0xFFFFFFFFu) {
-      if ((rc = graph_insert(s, old_n, fresh, 1))) return rc;
+    // in call order: a fresh key is an insertion, a known key hnswlib's update-in-place
+    if (s->g_n == old_n && s->params.build_batch != 0xFFFFFFFFu) {
+      if ((rc = graph_ensure_arrays(s))) return rc;
+      for (size_t i = 0; i < n; ++i) {
+        if (ids[i] >= s->g_n) {
+          if ((rc = graph_insert(s, ids[i], 1, 1))) return rc;
+        } else {
+          if ((rc = graph_update(s, (uint32_t)ids[i]))) return rc;
+        }
+      }
+    } else {
+      s->g_stale_updates += n - (next - old_n);
     }
   }
   return EHX_OK;

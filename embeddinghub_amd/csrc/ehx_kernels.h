@@ -253,9 +253,12 @@ struct InsertArgs {
   uint32_t* sel;           // [P][max_sel_levels][1+M]: per level (count, ids farthest first)
   uint32_t ef, dims, ld, M, M0, vis_words, vislog_cap, max_sel_levels, entry_point;
   int max_level, metric;
+  uint32_t exclude_self;   // 1: repairConnectionsForUpdate (drop the node itself from the search results)
 };
 size_t insert_lds_bytes(uint32_t ld, uint32_t ef);
 hipError_t launch_insert_search(const InsertArgs& a, uint32_t n_new, hipStream_t st);
+hipError_t launch_update_neigh(const InsertArgs& a, uint32_t n_items, const uint32_t* neigh, int level,
+                               const uint32_t* cand_off, const uint32_t* cand_ids, hipStream_t st);
 hipError_t launch_insert_link(const InsertArgs& a, uint32_t n_items, const uint32_t* tgt, const int32_t* tlevel,
                               const uint32_t* kind, const uint32_t* inc_off, const uint32_t* inc_ids, hipStream_t st);
 

@@ -300,6 +300,24 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
       for (uint32_t i = lane; i < a.vis_words; i += 64) vis[i] = 0u;
     }
     __syncthreads();
+    if (a.exclude_self) {
+      // repairConnectionsForUpdate: the node being updated is part of the graph and finds itself;
+      // hnswlib filters it out of the results (and skips the level if nothing else is left)
+      uint32_t pos = kNone;
+      for (uint32_t base = 0; base < nR && pos == kNone; base += 64) {
+        const uint32_t i = base + lane;
+        const uint64_t m = __ballot(i < nR && ((uint32_t)(R[i] & 0xFFFFFFFFull) >> 1) == me);
+        if (m) pos = base + (uint32_t)__builtin_ctzll(m);
+      }
+      if (pos != kNone) {
+        for (uint32_t i = lane; i < nR; i += 64) R2[i] = R[i];
+        __syncthreads();
+        for (uint32_t i = pos + lane; i + 1 < nR; i += 64) R[i] = R2[i + 1];
+        __syncthreads();
+        nR -= 1;
+      }
+      if (nR == 0) continue;  // level skipped: own list and entry for the next level unchanged
+    }
     // heuristic over the (sorted) results; selection is always with M, even at level 0
     const uint32_t nk = select_heuristic(a, R, nR, a.M, kept, lane);
     // own list: farthest first (hnswlib pops the max-heap); next entry = the closest selected
@@ -354,6 +372,7 @@ __global__ __launch_bounds__(64) void insert_link_kernel(const InsertArgs a, con
     uint32_t nb = kNone;
     if ((uint32_t)lane < width) nb = lst[lane];
     const uint32_t cnt = __builtin_popcountll(__ballot(nb != kNone));
+    if (kind[w] == 2 && __any(nb == nid)) continue;  // isUpdate: the link already exists
     if (cnt < width) {
       if (lane == 0) lst[cnt] = nid;
       __syncthreads();
@@ -375,6 +394,69 @@ __global__ __launch_bounds__(64) void insert_link_kernel(const InsertArgs a, con
     if ((uint32_t)lane < width) lst[lane] = (uint32_t)lane < nk ? (uint32_t)(kept[nk - 1 - lane] & 0xFFFFFFFFull) >> 1 : kNone;
     __syncthreads();
   }
+}
+
+// hnswlib updatePoint, first half: every one-hop neighbour `neigh` of the updated node re-selects its
+// links among sCand \ {neigh} (sCand = the updated node, its one-hop and two-hop neighbours): keep the
+// min(ef_construction, |candidates|) closest to neigh, run the heuristic with the level's max degree,
+// rewrite the list farthest first.  One wave per neighbour; candidates are passed by the host.
+__global__ __launch_bounds__(64) void update_neigh_kernel(const InsertArgs a, const uint32_t* __restrict__ neigh,
+                                                          int level, const uint32_t* __restrict__ cand_off,
+                                                          const uint32_t* __restrict__ cand_ids) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* R = (uint64_t*)smem;
+  uint64_t* R2 = R + a.ef;
+  uint64_t* batch = R2 + a.ef;
+  uint64_t* kept = batch + 64;
+  const int lane = threadIdx.x;
+  const uint32_t w = blockIdx.x;
+  const uint32_t s = neigh[w];
+  const uint32_t c0 = cand_off[w], c1 = cand_off[w + 1];
+  const uint32_t width = level == 0 ? a.M0 : a.M;
+  uint32_t* lst = level == 0 ? a.adj0 + (size_t)s * a.M0
+                             : a.up_lists + ((size_t)a.up_start[s] + (uint32_t)(level - 1)) * a.M;
+  const int metric01 = a.metric == 0 ? 0 : 1;
+  const bool scale = a.metric == 2;
+  const float ss = scale ? a.inv_norm[s] : 1.0f;
+  const uint32_t keep = (c1 - c0) < a.ef ? (c1 - c0) : a.ef;
+  uint32_t nR = 0;
+  for (uint32_t base = c0; base < c1; base += 64) {
+    const uint32_t n_here = c1 - base < 64 ? c1 - base : 64;
+    uint64_t key = kKeyInf;
+    if ((uint32_t)lane < n_here) {
+      const uint32_t id = cand_ids[base + lane];
+      const float d = row_row_dist(metric01, scale, a.X + (size_t)s * a.ld, ss, a.X + (size_t)id * a.ld,
+                                   scale ? a.inv_norm[id] : 1.0f, a.dims);
+      key = ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)id << 1);
+    }
+    key = wsort64(key, lane);
+    batch[lane] = key;
+    __syncthreads();
+    if ((uint32_t)lane < n_here) {
+      const uint32_t pos = lb_lds(R, nR, key) + lane;
+      if (pos < keep) R2[pos] = key;
+    }
+    for (uint32_t j = lane; j < nR; j += 64) {
+      const uint64_t kj = R[j];
+      const uint32_t pos = j + lb_lds(batch, n_here, kj);
+      if (pos < keep) R2[pos] = kj;
+    }
+    __syncthreads();
+    nR = nR + n_here < keep ? nR + n_here : keep;
+    uint64_t* t = R;
+    R = R2;
+    R2 = t;
+  }
+  const uint32_t nk = select_heuristic(a, R, nR, width, kept, lane);
+  if ((uint32_t)lane < width) lst[lane] = (uint32_t)lane < nk ? (uint32_t)(kept[nk - 1 - lane] & 0xFFFFFFFFull) >> 1 : kNone;
+}
+
+hipError_t launch_update_neigh(const InsertArgs& a, uint32_t n_items, const uint32_t* neigh, int level,
+                               const uint32_t* cand_off, const uint32_t* cand_ids, hipStream_t st) {
+  if (n_items == 0) return hipSuccess;
+  const size_t lds = (size_t)a.ef * 16 + 64 * 8 * 2;
+  hipLaunchKernelGGL(update_neigh_kernel, dim3(n_items), dim3(64), lds, st, a, neigh, level, cand_off, cand_ids);
+  return hipGetLastError();
 }
 
 hipError_t launch_insert_link(const InsertArgs& a, uint32_t n_items, const uint32_t* tgt, const int32_t* tlevel,

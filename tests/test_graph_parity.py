@@ -148,3 +148,51 @@ def test_batched_gpu_build_recall_parity_with_oracle():
     l0, lv, upper, ep, ml = s.graph_export()
     assert (l0[:, 0] >= 1).all() and (l0[:, 0] <= 32).all()  # every node linked, degree bound respected
     s.drop()
+
+
+def test_update_in_place_repairs_the_graph_like_hnswlib():
+    """index.cc:21-36: Set on an existing key keeps the label and takes hnswlib's updatePoint branch
+    (re-selection of the one-hop neighbours' links among the two-hop set + repairConnectionsForUpdate)."""
+    rng = np.random.default_rng(77)
+    n, d = 900, 32
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    h = pyoracle.Hnsw(d, pyoracle.METRIC_L2, n)
+    s = ehx.Space.unique("gupd", d, metric=ehx.METRIC_L2SQ, mode=ehx.MODE_GRAPH, initial_capacity=n)
+    h.add_rows(X)
+    s.set_batch(["k%d" % i for i in range(n)], X)
+    _same_graph(s, h)
+    upd = [3, 500, 11, h.enterpoint, 899, 3]  # incl. the entry point and a key updated twice
+    for j, i in enumerate(upd):
+        v = rng.standard_normal(d).astype(np.float32)
+        X[i] = v
+        h.add(v, i)           # addPoint with an existing label -> updatePoint
+        s.set("k%d" % i, v)
+        _same_graph(s, h)
+    # a batch that mixes fresh keys and re-writes, replayed in call order
+    Y = rng.standard_normal((6, d)).astype(np.float32)
+    keys = ["k%d" % n, "k7", "k%d" % (n + 1), "k%d" % n, "k8", "k%d" % (n + 2)]
+    labels = [n, 7, n + 1, n, 8, n + 2]
+    h.resize(n + 8)
+    for v, lab in zip(Y, labels):
+        h.add(v, lab)
+    s.set_batch(keys, Y)
+    _same_graph(s, h)
+    Q = rng.standard_normal((16, d)).astype(np.float32)
+    h.set_ef(64)
+    s.set_ef(64)
+    labels_o, dists_o, _, _, _ = h.search_batch(Q, 10, threads=1)
+    ids, dist, _ = s.knn(Q, 10)
+    np.testing.assert_array_equal(ids, labels_o)
+    assert dist.tobytes() == dists_o.tobytes()
+    s.drop()
+
+
+def test_reference_update_test_in_graph_mode():  # index_test.cc:39-49 through the graph path
+    s = ehx.Space.unique("gabc", 3, mode=ehx.MODE_GRAPH)
+    s.set("a", [0, 1, 0])
+    s.set("b", [1, 1, 0])
+    s.set("c", [1, 0, 0])
+    assert s.knn_keys([0, 1, 0], 2) == [["a", "b"]]
+    s.set("a", [0, -1, 0])
+    assert s.knn_keys([0, 1, 0], 1) == [["b"]]
+    s.drop()
