@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--dims", type=int, default=768)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--rows-dtype", choices=["f32", "f16"], default="f32",
+                    help="row storage in HBM (f16 = BASELINE configs[5] storage; arithmetic stays fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=16000)
     ap.add_argument("--cpu-sample-queries", type=int, default=256)
@@ -109,7 +111,8 @@ def main():
     row0, shard = shard_range(args.rows, G, rank)
     B, d, k = args.batch, args.dims, args.k
     t_fill = time.time()
-    space = ehx.Space("bench-r%d" % rank, d, metric=ehx.METRIC_COSINE, initial_capacity=shard)
+    space = ehx.Space("bench-r%d" % rank, d, metric=ehx.METRIC_COSINE, initial_capacity=shard,
+                      dtype=ehx.DTYPE_F16 if args.rows_dtype == "f16" else ehx.DTYPE_F32)
     space.fill_synthetic(ehx.SEED_CORPUS, row0, shard, True)
     torch.cuda.synchronize()
     t_fill = time.time() - t_fill
@@ -161,7 +164,7 @@ def main():
             "workload": "%dx%d cosine (EHX-GAUSS-1 seed %d), batch=%d, k=%d; exhaustive fp32 MFMA scan + "
                         "canonical re-rank = exact kNN (recall@10 = 1.0 vs exhaustive by construction)" % (
                             args.rows, d, ehx.SEED_CORPUS, B, k),
-            "rows_total": args.rows, "rows_per_gpu": shard, "dims": d, "batch": B, "k": k, "path": "flat",
+            "rows_total": args.rows, "rows_per_gpu": shard, "rows_dtype": args.rows_dtype, "dims": d, "batch": B, "k": k, "path": "flat",
             "parallelism": "row-shard x%d + all-gather top-k merge" % G if G > 1 else "single GPU",
             "fill_seconds": round(t_fill, 2),
         },
@@ -173,7 +176,7 @@ def main():
             "traffic": None,  # PMC pass (profiles/r01_e_*): FETCH_SIZE x2 (gfx950 correction) = 68 GB/batch vs 30.7 GB algorithmic
             "kernel_ms": round(scan_ms, 4), "launches_timed": int(st["scan_launches"]),
             "flops_per_launch": flops_per_launch,
-            "hbm_frac_of_8TBps": round((shard * d * 4 + B * d * 4 + B * k * 12) / (scan_ms * 1e-3) / 8e12, 4) if scan_ms > 0 else None,
+            "hbm_frac_of_8TBps": round((shard * d * (2 if args.rows_dtype == "f16" else 4) + B * d * 4 + B * k * 12) / (scan_ms * 1e-3) / 8e12, 4) if scan_ms > 0 else None,
         },
         "n_uncertified": int(st["n_uncertified"]),
     }

@@ -13,6 +13,7 @@ OK, EINVAL, ENOTFOUND, EEXISTS, EIMMUTABLE, ENODEVICE, ENOMEM, ERANGE, EUNSUPPOR
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9)
 METRIC_L2SQ, METRIC_IP, METRIC_COSINE = 0, 1, 2
 MODE_FLAT, MODE_GRAPH = 0, 1
+DTYPE_F32, DTYPE_F16 = 0, 1
 MAX_K = 48
 SEED_CORPUS, SEED_QUERY = 20250211, 20250212
 

@@ -96,7 +96,11 @@ struct ehx_space {
   std::shared_mutex mu;        // writers: set/drop/reserve ; readers: knn/get
 
   // HBM-resident state
-  float* dX = nullptr;       // [cap][ld]
+  void* dX = nullptr;        // [cap][ld] rows, fp32 or fp16 (x_half)
+  int x_half = 0;            // EHX_DTYPE_F16: rows stored as IEEE binary16 (flat mode only)
+  size_t esz = sizeof(float);  // bytes per stored element
+  char* xrow(uint64_t id) const { return (char*)dX + id * ld * esz; }
+  const float* xf32() const { return (const float*)dX; }
   float2* dRowp = nullptr;   // [cap]
   float* dInv = nullptr;     // [cap] (cosine)
   uint64_t cap = 0, n = 0;
@@ -217,10 +221,10 @@ int grow(ehx_space* s, uint64_t rows) {
   uint64_t want = round_up(rows < 256 ? 256 : rows, 256);
   if (want <= s->cap) return EHX_OK;
   HIP_TRY(hipDeviceSynchronize());  // no search may still read the old arrays
-  float* nx = nullptr;
+  char* nx = nullptr;
   float2* nr = nullptr;
   float* ni = nullptr;
-  HIP_TRY(hipMalloc((void**)&nx, want * s->ld * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&nx, want * s->ld * s->esz));
   hipError_t e1 = hipMalloc((void**)&nr, want * sizeof(float2));
   hipError_t e2 = hipMalloc((void**)&ni, want * sizeof(float));
   if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -232,11 +236,11 @@ int grow(ehx_space* s, uint64_t rows) {
   }
   const uint64_t keep = s->n;
   if (keep) {
-    HIP_TRY(hipMemcpyAsync(nx, s->dX, keep * s->ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(nx, s->dX, keep * s->ld * s->esz, hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(nr, s->dRowp, keep * sizeof(float2), hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(ni, s->dInv, keep * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
   }
-  HIP_TRY(hipMemsetAsync(nx + keep * s->ld, 0, (want - keep) * s->ld * sizeof(float), s->stream));
+  HIP_TRY(hipMemsetAsync(nx + keep * s->ld * s->esz, 0, (want - keep) * s->ld * s->esz, s->stream));
   HIP_TRY(hipMemsetAsync(ni + keep, 0, (want - keep) * sizeof(float), s->stream));
   HIP_TRY(launch_rowp_pad(nr, keep, want - keep, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -375,7 +379,7 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
     HIP_TRY(hipMemcpyAsync(s->dInsLevels.p, h_lv.data(), P * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, P * vis_words * sizeof(uint32_t), st));
     InsertArgs a;
-    a.X = s->dX;
+    a.X = s->xf32();
     a.inv_norm = s->dInv;
     a.adj0 = s->dAdj0;
     a.up_start = s->dUpStart;
@@ -472,7 +476,7 @@ int graph_update(ehx_space* s, uint32_t id) {
   const int level = s->h_levels[id];
   int rc;
   InsertArgs a;
-  a.X = s->dX;
+  a.X = s->xf32();
   a.inv_norm = s->dInv;
   a.adj0 = s->dAdj0;
   a.up_start = s->dUpStart;
@@ -649,7 +653,7 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, (size_t)nq * vis_words * sizeof(uint32_t), st));
   GraphArgs a;
   a.Q = s->dQ.p;
-  a.X = s->dX;
+  a.X = s->xf32();
   a.inv_norm = s->dInv;
   a.adj0 = s->dAdj0;
   a.up_start = s->dUpStart;
@@ -730,6 +734,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     ScanArgs a;
     a.Q = s->dQ.p;
     a.X = s->dX;
+    a.x_half = (uint32_t)s->x_half;
     a.rowp = s->dRowp;
     a.cand = s->dCand.p;
     a.part = s->dPart.p;
@@ -772,6 +777,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   RerankArgs r;
   r.Q = s->dQ.p;
   r.X = s->dX;
+  r.x_half = (uint32_t)s->x_half;
   r.inv_norm = s->dInv;
   r.merged = s->dMerged.p;
   r.out_ids = d_ids;
@@ -792,7 +798,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   s->n_dist += (uint64_t)nq * s->n;
   s->n_rerank += (uint64_t)nq * p.kprime;
   // SURVEY §8d brute force bytes per batch: N*d*s + B*d*4 + B*k*12
-  s->bytes_algo += s->n * s->dims * 4ull + (uint64_t)nq * s->dims * 4ull + (uint64_t)nq * k * 12ull;
+  s->bytes_algo += s->n * s->dims * (uint64_t)s->esz + (uint64_t)nq * s->dims * 4ull + (uint64_t)nq * k * 12ull;
   return EHX_OK;
 }
 
@@ -871,7 +877,9 @@ int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metri
   if (!name || !out) return fail(EHX_EINVAL, "name/out must not be NULL");
   if (dims == 0 || dims > (1u << 16)) return fail(EHX_EINVAL, "dims=%u out of range", dims);
   if (metric < EHX_METRIC_L2SQ || metric > EHX_METRIC_COSINE) return fail(EHX_EINVAL, "unknown metric %d", metric);
-  if (dtype != EHX_DTYPE_F32) return fail(EHX_EUNSUPPORTED, "dtype %d not supported", dtype);
+  if (dtype != EHX_DTYPE_F32 && dtype != EHX_DTYPE_F16) return fail(EHX_EUNSUPPORTED, "dtype %d not supported", dtype);
+  if (dtype == EHX_DTYPE_F16 && params && params->mode == EHX_MODE_GRAPH)
+    return fail(EHX_EUNSUPPORTED, "fp16 row storage is a flat-mode feature (graph mode stores fp32 rows)");
   int rc = ehx_init(nullptr, 0);
   if (rc) return rc;
   Engine& E = engine();
@@ -884,6 +892,8 @@ int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metri
   s->dims = dims;
   s->ld = (uint32_t)round_up(dims, kBK);
   s->metric = metric;
+  s->x_half = dtype == EHX_DTYPE_F16;
+  s->esz = s->x_half ? 2 : sizeof(float);
   if (params) s->params = *params;
   if (s->params.mode != EHX_MODE_FLAT && s->params.mode != EHX_MODE_GRAPH)
     return fail(EHX_EINVAL, "unknown mode %u", s->params.mode);
@@ -1019,23 +1029,31 @@ static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, con
   }
   for (auto& k : new_keys) s->id_to_key.push_back(std::move(k));
   // upload through pinned staging in slabs; rows may be non-contiguous (updates) so copy per row
-  const size_t row_bytes = (size_t)s->dims * sizeof(float);
+  // (fp16 spaces: rows are rounded to binary16, round-to-nearest-even, while they are staged)
+  const size_t row_bytes = (size_t)s->dims * s->esz;
   const size_t slab_rows = std::max<size_t>(1, std::min<size_t>(n, (8u << 20) / row_bytes));
   if ((rc = ensure_stage(s, slab_rows * row_bytes))) return rc;
+  char* stage = (char*)s->hStage;
   uint64_t min_id = ~0ull, max_id = 0;
   for (size_t i0 = 0; i0 < n; i0 += slab_rows) {
     const size_t m = std::min(slab_rows, n - i0);
-    memcpy(s->hStage, vecs + i0 * s->dims, m * row_bytes);
+    if (s->x_half) {
+      _Float16* h = (_Float16*)stage;
+      const float* src = vecs + i0 * s->dims;
+      for (size_t e = 0; e < m * s->dims; ++e) h[e] = (_Float16)src[e];
+    } else {
+      memcpy(stage, vecs + i0 * s->dims, m * row_bytes);
+    }
     // contiguous run of fresh ids -> one 2D copy; otherwise row by row
     bool contiguous = true;
     for (size_t i = 1; i < m; ++i)
       if (ids[i0 + i] != ids[i0] + i) { contiguous = false; break; }
     if (contiguous) {
-      HIP_TRY(hipMemcpy2DAsync(s->dX + ids[i0] * s->ld, (size_t)s->ld * sizeof(float), s->hStage, row_bytes,
+      HIP_TRY(hipMemcpy2DAsync(s->xrow(ids[i0]), (size_t)s->ld * s->esz, stage, row_bytes,
                                row_bytes, m, hipMemcpyHostToDevice, s->stream));
     } else {
       for (size_t i = 0; i < m; ++i)
-        HIP_TRY(hipMemcpyAsync(s->dX + ids[i0 + i] * s->ld, s->hStage + i * s->dims, row_bytes,
+        HIP_TRY(hipMemcpyAsync(s->xrow(ids[i0 + i]), stage + i * row_bytes, row_bytes,
                                hipMemcpyHostToDevice, s->stream));
     }
     HIP_TRY(hipStreamSynchronize(s->stream));  // staging buffer is reused
@@ -1046,8 +1064,8 @@ static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, con
   }
   s->n = next;
   // per-row statistics over the touched id range (idempotent for untouched rows in between)
-  HIP_TRY(launch_row_stats(s->dX, min_id, max_id - min_id + 1, s->dims, s->ld, s->metric, s->dInv, s->dRowp,
-                           s->stream));
+  HIP_TRY(launch_row_stats(s->dX, s->x_half, min_id, max_id - min_id + 1, s->dims, s->ld, s->metric, s->dInv,
+                           s->dRowp, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (s->params.mode == EHX_MODE_GRAPH) {
     // new rows join the graph one at a time, in id order (ANNIndex::set -> addPoint, index.cc:36);
@@ -1081,7 +1099,13 @@ int ehx_get_by_id(ehx_space* s, uint64_t id, float* out_vec) {
   std::shared_lock<std::shared_mutex> rl(s->mu);
   if (id >= s->n) return fail(EHX_ENOTFOUND, "Not found");
   HIP_TRY(hipSetDevice(engine().device));
-  HIP_TRY(hipMemcpy(out_vec, s->dX + id * s->ld, (size_t)s->dims * sizeof(float), hipMemcpyDeviceToHost));
+  if (s->x_half) {
+    std::vector<_Float16> h(s->dims);
+    HIP_TRY(hipMemcpy(h.data(), s->xrow(id), (size_t)s->dims * 2, hipMemcpyDeviceToHost));
+    for (uint32_t c = 0; c < s->dims; ++c) out_vec[c] = (float)h[c];
+    return EHX_OK;
+  }
+  HIP_TRY(hipMemcpy(out_vec, s->xrow(id), (size_t)s->dims * sizeof(float), hipMemcpyDeviceToHost));
   return EHX_OK;
 }
 
@@ -1327,8 +1351,22 @@ int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_ro
   int rc = grow(s, s->n + n_rows);
   if (rc) return rc;
   s->implicit_keys = true;
-  HIP_TRY(launch_gen_rows(seed, row0, n_rows, s->dims, s->ld, normalize, s->dX + s->n * s->ld, s->stream));
-  HIP_TRY(launch_row_stats(s->dX, s->n, n_rows, s->dims, s->ld, s->metric, s->dInv, s->dRowp, s->stream));
+  if (s->x_half) {
+    // generate fp32 slabs, round them into the fp16 rows
+    const uint64_t slab = 1u << 16;
+    DevBuf<float> tmp;
+    if ((rc = tmp.ensure(std::min<uint64_t>(slab, n_rows) * s->ld))) return rc;
+    for (uint64_t r0 = 0; r0 < n_rows; r0 += slab) {
+      const uint64_t m = std::min<uint64_t>(slab, n_rows - r0);
+      HIP_TRY(launch_gen_rows(seed, row0 + r0, m, s->dims, s->ld, normalize, tmp.p, s->stream));
+      HIP_TRY(launch_store_rows_f16(tmp.p, s->ld, nullptr, s->n + r0, m, s->dims, s->ld, (__half*)s->dX, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    tmp.release();
+  } else {
+    HIP_TRY(launch_gen_rows(seed, row0, n_rows, s->dims, s->ld, normalize, (float*)s->xrow(s->n), s->stream));
+  }
+  HIP_TRY(launch_row_stats(s->dX, s->x_half, s->n, n_rows, s->dims, s->ld, s->metric, s->dInv, s->dRowp, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   const uint64_t old_n = s->n;
   s->n += n_rows;

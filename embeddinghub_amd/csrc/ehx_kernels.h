@@ -2,6 +2,7 @@
 // Not part of the public boundary (include/ehx.h is).
 #pragma once
 
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -51,8 +52,13 @@ __device__ __forceinline__ float ex_sqrt(float a) { return __builtin_sqrtf(a); }
 // all 4 lanes of the group must be active.  metric01: 0 = L2^2, 1 = 1 - inner product.  For cosine
 // the stored row is normalised on the fly (x * inv_norm, one rounding — hnswlib-python's
 // normalize_vector) and the query arrives normalised.  Result valid in sub-lane 0.
+// row element load: fp32 rows as stored, fp16 rows widened exactly (every half is a float)
+__device__ __forceinline__ float ld_row(const float* x, uint32_t m) { return x[m]; }
+__device__ __forceinline__ float ld_row(const __half* x, uint32_t m) { return __half2float(x[m]); }
+
+template <typename XT>
 __device__ __forceinline__ float canon_dist(int metric, const float* __restrict__ q,
-                                            const float* __restrict__ x, float xscale, bool scale_x,
+                                            const XT* __restrict__ x, float xscale, bool scale_x,
                                             uint32_t dims, int sub) {
   uint32_t body;
   if ((dims & 15u) == 0 || (dims & 3u) == 0) body = dims;
@@ -62,13 +68,13 @@ __device__ __forceinline__ float canon_dist(int metric, const float* __restrict_
   float part = 0.0f;
   if (metric == 0) {
     for (uint32_t m = sub; m < body; m += 4) {
-      const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
+      const float xv = scale_x ? ex_mul(ld_row(x, m), xscale) : ld_row(x, m);
       const float diff = ex_sub(q[m], xv);
       part = ex_add(part, ex_mul(diff, diff));
     }
   } else {
     for (uint32_t m = sub; m < body; m += 4) {
-      const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
+      const float xv = scale_x ? ex_mul(ld_row(x, m), xscale) : ld_row(x, m);
       part = ex_add(part, ex_mul(q[m], xv));
     }
   }
@@ -79,13 +85,13 @@ __device__ __forceinline__ float canon_dist(int metric, const float* __restrict_
     float tail = 0.0f;
     if (metric == 0) {
       for (uint32_t m = body; m < dims; ++m) {
-        const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
+        const float xv = scale_x ? ex_mul(ld_row(x, m), xscale) : ld_row(x, m);
         const float diff = ex_sub(q[m], xv);
         tail = ex_add(tail, ex_mul(diff, diff));
       }
     } else {
       for (uint32_t m = body; m < dims; ++m) {
-        const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
+        const float xv = scale_x ? ex_mul(ld_row(x, m), xscale) : ld_row(x, m);
         tail = ex_add(tail, ex_mul(q[m], xv));
       }
     }
@@ -159,7 +165,8 @@ __device__ __forceinline__ float canon_dist_lane(int metric, const float* __rest
 
 struct ScanArgs {
   const float* Q;        // [q_tiles*256][ld] prepared queries (zero padded)
-  const float* X;        // [cap][ld] stored rows, cap % 256 == 0 (>= n_tiles*128), pad columns zero
+  const void* X;         // [cap][ld] stored rows (fp32, or fp16 when x_half), cap % 256 == 0, pad columns zero
+  uint32_t x_half;       // 1: rows are IEEE fp16
   const float2* rowp;    // [cap] epilogue (a, b): approx distance = dot*a + b
   uint64_t* cand;        // [grid][256][64] per-block candidate slots (scratch)
   uint64_t* part;        // [q_tiles*256][n_chunks][lists_per_chunk][kprime] sorted partial top-k' keys
@@ -194,7 +201,8 @@ hipError_t launch_flat_merge(const uint64_t* part, uint32_t nq, uint32_t n_chunk
 // canonical (oracle-order) distances of the merged candidates, sort by (dist, id), emit top-k.
 struct RerankArgs {
   const float* Q;          // prepared queries [*][ld]
-  const float* X;
+  const void* X;           // fp32 or fp16 rows
+  uint32_t x_half;
   const float* inv_norm;   // [cap] (cosine) or nullptr
   const uint64_t* merged;  // [nq][64] keys (approx score, id)
   uint64_t* out_ids;       // [nq][k]
@@ -211,10 +219,16 @@ hipError_t launch_prep_queries(const float* q_in, uint32_t nq, uint32_t dims, ui
                                uint32_t q_rows, int metric, float* q_out, hipStream_t st);
 
 // per-row statistics for rows [row0, row0+n): inv_norm (cosine), rowp (a,b) for the scan epilogue
-hipError_t launch_row_stats(const float* X, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
+hipError_t launch_row_stats(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
                             int metric, float* inv_norm, float2* rowp, hipStream_t st);
 // rowp for padding rows [row0, row0+n): (0, +inf)
 hipError_t launch_rowp_pad(float2* rowp, uint64_t row0, uint64_t n, hipStream_t st);
+
+// fp16 storage: rows of an fp32 matrix (stride src_ld) rounded to nearest-even into rows ids[i] (or
+// row0+i when ids == nullptr) of the fp16 matrix, and one fp16 row widened back for Get
+hipError_t launch_store_rows_f16(const float* src, uint32_t src_ld, const uint64_t* ids, uint64_t row0, uint64_t n,
+                                 uint32_t dims, uint32_t ld, __half* X, hipStream_t st);
+hipError_t launch_load_row_f16(const __half* X, uint64_t row, uint32_t dims, uint32_t ld, float* out, hipStream_t st);
 
 // EHX-GAUSS-1 rows generated straight into a [*, ld] matrix (optionally L2-normalised)
 hipError_t launch_gen_rows(uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims, uint32_t ld,

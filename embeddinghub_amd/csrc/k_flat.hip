@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a
 
   if (total_steps > 0) {
     {  // stage 0 -> buffer 0
-      const float* Xt = a.X + (size_t)tile_begin * kTileRows * a.ld;
+      const float* Xt = (const float*)a.X + (size_t)tile_begin * kTileRows * a.ld;
       char* gxs = smem + kXOff + (uint32_t)w * 4096;
       char* gqs = smem + kQOff + (uint32_t)w * 8192;
 #pragma unroll
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a
     for (int c = 0; c < 4; ++c) fb0[c] = *(const f32x4*)(smem + kQOff + b_row_off + c * 4096 + joff[0]);
     if (total_steps > 1) {  // stage 1 -> buffer 1
       const uint32_t nt = 1u / ktiles, nkt = 1u - nt * ktiles;
-      const float* Xt = a.X + (size_t)(tile_begin + nt) * kTileRows * a.ld + nkt * kBK;
+      const float* Xt = (const float*)a.X + (size_t)(tile_begin + nt) * kTileRows * a.ld + nkt * kBK;
       const float* Qt = Qtile + nkt * kBK;
       char* gxs = smem + kXOff + kXStage + (uint32_t)w * 4096;
       char* gqs = smem + kQOff + kQStage + (uint32_t)w * 8192;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a
     const uint32_t nstep = step + 2;
     const uint32_t nt = has_next2 ? nstep / ktiles : 0u;
     const uint32_t nkt = has_next2 ? nstep - nt * ktiles : 0u;
-    const float* Xt = a.X + (size_t)(tile_begin + nt) * kTileRows * a.ld + nkt * kBK;
+    const float* Xt = (const float*)a.X + (size_t)(tile_begin + nt) * kTileRows * a.ld + nkt * kBK;
     const float* Qt = Qtile + nkt * kBK;
     char* gxs = smem + kXOff + buf * kXStage + (uint32_t)w * 4096;
     char* gqs = smem + kQOff + buf * kQStage + (uint32_t)w * 8192;
@@ -443,6 +443,7 @@ uint32_t scan_lists_per_chunk() { return scan_variant() == 4 ? 1u : 2u; }
 
 hipError_t launch_flat_scan(const ScanArgs& a, hipStream_t st) {
   const int variant = scan_variant();
+  if (variant == 4 && a.x_half) return hipErrorInvalidValue;  // the 4-wave A/B variant scans fp32 rows only
   return variant == 4 ? launch_flat_scan4(a, st) : launch_flat_scan8(a, st);
 }
 
@@ -504,6 +505,7 @@ hipError_t launch_flat_merge(const uint64_t* part, uint32_t nq, uint32_t n_chunk
 // and add NOT fused), horizontal sum t0+t1+t2+t3 left to right, scalar tail added afterwards.
 // One 4-lane group per candidate; lane j of the group plays SSE lane j.
 // ---------------------------------------------------------------------------------------------
+template <typename XT>
 __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
   __shared__ uint64_t keys[64];
   __shared__ float approx[64];
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
   float d = __builtin_inff();
   if (valid) {
     const float* qv = a.Q + (size_t)q * a.ld;
-    const float* xv = a.X + (size_t)id * a.ld;
+    const XT* xv = (const XT*)a.X + (size_t)id * a.ld;
     const bool scale_x = a.metric == 2;
     const float xs = scale_x ? a.inv_norm[id] : 1.0f;
     d = canon_dist(a.metric == 0 ? 0 : 1, qv, xv, xs, scale_x, a.dims, sub);
@@ -562,7 +564,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
 }
 
 hipError_t launch_rerank(const RerankArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(rerank_kernel, dim3(a.nq), dim3(256), 0, st, a);
+  if (a.x_half) hipLaunchKernelGGL(rerank_kernel<__half>, dim3(a.nq), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(rerank_kernel<float>, dim3(a.nq), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -51,6 +51,23 @@ __device__ __forceinline__ f32x4 frag_read(const char* p) {
 #endif
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// fp16 rows: 4 consecutive halves (8 bytes) widened exactly to fp32
+__device__ __forceinline__ f32x4 frag_read_h(const char* p) {
+#if (EHX_ABL & 4)
+  return frag_read(p);
+#else
+  const uint2 u = *(const uint2*)p;
+  const __half2 lo = *(const __half2*)&u.x, hi = *(const __half2*)&u.y;
+  const float2 a = __half22float2(lo), b = __half22float2(hi);
+  return (f32x4){a.x, a.y, b.x, b.y};
+#endif
+}
+
 __device__ __forceinline__ void glds16_8(const void* gsrc, void* lds_dst_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
@@ -154,6 +171,7 @@ __device__ __attribute__((noinline)) void scan8_compact(int w, int wc, int lane,
 
 size_t scan8_lds_bytes() { return kLdsBytes8; }
 
+template <bool HALF>
 __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -211,9 +229,15 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
   // piece `ins` = 8 tile rows x 128 B; lane L -> row 8*ins + (L>>3), physical chunk p = L&7, logical
   // chunk c = p ^ ((4*ins + (L>>4)) & 7): only the parity of ins matters -> two lane offsets.
   const float* Qtile = a.Q + (size_t)qt * kTileQ * a.ld;
-  const float* Xbase = a.X + (size_t)tile_begin * kTileRows * a.ld;
+  // X rows: fp32 (128-B stage rows, 8 rows per DMA piece, 16 pieces per stage, 2 per wave) or fp16 (64-B
+  // stage rows, 16 rows per piece, 8 pieces per stage, 1 per wave; 16-B chunk p of a row holds logical
+  // chunk p ^ ((row>>2)&3))
+  constexpr uint32_t kXElem = HALF ? 2u : 4u;
+  const char* Xbase = (const char*)a.X + (size_t)tile_begin * kTileRows * a.ld * kXElem;
   const float2* Rbase = a.rowp + (size_t)tile_begin * kTileRows;
-  const size_t tile_stride = (size_t)kTileRows * a.ld;
+  const size_t tile_stride = (size_t)kTileRows * a.ld * kXElem;  // bytes
+  const uint32_t lh = ((uint32_t)(lane >> 2) * a.ld * 2u) + (((uint32_t)(lane & 3) ^ ((uint32_t)(lane >> 4) & 3u)) * 16u);  // fp16 piece: lane byte offset
+  const uint32_t piece_stride_h = 16u * a.ld * 2u;
   const uint32_t c0 = (uint32_t)(lane & 7) ^ (uint32_t)(lane >> 4);
   const uint32_t lane_row = (uint32_t)(lane >> 3) * a.ld;
   const uint32_t l_even = (lane_row + c0 * 4u) * 4u;  // bytes
@@ -226,9 +250,13 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
   do {                                                                                                  \
     if (ABL_NO_DMA) break;                                                                              \
     if ((U) < 2) {                                                                                      \
-      const char* Xt = (const char*)(Xbase + pre_t * tile_stride + pre_kt * kBK);                       \
-      glds16_8(Xt + (size_t)((2 * w + (U)) * piece_stride) + (((U) & 1) ? l_odd : l_even),              \
-               smem + kXOff8 + pre_buf * kXStage8 + (2 * w + (U)) * 1024);                              \
+      const char* Xt = Xbase + pre_t * tile_stride + (size_t)pre_kt * kBK * kXElem;                     \
+      if (!HALF) {                                                                                      \
+        glds16_8(Xt + (size_t)((2 * w + (U)) * piece_stride) + (((U) & 1) ? l_odd : l_even),            \
+                 smem + kXOff8 + pre_buf * kXStage8 + (2 * w + (U)) * 1024);                            \
+      } else if ((U) == 0) {                                                                            \
+        glds16_8(Xt + (size_t)(w * piece_stride_h) + lh, smem + kXOff8 + pre_buf * kXStage8 + w * 1024); \
+      }                                                                                                 \
     } else if ((U) < 6) {                                                                               \
       const char* Qt = (const char*)(Qtile + pre_kt * kBK);                                             \
       glds16_8(Qt + (size_t)((4 * w + (U) - 2) * piece_stride) + ((((U) - 2) & 1) ? l_odd : l_even),    \
@@ -248,12 +276,23 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
     ++issued;                                       \
   } while (0)
 
+  // pieces this wave has in flight per stage (for the counted vmcnt waits)
+  constexpr int kP = HALF ? 5 : 6;  // X + Q pieces of a wave; wave 0 adds the row-parameter piece
+
   // ---- fragment read constants ----
   const uint32_t hs = (uint32_t)h ^ ((uint32_t)(i31 >> 1) & 7u);
   uint32_t joff[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) joff[j] = (((uint32_t)(2 * j)) ^ hs) * 16;
-  const uint32_t a_row_off = (uint32_t)(wr * 64 + i31) * 128;  // + rb*4096
+  // A (row) fragments: fp32 stage rows are 128 B (b128 read at the swizzled 16-B chunk), fp16 stage rows
+  // are 64 B (b64 read: chunk j ^ ((row>>2)&3), 8-byte half h)
+  const uint32_t a_row_off = (uint32_t)(wr * 64 + i31) * (HALF ? 64u : 128u);  // + rb*kXrb
+  constexpr uint32_t kXrb = HALF ? 2048u : 4096u;
+  uint32_t joffa[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    joffa[j] = HALF ? ((((uint32_t)j) ^ ((uint32_t)(i31 >> 2) & 3u)) * 16u + (uint32_t)h * 8u) : joff[j];
+#define EHX_XREAD(P) (HALF ? frag_read_h((const char*)(P)) : frag_read((const char*)(P)))
   const uint32_t b_row_off = (uint32_t)(wc * 64 + i31) * 128;  // + cb*4096
 
   f32x16 acc[2][2];
@@ -343,20 +382,20 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
   }
   // stage 0 landed <=> at most the pieces of the younger stages are still in flight
   if (w == 0) {
-    if (issued >= 3) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    else if (issued == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (issued >= 3) wait_vmcnt<2 * (kP + 1)>();
+    else if (issued == 2) wait_vmcnt<kP + 1>();
+    else wait_vmcnt<0>();
   } else {
-    if (issued >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (issued == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (issued >= 3) wait_vmcnt<2 * kP>();
+    else if (issued == 2) wait_vmcnt<kP>();
+    else wait_vmcnt<0>();
   }
   hot_barrier();  // B_0 (also publishes the state init)
 
   f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
   if (total_steps > 0) {
-    fa0[0] = frag_read((const char*)(smem + kXOff8 + a_row_off + joff[0]));
-    fa0[1] = frag_read((const char*)(smem + kXOff8 + a_row_off + 4096 + joff[0]));
+    fa0[0] = EHX_XREAD(smem + kXOff8 + a_row_off + joffa[0]);
+    fa0[1] = EHX_XREAD(smem + kXOff8 + a_row_off + kXrb + joffa[0]);
     fb0[0] = frag_read((const char*)(smem + kQOff8 + b_row_off + joff[0]));
     fb0[1] = frag_read((const char*)(smem + kQOff8 + b_row_off + 4096 + joff[0]));
   }
@@ -364,8 +403,8 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
   // one group: 16 MFMAs on (A,B); the 4 fragment reads of the next group in their shadow
 #define EHX_GROUP8(A, B, An, Bn, XS, QS)                                  \
   do {                                                                    \
-    An[0] = frag_read((const char*)((XS)));                                        \
-    An[1] = frag_read((const char*)((XS) + 4096));                                 \
+    An[0] = EHX_XREAD((XS));                                                       \
+    An[1] = EHX_XREAD((XS) + kXrb);                                                \
     _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                   \
       acc[0][0] = EHX_MFMA8(A[0][tt], B[0][tt], acc[0][0]);               \
       acc[1][0] = EHX_MFMA8(A[1][tt], B[0][tt], acc[1][0]);               \
@@ -406,21 +445,21 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
     const bool early_dma = !late && has_next && issued < total_steps;
 
     // ---- group 0 (set 0): the late waves do their DMA duty here, one piece per MFMA ----
-    fa1[0] = frag_read((const char*)(xs + joff[1]));
-    fa1[1] = frag_read((const char*)(xs + 4096 + joff[1]));
+    fa1[0] = EHX_XREAD(xs + joffa[1]);
+    fa1[1] = EHX_XREAD(xs + kXrb + joffa[1]);
     fb1[0] = frag_read((const char*)(qs + joff[1]));
     fb1[1] = frag_read((const char*)(qs + 4096 + joff[1]));
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       EHX_ONE8(fa0, fb0, m);
-      if (m < 6) {
+      if (m < 7) {  // 7 pieces: wave 0 may be a late wave and owns the row-parameter piece
         if (late_dma) EHX_PIECE(m);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (late_dma) EHX_STAGE_ADVANCE();
-    EHX_GROUP8(fa1, fb1, fa0, fb0, xs + joff[2], qs + joff[2]);
-    EHX_GROUP8(fa0, fb0, fa1, fb1, xs + joff[3], qs + joff[3]);
+    EHX_GROUP8(fa1, fb1, fa0, fb0, xs + joffa[2], qs + joff[2]);
+    EHX_GROUP8(fa0, fb0, fa1, fb1, xs + joffa[3], qs + joff[3]);
 
     // ---- group 3 (set 1): 4 MFMAs, the stage barrier, then 12 MFMAs with the next stage's first
     // fragment reads and (early waves) the DMA pieces of stage step+3 in their shadow ----
@@ -430,10 +469,10 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
     if (has_next) {
       // own pieces of stage step+1 landed?  Only stage step+2's may still be in flight.
       if (step + 2 < total_steps) {
-        if (w == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (w == 0) wait_vmcnt<kP + 1>();
+        else wait_vmcnt<kP>();
       } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_vmcnt<0>();
       }
       if (!ABL_NO_BARRIER) hot_barrier();  // B_{step+1}: stage step+1 visible; ring slot `buf` is free again
     }
@@ -441,8 +480,8 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
     for (int m = 4; m < 16; ++m) {
       EHX_ONE8(fa1, fb1, m);
       if (has_next) {
-        if (m == 4) fa0[0] = frag_read((const char*)(xn + joff[0]));
-        if (m == 5) fa0[1] = frag_read((const char*)(xn + 4096 + joff[0]));
+        if (m == 4) fa0[0] = EHX_XREAD(xn + joffa[0]);
+        if (m == 5) fa0[1] = EHX_XREAD(xn + kXrb + joffa[0]);
         if (m == 6) fb0[0] = frag_read((const char*)(qn + joff[0]));
         if (m == 7) fb0[1] = frag_read((const char*)(qn + 4096 + joff[0]));
       }
@@ -470,6 +509,7 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
     }
   }
 #undef EHX_GROUP8
+#undef EHX_XREAD
 #undef EHX_ONE8
 #undef EHX_PIECE
 #undef EHX_STAGE_ADVANCE
@@ -490,13 +530,17 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
 hipError_t launch_flat_scan8(const ScanArgs& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)flat_scan8_kernel,
+    hipError_t e = hipFuncSetAttribute((const void*)flat_scan8_kernel<false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes8);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)flat_scan8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kLdsBytes8);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const uint32_t grid = a.q_tiles * a.n_chunks;
-  hipLaunchKernelGGL(flat_scan8_kernel, dim3(grid), dim3(kThreads8), kLdsBytes8, st, a);
+  if (a.x_half) hipLaunchKernelGGL(flat_scan8_kernel<true>, dim3(grid), dim3(kThreads8), kLdsBytes8, st, a);
+  else hipLaunchKernelGGL(flat_scan8_kernel<false>, dim3(grid), dim3(kThreads8), kLdsBytes8, st, a);
   return hipGetLastError();
 }
 

@@ -11,9 +11,13 @@ namespace ehx {
 
 namespace {
 // one thread walks one row sequentially: the summation ORDER is the contract here
-__device__ __forceinline__ float seq_sumsq(const float* __restrict__ x, uint32_t dims) {
+template <typename XT>
+__device__ __forceinline__ float seq_sumsq(const XT* __restrict__ x, uint32_t dims) {
   float s = 0.0f;
-  for (uint32_t i = 0; i < dims; ++i) s = ex_add(s, ex_mul(x[i], x[i]));
+  for (uint32_t i = 0; i < dims; ++i) {
+    const float v = ld_row(x, i);
+    s = ex_add(s, ex_mul(v, v));
+  }
   return s;
 }
 __device__ __forceinline__ float inv_norm_of(float sumsq) {
@@ -53,7 +57,8 @@ hipError_t launch_prep_queries(const float* q_in, uint32_t nq, uint32_t dims, ui
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ X, uint64_t row0,
+template <typename XT>
+__global__ __launch_bounds__(256) void row_stats_kernel(const XT* __restrict__ X, uint64_t row0,
                                                         uint64_t n, uint32_t dims, uint32_t ld, int metric,
                                                         float* __restrict__ inv_norm,
                                                         float2* __restrict__ rowp) {
@@ -72,12 +77,49 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
   }
 }
 
-hipError_t launch_row_stats(const float* X, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
+hipError_t launch_row_stats(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
                             int metric, float* inv_norm, float2* rowp, hipStream_t st) {
   if (n == 0) return hipSuccess;
   const uint32_t grid = (uint32_t)((n + 255) / 256);
-  hipLaunchKernelGGL(row_stats_kernel, dim3(grid), dim3(256), 0, st, X, row0, n, dims, ld, metric,
-                     inv_norm, rowp);
+  if (x_half)
+    hipLaunchKernelGGL(row_stats_kernel<__half>, dim3(grid), dim3(256), 0, st, (const __half*)X, row0, n, dims, ld,
+                       metric, inv_norm, rowp);
+  else
+    hipLaunchKernelGGL(row_stats_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)X, row0, n, dims, ld,
+                       metric, inv_norm, rowp);
+  return hipGetLastError();
+}
+
+// ---- fp16 storage ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void store_rows_f16_kernel(const float* __restrict__ src, uint32_t src_ld,
+                                                             const uint64_t* __restrict__ ids, uint64_t row0,
+                                                             uint64_t n, uint32_t dims, uint32_t ld,
+                                                             __half* __restrict__ X) {
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * ld) return;
+  const uint64_t i = gid / ld;
+  const uint32_t c = (uint32_t)(gid - i * ld);
+  const uint64_t r = ids ? ids[i] : row0 + i;
+  X[r * ld + c] = c < dims ? __float2half_rn(src[i * src_ld + c]) : __float2half_rn(0.0f);
+}
+
+hipError_t launch_store_rows_f16(const float* src, uint32_t src_ld, const uint64_t* ids, uint64_t row0, uint64_t n,
+                                 uint32_t dims, uint32_t ld, __half* X, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const uint64_t work = n * ld;
+  hipLaunchKernelGGL(store_rows_f16_kernel, dim3((uint32_t)((work + 255) / 256)), dim3(256), 0, st, src, src_ld, ids,
+                     row0, n, dims, ld, X);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void load_row_f16_kernel(const __half* __restrict__ X, uint64_t row, uint32_t dims,
+                                                           uint32_t ld, float* __restrict__ out) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < dims) out[c] = __half2float(X[row * ld + c]);
+}
+
+hipError_t launch_load_row_f16(const __half* X, uint64_t row, uint32_t dims, uint32_t ld, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(load_row_f16_kernel, dim3((dims + 255) / 256), dim3(256), 0, st, X, row, dims, ld, out);
   return hipGetLastError();
 }
 

@@ -59,7 +59,13 @@ enum {
   EHX_METRIC_IP = 1,     /* 1 - sum a*b   — hnswlib::InnerProductSpace                                     */
   EHX_METRIC_COSINE = 2  /* normalise on Set and on query, then IP — Go providers (redis.go:253)           */
 };
-enum { EHX_DTYPE_F32 = 0 };
+enum {
+  EHX_DTYPE_F32 = 0, /* rows stored as given (the reference's std::vector<float>, index.h:14)                     */
+  EHX_DTYPE_F16 = 1  /* flat mode only: rows rounded to IEEE binary16 (nearest-even) when written and widened
+                        exactly to fp32 wherever they are read — results are those of an F32 space fed the
+                        rounded rows; halves the HBM footprint and the scan's bytes (BASELINE.json configs[5]);
+                        the API still speaks fp32 (Get returns the widened stored values)                         */
+};
 enum {
   EHX_MODE_FLAT = 0,  /* exhaustive scan on the matrix cores + canonical re-rank: exact kNN */
   EHX_MODE_GRAPH = 1  /* HNSW-style level-0 best-first search over an HBM-resident graph      */

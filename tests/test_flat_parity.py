@@ -218,6 +218,48 @@ def test_nan_and_inf_rows_do_not_poison_results():
     assert 5 not in ids and 9 not in ids
 
 
+# ---- fp16 row storage (BASELINE.json configs[5]) -------------------------------------------------
+# An F16 space must behave exactly like an F32 space that was fed the rows rounded to binary16
+# (round-to-nearest-even), so the oracle is run on the rounded rows and everything stays bit-exact.
+@pytest.mark.parametrize("n,d,nq,k", [
+    (1000, 32, 8, 10),
+    (5000, 100, 33, 10),     # dims not a multiple of the 32-element stage
+    (3000, 1536, 16, 10),    # config-5 dims
+    (70000, 64, 64, 10),     # many tiles per chunk
+])
+@pytest.mark.parametrize("em,om", METRICS)
+def test_fp16_rows_parity(n, d, nq, k, em, om):
+    rng = np.random.default_rng(n * 17 + d)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    Xh = X.astype(np.float16).astype(np.float32)
+    s = ehx.Space.unique("h16", d, metric=em, dtype=ehx.DTYPE_F16)
+    s.set_batch(_keys(n), X)
+    _check(s, Xh, Q, k, om)
+    assert s.get("k7").tobytes() == Xh[7].tobytes()  # Get returns the stored (rounded) row
+    # update in place + growth
+    X2 = rng.standard_normal((300, d)).astype(np.float32)
+    s.set_batch(_keys(n + 200)[n - 100:], X2)
+    Xh = np.concatenate([Xh[:n - 100], X2.astype(np.float16).astype(np.float32)])
+    _check(s, Xh, Q, k, om)
+    st = s.stats()
+    assert st["n_uncertified"] == 0 and st["n_rows"] == n + 200
+    s.drop()
+
+
+def test_fp16_synthetic_fill_and_mode_restrictions():
+    n, d = 20000, 768
+    s = ehx.Space.unique("h16s", d, metric=ehx.METRIC_COSINE, dtype=ehx.DTYPE_F16, initial_capacity=n)
+    s.fill_synthetic(ehx.SEED_CORPUS, 0, n, True)
+    Xh = pyoracle.gen_rows(ehx.SEED_CORPUS, 0, n, d, normalize=True).astype(np.float16).astype(np.float32)
+    Q = pyoracle.gen_rows(ehx.SEED_QUERY, 0, 32, d, normalize=True)
+    _check(s, Xh, Q, 10, pyoracle.METRIC_COSINE)
+    s.drop()
+    with pytest.raises(ehx.EhxError) as e:
+        ehx.Space.unique("h16g", d, mode=ehx.MODE_GRAPH, dtype=ehx.DTYPE_F16)
+    assert e.value.code == ehx._lib.EUNSUPPORTED
+
+
 # ---- BASELINE-size properties (size-independent checks at the bench workload's shape) -------------
 def test_full_size_split_invariance_and_sample_vs_oracle():
     """1M x 768 cosine, batch 1024 (BASELINE config 2): (a) kNN over the whole index == merge of the
