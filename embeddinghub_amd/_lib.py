@@ -14,6 +14,7 @@ OK, EINVAL, ENOTFOUND, EEXISTS, EIMMUTABLE, ENODEVICE, ENOMEM, ERANGE, EUNSUPPOR
 METRIC_L2SQ, METRIC_IP, METRIC_COSINE = 0, 1, 2
 MODE_FLAT, MODE_GRAPH = 0, 1
 DTYPE_F32, DTYPE_F16 = 0, 1
+SCAN_AUTO, SCAN_F32 = 0, 1
 MAX_K = 48
 SEED_CORPUS, SEED_QUERY = 20250211, 20250212
 
@@ -27,7 +28,7 @@ class EhxError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("M", C.c_uint32), ("ef_construction", C.c_uint32),
                 ("ef", C.c_uint32), ("seed", C.c_uint64), ("initial_capacity", C.c_uint64),
-                ("build_batch", C.c_uint32), ("reserved", C.c_uint32 * 7)]
+                ("build_batch", C.c_uint32), ("scan", C.c_uint32), ("reserved", C.c_uint32 * 6)]
 
 
 class Stats(C.Structure):
@@ -35,7 +36,8 @@ class Stats(C.Structure):
                 ("n_dist", C.c_uint64), ("n_hops", C.c_uint64), ("n_rerank", C.c_uint64),
                 ("n_uncertified", C.c_uint64), ("bytes_algorithmic", C.c_uint64),
                 ("last_scan_ms", C.c_double), ("last_total_ms", C.c_double),
-                ("scan_ms_mean", C.c_double), ("scan_launches", C.c_uint64)]
+                ("scan_ms_mean", C.c_double), ("scan_launches", C.c_uint64),
+                ("n_filter_queries", C.c_uint64), ("n_filter_fallback", C.c_uint64)]
 
 
 # every symbol include/ehx.h declares: name -> (restype, argtypes)

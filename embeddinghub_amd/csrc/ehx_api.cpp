@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -104,6 +105,13 @@ struct ehx_space {
   float2* dRowp = nullptr;   // [cap]
   float* dInv = nullptr;     // [cap] (cosine)
   uint64_t cap = 0, n = 0;
+  // fp16-MFMA filter scan (k_flat16.hip): unit-normalised binary16 scan copy of the rows
+  bool use16 = false;          // this space scans with the fp16 filter (fp32 flat spaces, unless disabled)
+  __half* dX16 = nullptr;      // [cap][ld16]
+  float2* dRowp16 = nullptr;   // [cap]
+  uint32_t ld16 = 0;
+  unsigned long long* dUnsafe = nullptr;  // rows the filter cannot bound (then every scan is the fp32 scan)
+  uint64_t h_unsafe = 0;
 
   // graph (graph mode): imported adjacency, re-laid-out for the GPU (k_graph.hip)
   uint32_t* dAdj0 = nullptr;     // [g_n][2M]
@@ -136,6 +144,14 @@ struct ehx_space {
   DevBuf<float> dOutDist;
   DevBuf<uint32_t> dOutCount;
   unsigned long long* dUncert = nullptr;
+  // filter scratch: fp16 queries, per-query (gamma, u, v), per-query certification flags, re-run buffers
+  DevBuf<__half> dQ16;
+  DevBuf<float> dQgamma, dFbQ, dFbDist;
+  DevBuf<float2> dQuv;
+  DevBuf<uint32_t> dUflags, dFbCnt;
+  DevBuf<uint64_t> dFbIds;
+  unsigned long long* dUncert16 = nullptr;  // queries the filter pass could not certify
+  std::atomic<uint64_t> n_filter_queries{0}, n_filter_fallback{0};
   float* hStage = nullptr;  // pinned staging (Set / Get / query upload)
   size_t hStageBytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -170,6 +186,18 @@ struct ehx_space {
     if (dX) (void)hipFree(dX);
     if (dRowp) (void)hipFree(dRowp);
     if (dInv) (void)hipFree(dInv);
+    if (dX16) (void)hipFree(dX16);
+    if (dRowp16) (void)hipFree(dRowp16);
+    if (dUnsafe) (void)hipFree(dUnsafe);
+    if (dUncert16) (void)hipFree(dUncert16);
+    dQ16.release();
+    dQgamma.release();
+    dFbQ.release();
+    dFbDist.release();
+    dQuv.release();
+    dUflags.release();
+    dFbCnt.release();
+    dFbIds.release();
     if (dAdj0) (void)hipFree(dAdj0);
     if (dUpStart) (void)hipFree(dUpStart);
     if (dUpLists) (void)hipFree(dUpLists);
@@ -244,6 +272,32 @@ int grow(ehx_space* s, uint64_t rows) {
   HIP_TRY(hipMemsetAsync(ni + keep, 0, (want - keep) * sizeof(float), s->stream));
   HIP_TRY(launch_rowp_pad(nr, keep, want - keep, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->use16) {
+    __half* nx16 = nullptr;
+    float2* nr16 = nullptr;
+    hipError_t e3 = hipMalloc((void**)&nx16, want * s->ld16 * sizeof(__half));
+    hipError_t e4 = hipMalloc((void**)&nr16, want * sizeof(float2));
+    if (e3 != hipSuccess || e4 != hipSuccess) {
+      if (nx16) (void)hipFree(nx16);
+      if (nr16) (void)hipFree(nr16);
+      (void)hipFree(nx);
+      (void)hipFree(nr);
+      (void)hipFree(ni);
+      return fail(EHX_ENOMEM, "hipMalloc failed growing the scan copy of space '%s' to %llu rows", s->name.c_str(),
+                  (unsigned long long)want);
+    }
+    if (keep) {
+      HIP_TRY(hipMemcpyAsync(nx16, s->dX16, keep * s->ld16 * sizeof(__half), hipMemcpyDeviceToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(nr16, s->dRowp16, keep * sizeof(float2), hipMemcpyDeviceToDevice, s->stream));
+    }
+    HIP_TRY(hipMemsetAsync(nx16 + keep * s->ld16, 0, (want - keep) * s->ld16 * sizeof(__half), s->stream));
+    HIP_TRY(launch_rowp_pad(nr16, keep, want - keep, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->dX16) (void)hipFree(s->dX16);
+    if (s->dRowp16) (void)hipFree(s->dRowp16);
+    s->dX16 = nx16;
+    s->dRowp16 = nr16;
+  }
   if (s->dX) (void)hipFree(s->dX);
   if (s->dRowp) (void)hipFree(s->dRowp);
   if (s->dInv) (void)hipFree(s->dInv);
@@ -689,24 +743,29 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   return EHX_OK;
 }
 
-// device pipeline: prepared queries -> scan -> merge -> canonical re-rank
-int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k,
-                      uint64_t* d_ids, float* d_dist, uint32_t* d_count) {
-  if (k == 0 || nq == 0) return EHX_OK;
-  if (k > EHX_MAX_K) return fail(EHX_EUNSUPPORTED, "k=%u exceeds EHX_MAX_K=%u", k, EHX_MAX_K);
-  if (nq > (1u << 24)) return fail(EHX_EINVAL, "too many queries in one call: %zu", nq);
-  if (s->params.mode == EHX_MODE_GRAPH) return knn_graph_locked(s, st, nq, d_queries, k, d_ids, d_dist, d_count);
+// one flat pipeline: prepared queries -> scan -> merge -> canonical re-rank.
+//   f16 = false: the fp32 MFMA scan (k_flat8.hip), exact on its own.
+//   f16 = true : the fp16 MFMA filter scan (k_flat16.hip); per-query certification flags land in
+//                s->dUflags and the caller re-runs the unflagged remainder through the fp32 scan.
+int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k, uint64_t* d_ids,
+              float* d_dist, uint32_t* d_count, bool f16, bool count_stats) {
   Engine& E = engine();
-  // Two passes (8-wave kernel): a SAMPLE pass over the first ~1/32 of the row tiles produces, per
+  // Two passes (8-wave kernels): a SAMPLE pass over the first ~1/32 of the row tiles produces, per
   // query, the k'-th best key of the sample — an upper bound of the global k'-th best — and the main
   // pass over the remaining tiles starts from that threshold, so its slow path (candidate appends)
   // runs ~10x less often than when every workgroup has to warm its thresholds up from +inf.
   const uint32_t n_tiles = (uint32_t)((s->n + kTileRows - 1) / kTileRows);
-  const uint32_t lpc = scan_lists_per_chunk();
+  const uint32_t lpc = f16 ? 2u : scan_lists_per_chunk();
   uint32_t sample_tiles = 0;
   if (lpc == 2 && n_tiles >= 4096) sample_tiles = (n_tiles / 32 + 255) / 256 * 256;
-  const ScanPlan p = plan_scan((uint32_t)nq, n_tiles - sample_tiles, k, E.n_cus);   // main pass
-  const ScanPlan ps = plan_scan((uint32_t)nq, sample_tiles, k, E.n_cus);            // sample pass
+  ScanPlan p = plan_scan((uint32_t)nq, n_tiles - sample_tiles, k, E.n_cus);   // main pass
+  ScanPlan ps = plan_scan((uint32_t)nq, sample_tiles, k, E.n_cus);            // sample pass
+  if (f16) {
+    // the filter keeps k' = k + 22 candidates (<= 56): the certification needs the k'-th lower bound to
+    // clear the k-th exact distance by the fp16 error bound, so it wants more slack than the fp32 scan
+    const uint32_t kp = k + 22 > 56 ? (k + 8 > 56 ? k + 8 : 56) : k + 22;
+    p.kprime = ps.kprime = kp;
+  }
   const uint32_t lists_main = p.n_chunks * lpc, lists_sample = sample_tiles ? ps.n_chunks * lpc : 0;
   const uint32_t lists_total = lists_main + lists_sample;
   const uint32_t grid_max = p.grid > ps.grid ? p.grid : ps.grid;
@@ -720,11 +779,24 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     HIP_TRY(hipMalloc((void**)&s->dUncert, 2 * sizeof(unsigned long long)));  // [0] uncertified, [1] scan error
     HIP_TRY(hipMemset(s->dUncert, 0, 2 * sizeof(unsigned long long)));
   }
+  if (f16) {
+    if ((rc = s->dQ16.ensure((size_t)p.q_rows * s->ld16))) return rc;
+    if ((rc = s->dQgamma.ensure(p.q_rows))) return rc;
+    if ((rc = s->dQuv.ensure(p.q_rows))) return rc;
+    if ((rc = s->dUflags.ensure(p.q_rows))) return rc;
+    if (!s->dUncert16) {
+      HIP_TRY(hipMalloc((void**)&s->dUncert16, sizeof(unsigned long long)));
+      HIP_TRY(hipMemset(s->dUncert16, 0, sizeof(unsigned long long)));
+    }
+  }
   // scratch buffers are shared by all callers: order this pipeline after the previous one even
   // when it was enqueued on a different stream
   if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
   HIP_TRY(hipEventRecord(s->ev[0], st));
   HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, p.q_rows, s->metric, s->dQ.p, st));
+  if (f16)
+    HIP_TRY(launch_prep_queries16(d_queries, (uint32_t)nq, s->dims, s->ld16, p.q_rows, s->metric, s->dQ16.p,
+                                  s->dQgamma.p, s->dQuv.p, st));
   if (s->n == 0) {
     // empty space: every query returns count 0
     HIP_TRY(hipMemsetAsync(s->dMerged.p, 0xFF, (size_t)p.q_rows * 64 * sizeof(uint64_t), st));
@@ -745,30 +817,52 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     a.lists_total = lists_total;
     a.err = (uint32_t*)(s->dUncert + 1);
     a.gthr = (unsigned long long*)s->dGthr.p;
+    ScanArgs16 h;
+    h.Q = s->dQ16.p;
+    h.X = s->dX16;
+    h.rowp = s->dRowp16;
+    h.qgamma = s->dQgamma.p;
+    h.eps = scan16_eps(s->dims);
+    h.cos = s->metric == EHX_METRIC_COSINE;
+    h.cand = a.cand;
+    h.part = a.part;
+    h.n = a.n;
+    h.ld = s->ld16;
+    h.q_tiles = a.q_tiles;
+    h.kprime = a.kprime;
+    h.lists_total = lists_total;
+    h.err = a.err;
+    h.gthr = a.gthr;
+    auto scan = [&](const ScanPlan& pl, uint32_t tile0, uint32_t list0) -> hipError_t {
+      if (f16) {
+        h.tile0 = tile0;
+        h.n_tiles = pl.n_tiles;
+        h.n_chunks = pl.n_chunks;
+        h.tiles_per_chunk = pl.tiles_per_chunk;
+        h.xcd_map = pl.xcd_map;
+        h.list0 = list0;
+        return launch_flat_scan16(h, st);
+      }
+      a.tile0 = tile0;
+      a.n_tiles = pl.n_tiles;
+      a.n_chunks = pl.n_chunks;
+      a.tiles_per_chunk = pl.tiles_per_chunk;
+      a.xcd_map = pl.xcd_map;
+      a.list0 = list0;
+      return launch_flat_scan(a, st);
+    };
     HIP_TRY(hipMemsetAsync(s->dGthr.p, 0xFF, (size_t)p.q_rows * sizeof(uint64_t), st));
     hipEvent_t* pr = s->ring[s->ring_count % ehx_space::kRing];
     HIP_TRY(hipEventRecord(s->ev[1], st));
     HIP_TRY(hipEventRecord(pr[0], st));
     if (sample_tiles) {
-      a.tile0 = 0;
-      a.n_tiles = ps.n_tiles;
-      a.n_chunks = ps.n_chunks;
-      a.tiles_per_chunk = ps.tiles_per_chunk;
-      a.xcd_map = ps.xcd_map;
-      a.list0 = lists_main;
-      HIP_TRY(launch_flat_scan(a, st));
+      HIP_TRY(scan(ps, 0, lists_main));
       // threshold = k'-th best of the merged sample lists
       HIP_TRY(launch_flat_merge(s->dPart.p + (size_t)lists_main * p.kprime, (uint32_t)nq, lists_sample, p.kprime,
                                 s->dMerged.p, st, lists_total));
       HIP_TRY(launch_set_gthr(s->dMerged.p, (uint32_t)nq, p.kprime, (unsigned long long*)s->dGthr.p, st));
     }
-    a.tile0 = sample_tiles;
-    a.n_tiles = p.n_tiles;
-    a.n_chunks = p.n_chunks;
-    a.tiles_per_chunk = p.tiles_per_chunk;
-    a.xcd_map = p.xcd_map;
-    a.list0 = 0;
-    HIP_TRY(launch_flat_scan(a, st));
+    HIP_TRY(scan(p, sample_tiles, 0));
     HIP_TRY(hipEventRecord(pr[1], st));
     HIP_TRY(hipEventRecord(s->ev[2], st));
     s->ring_count++;
@@ -783,7 +877,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   r.out_ids = d_ids;
   r.out_dist = d_dist;
   r.out_count = d_count;
-  r.n_uncertified = s->dUncert;
+  r.n_uncertified = f16 ? s->dUncert16 : s->dUncert;
   r.nq = (uint32_t)nq;
   r.k = k;
   r.kprime = p.kprime;
@@ -791,14 +885,70 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   r.dims = s->dims;
   r.ld = s->ld;
   r.metric = s->metric;
+  if (f16) {
+    r.quv = s->dQuv.p;
+    r.uncert_flags = s->dUflags.p;
+  }
   HIP_TRY(launch_rerank(r, st));
   HIP_TRY(hipEventRecord(s->ev[3], st));
   s->ev_valid = true;
-  s->n_queries += nq;
-  s->n_dist += (uint64_t)nq * s->n;
+  if (count_stats) {
+    s->n_queries += nq;
+    s->n_dist += (uint64_t)nq * s->n;
+    // SURVEY §8d brute force bytes per batch: N*d*s + B*d*4 + B*k*12 (s = bytes per element the scan reads)
+    s->bytes_algo += s->n * s->dims * (uint64_t)(f16 ? 2 : s->esz) + (uint64_t)nq * s->dims * 4ull +
+                     (uint64_t)nq * k * 12ull;
+  }
   s->n_rerank += (uint64_t)nq * p.kprime;
-  // SURVEY §8d brute force bytes per batch: N*d*s + B*d*4 + B*k*12
-  s->bytes_algo += s->n * s->dims * (uint64_t)s->esz + (uint64_t)nq * s->dims * 4ull + (uint64_t)nq * k * 12ull;
+  return EHX_OK;
+}
+
+// device pipeline of a flat space.  fp32 spaces scan with the fp16 filter first; the (rare) queries
+// whose top-k the filter cannot certify are re-run through the fp32 scan, so the results are always
+// those of the fp32 scan + canonical re-rank.
+int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k,
+                      uint64_t* d_ids, float* d_dist, uint32_t* d_count) {
+  if (k == 0 || nq == 0) return EHX_OK;
+  if (k > EHX_MAX_K) return fail(EHX_EUNSUPPORTED, "k=%u exceeds EHX_MAX_K=%u", k, EHX_MAX_K);
+  if (nq > (1u << 24)) return fail(EHX_EINVAL, "too many queries in one call: %zu", nq);
+  if (s->params.mode == EHX_MODE_GRAPH) return knn_graph_locked(s, st, nq, d_queries, k, d_ids, d_dist, d_count);
+  const bool f16 = s->use16 && s->h_unsafe == 0 && s->n > 0;
+  if (!f16) return flat_pass(s, st, nq, d_queries, k, d_ids, d_dist, d_count, false, true);
+  int rc = flat_pass(s, st, nq, d_queries, k, d_ids, d_dist, d_count, true, true);
+  if (rc) return rc;
+  s->n_filter_queries += nq;
+  // certification verdict of the filter pass (the only host round trip of the pipeline)
+  unsigned long long n_unc = 0;
+  HIP_TRY(hipMemcpyAsync(&n_unc, s->dUncert16, sizeof(n_unc), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (n_unc == 0) return EHX_OK;
+  HIP_TRY(hipMemsetAsync(s->dUncert16, 0, sizeof(unsigned long long), st));
+  std::vector<uint32_t> flags(nq);
+  HIP_TRY(hipMemcpyAsync(flags.data(), s->dUflags.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<uint32_t> redo;
+  for (size_t i = 0; i < nq; ++i)
+    if (flags[i]) redo.push_back((uint32_t)i);
+  s->n_filter_fallback += redo.size();
+  if (redo.empty()) return EHX_OK;
+  if (redo.size() * 2 > nq)  // most of the batch: just run it all through the fp32 scan
+    return flat_pass(s, st, nq, d_queries, k, d_ids, d_dist, d_count, false, false);
+  const size_t m = redo.size();
+  if ((rc = s->dFbQ.ensure(m * s->dims))) return rc;
+  if ((rc = s->dFbIds.ensure(m * k))) return rc;
+  if ((rc = s->dFbDist.ensure(m * k))) return rc;
+  if ((rc = s->dFbCnt.ensure(m))) return rc;
+  for (size_t j = 0; j < m; ++j)
+    HIP_TRY(hipMemcpyAsync(s->dFbQ.p + j * s->dims, d_queries + (size_t)redo[j] * s->dims, s->dims * sizeof(float),
+                           hipMemcpyDeviceToDevice, st));
+  if ((rc = flat_pass(s, st, m, s->dFbQ.p, k, s->dFbIds.p, s->dFbDist.p, s->dFbCnt.p, false, false))) return rc;
+  for (size_t j = 0; j < m; ++j) {
+    const size_t q = redo[j];
+    HIP_TRY(hipMemcpyAsync(d_ids + q * k, s->dFbIds.p + j * k, k * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_dist + q * k, s->dFbDist.p + j * k, k * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_count + q, s->dFbCnt.p + j, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  }
+  HIP_TRY(hipEventRecord(s->ev[3], st));
   return EHX_OK;
 }
 
@@ -901,6 +1051,17 @@ int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metri
   if (s->params.ef_construction == 0) s->params.ef_construction = 200;
   if (s->params.ef == 0) s->params.ef = 10;
   if (s->params.seed == 0) s->params.seed = 100;
+  if (s->params.scan > EHX_SCAN_F32) return fail(EHX_EINVAL, "unknown scan engine %u", s->params.scan);
+  {
+    const char* env = getenv("EHX_SCAN");  // "f32": every space scans in fp32 (A/B runs, profiling)
+    const bool env_f32 = env && strcmp(env, "f32") == 0;
+    s->use16 = s->params.mode == EHX_MODE_FLAT && !s->x_half && s->params.scan != EHX_SCAN_F32 && !env_f32;
+    s->ld16 = (uint32_t)round_up(dims, 64);
+    if (s->use16) {
+      HIP_TRY(hipMalloc((void**)&s->dUnsafe, sizeof(unsigned long long)));
+      HIP_TRY(hipMemset(s->dUnsafe, 0, sizeof(unsigned long long)));
+    }
+  }
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
   for (auto& pr : s->ring)
@@ -999,6 +1160,18 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
   return set_batch_locked(s, n, keys, klens, vecs);
 }
 
+// (re)build the fp16 scan copy of rows [row0, row0+n) after they were written; must follow row_stats
+static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n) {
+  if (!s->use16 || n == 0) return EHX_OK;
+  HIP_TRY(launch_make_scan16(s->xf32(), row0, n, s->dims, s->ld, s->ld16, s->metric, s->dX16, s->dRowp16, s->dUnsafe,
+                             s->stream));
+  unsigned long long u = 0;
+  HIP_TRY(hipMemcpyAsync(&u, s->dUnsafe, sizeof(u), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->h_unsafe = u;
+  return EHX_OK;
+}
+
 static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, const size_t* klens, const float* vecs) {
   if (s->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
   if (s->implicit_keys) return fail(EHX_EINVAL, "space '%s' holds synthetic rows with implicit keys", s->name.c_str());
@@ -1066,6 +1239,7 @@ static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, con
   // per-row statistics over the touched id range (idempotent for untouched rows in between)
   HIP_TRY(launch_row_stats(s->dX, s->x_half, min_id, max_id - min_id + 1, s->dims, s->ld, s->metric, s->dInv,
                            s->dRowp, s->stream));
+  if ((rc = refresh_scan16(s, min_id, max_id - min_id + 1))) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (s->params.mode == EHX_MODE_GRAPH) {
     // new rows join the graph one at a time, in id order (ANNIndex::set -> addPoint, index.cc:36);
@@ -1368,6 +1542,7 @@ int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_ro
   }
   HIP_TRY(launch_row_stats(s->dX, s->x_half, s->n, n_rows, s->dims, s->ld, s->metric, s->dInv, s->dRowp, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if ((rc = refresh_scan16(s, s->n, n_rows))) return rc;
   const uint64_t old_n = s->n;
   s->n += n_rows;
   if (s->params.mode == EHX_MODE_GRAPH && s->g_n == old_n && s->params.build_batch != 0xFFFFFFFFu) {
@@ -1500,6 +1675,8 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
   out->n_dist = s->n_dist;
   out->n_rerank = s->n_rerank;
   out->bytes_algorithmic = s->bytes_algo;
+  out->n_filter_queries = s->n_filter_queries;
+  out->n_filter_fallback = s->n_filter_fallback;
   if (s->dGraphCounters) {
     unsigned long long g[3] = {0, 0, 0};
     HIP_TRY(hipMemcpy(g, s->dGraphCounters, sizeof(g), hipMemcpyDeviceToHost));
@@ -1541,6 +1718,8 @@ int ehx_stats_reset(ehx_space* s) {
   s->n_dist = 0;
   s->n_rerank = 0;
   s->bytes_algo = 0;
+  s->n_filter_queries = 0;
+  s->n_filter_fallback = 0;
   s->ring_count = 0;
   if (s->dUncert) HIP_TRY(hipMemset(s->dUncert, 0, 2 * sizeof(unsigned long long)));
   if (s->dGraphCounters) HIP_TRY(hipMemset(s->dGraphCounters, 0, 3 * sizeof(unsigned long long)));

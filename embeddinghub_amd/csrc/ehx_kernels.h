@@ -191,6 +191,38 @@ hipError_t launch_flat_scan(const ScanArgs& a, hipStream_t st);   // dispatches 
 hipError_t launch_flat_scan4(const ScanArgs& a, hipStream_t st);  // k_flat.hip: 4 waves, one per SIMD
 hipError_t launch_flat_scan8(const ScanArgs& a, hipStream_t st);  // k_flat8.hip: 8 waves, two per SIMD
 
+// ---- fp16-MFMA filter scan (k_flat16.hip) ----
+struct ScanArgs16 {
+  const __half* Q;       // [q_tiles*256][ld] unit-normalised queries, binary16 (zero padded)
+  const __half* X;       // [cap][ld] scan copy: unit-normalised rows, binary16; cap % 256 == 0
+  const float2* rowp;    // [cap] (a_r, b_r): S = b_r*gamma_q + a_r*dot;  padding rows (0, +inf)
+  const float* qgamma;   // [q_tiles*256] gamma_q
+  float eps;             // accumulator start value: bound of |dot16 - true dot|
+  uint32_t cos;          // 1: every valid row has (a, b) = (-1, 1) and gamma = 1 (cosine): fast phase 1
+  uint64_t* cand;
+  uint64_t* part;
+  uint32_t n;
+  uint32_t ld;           // row stride in halves, % 64 == 0
+  uint32_t tile0, n_tiles, list0, lists_total, q_tiles, n_chunks, tiles_per_chunk, kprime;
+  uint32_t* err;
+  unsigned long long* gthr;
+  uint32_t xcd_map;
+};
+size_t scan16_lds_bytes();
+hipError_t launch_flat_scan16(const ScanArgs16& a, hipStream_t st);
+// bound of |<fp16(q^), fp16(x^)> accumulated in fp32 - <q^, x^>| for unit vectors of `dims` elements
+inline float scan16_eps(uint32_t dims) { return 1.0e-3f + 2.0e-7f * (float)dims; }
+
+// scan copy of rows [row0, row0+n): X16 = fp16(x/|x|), rowp16 = (a_r, b_r) per metric.  Rows the filter
+// cannot bound (non-finite or denormal-range norms) are counted in *n_unsafe (the space then stays on
+// the fp32 scan).
+hipError_t launch_make_scan16(const float* X, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld, uint32_t ld16,
+                              int metric, __half* X16, float2* rowp16, unsigned long long* n_unsafe, hipStream_t st);
+// filter-side query preparation: Q16 = fp16(q/|q|) padded to [q_rows][ld16]; qgamma[q]; quv[q] = (u, v) with
+// D = u*S + v.  Queries the filter cannot bound get u = NaN (never certified -> fp32 re-run).
+hipError_t launch_prep_queries16(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld16, uint32_t q_rows,
+                                 int metric, __half* Q16, float* qgamma, float2* quv, hipStream_t st);
+
 hipError_t launch_set_gthr(const uint64_t* merged, uint32_t nq, uint32_t kprime, unsigned long long* gthr, hipStream_t st);
 
 // one wave per query: k-way merge of the per-chunk sorted key lists -> top-kprime keys
@@ -211,6 +243,10 @@ struct RerankArgs {
   unsigned long long* n_uncertified;  // device counter
   uint32_t nq, k, kprime, n, dims, ld;
   int metric;
+  // fp16-filter scans: the keys hold S_lower; D = u*S + v maps the worst candidate back to a distance.
+  // nullptr for the fp32 scan.
+  const float2* quv = nullptr;
+  uint32_t* uncert_flags = nullptr;  // [nq] 1 = not certified (optional)
 };
 hipError_t launch_rerank(const RerankArgs& a, hipStream_t st);
 

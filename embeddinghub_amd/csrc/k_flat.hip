@@ -544,12 +544,19 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
     // A_last - margin > exact k-th distance, no outsider can beat the k-th result, so the top-k is
     // provably the exhaustive top-k.  margin bounds the fp32 rounding gap between the MFMA-order
     // score and the canonical-order distance.  (Skipped when every row is a candidate.)
+    bool uncert = false;
     if (a.n > a.kprime && cnt == a.k && a.k > 0) {
       float worst = -__builtin_inff();
       for (int j = 0; j < 64; ++j)
         if (approx[j] != __builtin_inff() && approx[j] > worst) worst = approx[j];
       float qn = 0.0f;
-      if (a.metric == 0) {
+      if (a.quv) {
+        // fp16-filter keys: `worst` is a lower bound S of every outsider's score; map it to a distance
+        // (NaN u marks a query the filter could not bound: the comparison below fails)
+        const float2 uv = a.quv[q];
+        worst = __builtin_fmaf(uv.x, worst, uv.y);
+        qn = a.metric == 0 ? uv.y : 0.0f;
+      } else if (a.metric == 0) {
         const float* qv = a.Q + (size_t)q * a.ld;
         for (uint32_t m = tid; m < a.dims; m += 64) qn += qv[m] * qv[m];
         for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o, 64);
@@ -558,7 +565,13 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
       const float kth = ordered_to_f32((uint32_t)(__shfl(key, (int)a.k - 1, 64) >> 32));
       const float scale = fmaxf(fmaxf(fabsf(kth), fabsf(worst)), fmaxf(qn, 1.0f));
       const float margin = 1e-5f * scale;
-      if (tid == 0 && !(worst - margin > kth)) atomicAdd(a.n_uncertified, 1ull);
+      uncert = !(worst - margin > kth);
+    } else if (a.quv && a.n > a.kprime && cnt < a.k) {
+      uncert = true;  // the filter lost candidates (overflowing gamma etc.): let the fp32 scan decide
+    }
+    if (tid == 0) {
+      if (uncert) atomicAdd(a.n_uncertified, 1ull);
+      if (a.uncert_flags) a.uncert_flags[q] = uncert ? 1u : 0u;
     }
   }
 }

@@ -90,6 +90,107 @@ hipError_t launch_row_stats(const void* X, int x_half, uint64_t row0, uint64_t n
   return hipGetLastError();
 }
 
+// ---- fp16-MFMA filter scan: scan copy and query preparation (k_flat16.hip) ---------------------------
+// One wave per row.  The norm here is the filter's own (parallel fp32 sum; its rounding is inside the
+// eps of scan16_eps) — the canonical distances never see it.
+namespace {
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// norms the filter's error analysis covers: finite, and far from the fp32 underflow/overflow ranges
+__device__ __forceinline__ bool norm_ok(float sumsq) { return sumsq == 0.0f || (sumsq > 1e-24f && sumsq < 1e30f); }
+}  // namespace
+
+__global__ __launch_bounds__(256) void make_scan16_kernel(const float* __restrict__ X, uint64_t row0, uint64_t n,
+                                                          uint32_t dims, uint32_t ld, uint32_t ld16, int metric,
+                                                          __half* __restrict__ X16, float2* __restrict__ rowp16,
+                                                          unsigned long long* __restrict__ n_unsafe) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const uint64_t r = row0 + i;
+  const float* x = X + r * ld;
+  float ss = 0.0f;
+  for (uint32_t c = lane; c < dims; c += 64) ss += x[c] * x[c];
+  ss = wave_sum(ss);
+  const bool ok = norm_ok(ss);
+  const float nr = ok ? __builtin_sqrtf(ss) : 0.0f;
+  const float inv = nr > 0.0f ? 1.0f / nr : 0.0f;
+  __half* o = X16 + r * ld16;
+  for (uint32_t c = lane; c < ld16; c += 64) o[c] = __float2half_rn(c < dims ? x[c] * inv : 0.0f);
+  if (lane == 0) {
+    float2 p;
+    if (!ok) {
+      p = make_float2(0.0f, __builtin_inff());
+      atomicAdd(n_unsafe, 1ull);
+    } else if (metric == 2) {
+      p = make_float2(-1.0f, 1.0f);
+    } else if (metric == 1) {
+      p = make_float2(-nr, 1.0f);
+    } else {
+      p = make_float2(-nr, ss);
+    }
+    rowp16[r] = p;
+  }
+}
+
+hipError_t launch_make_scan16(const float* X, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld, uint32_t ld16,
+                              int metric, __half* X16, float2* rowp16, unsigned long long* n_unsafe, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(make_scan16_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, X, row0, n, dims, ld, ld16,
+                     metric, X16, rowp16, n_unsafe);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void prep_queries16_kernel(const float* __restrict__ q_in, uint32_t nq, uint32_t dims,
+                                                            uint32_t ld16, int metric, __half* __restrict__ Q16,
+                                                            float* __restrict__ qgamma, float2* __restrict__ quv) {
+  const uint32_t row = blockIdx.x;
+  const int lane = threadIdx.x;
+  __half* out = Q16 + (size_t)row * ld16;
+  if (row >= nq) {
+    for (uint32_t c = lane; c < ld16; c += 64) out[c] = __float2half_rn(0.0f);
+    if (lane == 0) {
+      qgamma[row] = 1.0f;
+      quv[row] = make_float2(1.0f, 0.0f);
+    }
+    return;
+  }
+  const float* in = q_in + (size_t)row * dims;
+  float ss = 0.0f;
+  for (uint32_t c = lane; c < dims; c += 64) ss += in[c] * in[c];
+  ss = wave_sum(ss);
+  const bool ok = norm_ok(ss);
+  const float beta = ok ? __builtin_sqrtf(ss) : 0.0f;
+  const float inv = beta > 0.0f ? 1.0f / beta : 0.0f;
+  for (uint32_t c = lane; c < ld16; c += 64) out[c] = __float2half_rn(c < dims ? in[c] * inv : 0.0f);
+  if (lane == 0) {
+    float g = 1.0f, u = 1.0f, v = 0.0f;
+    if (beta > 0.0f) {
+      if (metric == 1) {
+        g = 1.0f / beta;
+        u = beta;
+      } else if (metric == 0) {
+        g = 0.5f / beta;
+        u = 2.0f * beta;
+        v = ss;
+      }
+    }
+    if (!ok) u = __builtin_nanf("");
+    qgamma[row] = g;
+    quv[row] = make_float2(u, v);
+  }
+}
+
+hipError_t launch_prep_queries16(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld16, uint32_t q_rows,
+                                 int metric, __half* Q16, float* qgamma, float2* quv, hipStream_t st) {
+  hipLaunchKernelGGL(prep_queries16_kernel, dim3(q_rows), dim3(64), 0, st, q_in, nq, dims, ld16, metric, Q16, qgamma,
+                     quv);
+  return hipGetLastError();
+}
+
 // ---- fp16 storage ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void store_rows_f16_kernel(const float* __restrict__ src, uint32_t src_ld,
                                                              const uint64_t* __restrict__ ids, uint64_t row0,

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define EHX_ABI_VERSION 1
+#define EHX_ABI_VERSION 2
 
 /* ---- error codes (shim mapping: gRPC status for contract 1, fferr type for contract 2) ---- */
 enum {
@@ -71,6 +71,8 @@ enum {
   EHX_MODE_GRAPH = 1  /* HNSW-style level-0 best-first search over an HBM-resident graph      */
 };
 
+enum { EHX_SCAN_AUTO = 0, EHX_SCAN_F32 = 1 };
+
 #define EHX_MAX_K 48u /* largest k served by one scan pass (k + 8 slack < 64 candidate slots) */
 
 typedef struct ehx_space ehx_space; /* opaque; owned by the process-global registry */
@@ -87,7 +89,10 @@ typedef struct ehx_params {
   uint32_t build_batch;     /* graph mode: rows inserted concurrently per round by bulk loads
                                (ehx_fill_synthetic); 0 = auto, 1 = strictly sequential (hnswlib order).
                                ehx_set / ehx_set_batch always insert sequentially.                     */
-  uint32_t reserved[7];
+  uint32_t scan;            /* flat mode, fp32 rows: EHX_SCAN_AUTO (0) = fp16 matrix-core filter scan in front of
+                               the canonical fp32 re-rank, with an fp32 re-scan of every query the filter cannot
+                               certify — results identical to EHX_SCAN_F32 (1) = fp32 matrix-core scan only.   */
+  uint32_t reserved[6];
 } ehx_params;
 
 /* Work and time counters, same definitions as the oracle. */
@@ -104,6 +109,8 @@ typedef struct ehx_stats_t {
   double   last_total_ms;    /* device time of the last full ehx_knn* pipeline                       */
   double   scan_ms_mean;     /* mean device time of the last <=64 scan/search kernel launches        */
   uint64_t scan_launches;    /* number of launches averaged in scan_ms_mean                          */
+  uint64_t n_filter_queries; /* queries answered through the fp16 filter scan                        */
+  uint64_t n_filter_fallback;/* ... of which the filter could not certify and the fp32 scan re-ran   */
 } ehx_stats_t;
 
 /* ---- process / device ---- */

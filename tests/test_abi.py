@@ -38,13 +38,28 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.ehx_abi_version() == 1
+    assert lib.ehx_abi_version() == 2
 
 
-def test_struct_layouts_match_header():
-    # ehx_params: 4 x u32 + 2 x u64 + 8 x u32 ; ehx_stats_t: 8 x u64 + 3 x double + u64
-    assert C.sizeof(_lib.Params) == 4 * 4 + 2 * 8 + 8 * 4
-    assert C.sizeof(_lib.Stats) == 8 * 8 + 3 * 8 + 8
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof / offsetof of every struct field as a C compiler sees include/ehx.h == the ctypes mirror."""
+    import subprocess
+    fields = {"ehx_params": [f for f, _ in _lib.Params._fields_], "ehx_stats_t": [f for f, _ in _lib.Stats._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "ehx.h"', 'int main(void) {']
+    for st, fs in fields.items():
+        src.append('printf("%s %%zu\\n", sizeof(%s));' % (st, st))
+        for f in fs:
+            src.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (st, f, st, f))
+    src += ['return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    for st, cls in (("ehx_params", _lib.Params), ("ehx_stats_t", _lib.Stats)):
+        assert int(got[st]) == C.sizeof(cls), st
+        for f, _ in cls._fields_:
+            assert int(got["%s.%s" % (st, f)]) == getattr(cls, f).offset, (st, f)
 
 
 def test_no_device_fails_loudly(lib):

@@ -160,16 +160,48 @@ def test_go_vectorstore_golden(golden_dir):  # vectorstore_test.go:121-166
     (70000, 32, 64, 10),     # many tiles per chunk, every CU busy
 ])
 @pytest.mark.parametrize("em,om", METRICS)
-def test_random_parity(n, d, nq, k, em, om):
+@pytest.mark.parametrize("scan", [ehx.SCAN_AUTO, ehx.SCAN_F32])  # fp16 filter + fp32 re-rank | fp32 scan only
+def test_random_parity(n, d, nq, k, em, om, scan):
     rng = np.random.default_rng(n * 31 + d)
     X = rng.standard_normal((n, d)).astype(np.float32)
     Q = rng.standard_normal((nq, d)).astype(np.float32)
-    s = ehx.Space.unique("rand", d, metric=em)
+    s = ehx.Space.unique("rand", d, metric=em, scan=scan)
     s.set_batch(_keys(n), X)
     assert len(s) == n
     _check(s, X, Q, k, om)
     st = s.stats()
     assert st["n_uncertified"] == 0 and st["n_rows"] == n
+    assert st["n_filter_queries"] == (nq if scan == ehx.SCAN_AUTO else 0)
+    assert st["n_filter_fallback"] <= nq // 4  # re-runs through the fp32 scan must stay the exception
+    s.drop()
+
+
+@pytest.mark.parametrize("em,om", METRICS)
+def test_filter_scale_invariance_and_fallback(em, om):
+    """The fp16 filter normalises rows and queries, so wildly scaled data must give the oracle's answers;
+    near-duplicate rows defeat its certification and must be answered by the fp32 re-run."""
+    rng = np.random.default_rng(77)
+    n, d = 4000, 96
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    X *= np.exp(rng.uniform(-12, 12, size=(n, 1))).astype(np.float32)  # row norms over ten decades
+    Q = (rng.standard_normal((24, d)) * np.exp(rng.uniform(-8, 8, size=(24, 1)))).astype(np.float32)
+    s = ehx.Space.unique("scale", d, metric=em)
+    s.set_batch(_keys(n), X)
+    _check(s, X, Q, 10, om)
+    s.drop()
+    # 40 rows within 5 % of each other around the query: more near-ties than the filter keeps candidates,
+    # its lower bounds cannot separate them — such queries must fall back to the fp32 scan and stay exact
+    base = rng.standard_normal(d).astype(np.float32)
+    Y = rng.standard_normal((3000, d)).astype(np.float32)
+    Y[:40] = base * (1.0 + 5e-2 * rng.standard_normal((40, d)).astype(np.float32))
+    s = ehx.Space.unique("dups", d, metric=em)
+    s.set_batch(_keys(3000), Y)
+    Qd = np.stack([base, Y[5], rng.standard_normal(d).astype(np.float32)])
+    _check(s, Y, Qd, 10, om)
+    st = s.stats()
+    assert st["n_uncertified"] == 0
+    if em != ehx.METRIC_IP:  # (raw inner products of these rows are spread far enough for the filter)
+        assert st["n_filter_fallback"] >= 1
     s.drop()
 
 
