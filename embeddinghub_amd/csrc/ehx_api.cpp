@@ -754,10 +754,11 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
   // query, the k'-th best key of the sample — an upper bound of the global k'-th best — and the main
   // pass over the remaining tiles starts from that threshold, so its slow path (candidate appends)
   // runs ~10x less often than when every workgroup has to warm its thresholds up from +inf.
-  const uint32_t n_tiles = (uint32_t)((s->n + kTileRows - 1) / kTileRows);
+  const uint32_t tile_rows = f16 ? kTileRows16 : kTileRows;
+  const uint32_t n_tiles = (uint32_t)((s->n + tile_rows - 1) / tile_rows);
   const uint32_t lpc = f16 ? 2u : scan_lists_per_chunk();
   uint32_t sample_tiles = 0;
-  if (lpc == 2 && n_tiles >= 4096) sample_tiles = (n_tiles / 32 + 255) / 256 * 256;
+  if (lpc == 2 && (uint64_t)n_tiles * tile_rows >= 4096u * 128u) sample_tiles = (n_tiles / 32 + 255) / 256 * 256;
   ScanPlan p = plan_scan((uint32_t)nq, n_tiles - sample_tiles, k, E.n_cus);   // main pass
   ScanPlan ps = plan_scan((uint32_t)nq, sample_tiles, k, E.n_cus);            // sample pass
   if (f16) {
@@ -921,6 +922,9 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   unsigned long long n_unc = 0;
   HIP_TRY(hipMemcpyAsync(&n_unc, s->dUncert16, sizeof(n_unc), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+#if defined(EHX_ABL) && EHX_ABL
+  return EHX_OK;  // profiling builds with ablated (wrong-by-construction) kernels: time the filter only
+#endif
   if (n_unc == 0) return EHX_OK;
   HIP_TRY(hipMemsetAsync(s->dUncert16, 0, sizeof(unsigned long long), st));
   std::vector<uint32_t> flags(nq);
@@ -1056,7 +1060,7 @@ int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metri
     const char* env = getenv("EHX_SCAN");  // "f32": every space scans in fp32 (A/B runs, profiling)
     const bool env_f32 = env && strcmp(env, "f32") == 0;
     s->use16 = s->params.mode == EHX_MODE_FLAT && !s->x_half && s->params.scan != EHX_SCAN_F32 && !env_f32;
-    s->ld16 = (uint32_t)round_up(dims, 64);
+    s->ld16 = (uint32_t)round_up(dims, 32);
     if (s->use16) {
       HIP_TRY(hipMalloc((void**)&s->dUnsafe, sizeof(unsigned long long)));
       HIP_TRY(hipMemset(s->dUnsafe, 0, sizeof(unsigned long long)));

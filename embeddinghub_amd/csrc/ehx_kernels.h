@@ -10,6 +10,7 @@ namespace ehx {
 
 constexpr uint32_t kTileRows = 128;   // corpus rows per scan tile
 constexpr uint32_t kTileQ = 256;      // queries per scan tile
+constexpr uint32_t kTileRows16 = 256; // corpus rows per tile of the fp16 filter scan (k_flat16.hip)
 constexpr uint32_t kBK = 32;          // k-depth of one LDS stage (floats)
 constexpr uint32_t kCandSlots = 64;   // per-(query, block) candidate slots = one wave row
 constexpr uint64_t kKeyInf = ~0ull;
@@ -202,7 +203,7 @@ struct ScanArgs16 {
   uint64_t* cand;
   uint64_t* part;
   uint32_t n;
-  uint32_t ld;           // row stride in halves, % 64 == 0
+  uint32_t ld;           // row stride in halves, % 32 == 0
   uint32_t tile0, n_tiles, list0, lists_total, q_tiles, n_chunks, tiles_per_chunk, kprime;
   uint32_t* err;
   unsigned long long* gthr;

@@ -41,9 +41,23 @@ def summarize(path):
         print("%-46s %-28s %8s %18s %18s" % ("kernel", "counter", "samples", "mean_per_dispatch", "sum"))
         for r in pm:
             print("%-46s %-28s %8d %18.1f %18.1f" % (r[0].split("(")[0][-46:], r[1], r[2], r[3], r[4]))
+    # dispatch sequence of the scan kernels (sample pass / main pass alternate): last 12 dispatches
+    seq = c.execute("""
+        select s.kernel_name, d.end - d.start from rocpd_kernel_dispatch d
+        join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+        where s.kernel_name like '%flat_scan%' order by d.start""").fetchall()
+    if seq:
+        print("# last scan-kernel dispatches in launch order (ms): " +
+              " ".join("%.3f" % (r[1] / 1e6) for r in seq[-12:]))
     print()
 
 
 if __name__ == "__main__":
+    import glob
+    import os
     for p in sys.argv[1:]:
-        summarize(p)
+        if os.path.isdir(p):  # a rocprofv3 output directory: every *.db below it
+            for f in sorted(glob.glob(os.path.join(p, "**", "*.db"), recursive=True)):
+                summarize(f)
+        else:
+            summarize(p)
