@@ -107,7 +107,7 @@ struct ehx_space {
   uint64_t cap = 0, n = 0;
   // fp16-MFMA filter scan (k_flat16.hip): unit-normalised binary16 scan copy of the rows
   bool use16 = false;          // this space scans with the fp16 filter (fp32 flat spaces, unless disabled)
-  __half* dX16 = nullptr;      // [cap][ld16]
+  __half* dX16 = nullptr;      // [cap][ld16] in the stage-blocked scan16_index layout
   float2* dRowp16 = nullptr;   // [cap]
   uint32_t ld16 = 0;
   unsigned long long* dUnsafe = nullptr;  // rows the filter cannot bound (then every scan is the fp32 scan)
@@ -275,8 +275,9 @@ int grow(ehx_space* s, uint64_t rows) {
   if (s->use16) {
     __half* nx16 = nullptr;
     float2* nr16 = nullptr;
-    hipError_t e3 = hipMalloc((void**)&nx16, want * s->ld16 * sizeof(__half));
-    hipError_t e4 = hipMalloc((void**)&nr16, want * sizeof(float2));
+    // (+ tail padding: the scan's DMA reads three stage blocks / one tile of row parameters ahead)
+    hipError_t e3 = hipMalloc((void**)&nx16, (want * s->ld16 + kScan16TailPadHalves) * sizeof(__half));
+    hipError_t e4 = hipMalloc((void**)&nr16, (want + kTileRows16) * sizeof(float2));
     if (e3 != hipSuccess || e4 != hipSuccess) {
       if (nx16) (void)hipFree(nx16);
       if (nr16) (void)hipFree(nr16);
@@ -286,12 +287,15 @@ int grow(ehx_space* s, uint64_t rows) {
       return fail(EHX_ENOMEM, "hipMalloc failed growing the scan copy of space '%s' to %llu rows", s->name.c_str(),
                   (unsigned long long)want);
     }
+    // the scan copy is stored in whole 256-row tiles (scan16_index): copy the tiles that hold rows
+    const uint64_t keep16 = round_up(keep, kTileRows16);
     if (keep) {
-      HIP_TRY(hipMemcpyAsync(nx16, s->dX16, keep * s->ld16 * sizeof(__half), hipMemcpyDeviceToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(nx16, s->dX16, keep16 * s->ld16 * sizeof(__half), hipMemcpyDeviceToDevice, s->stream));
       HIP_TRY(hipMemcpyAsync(nr16, s->dRowp16, keep * sizeof(float2), hipMemcpyDeviceToDevice, s->stream));
     }
-    HIP_TRY(hipMemsetAsync(nx16 + keep * s->ld16, 0, (want - keep) * s->ld16 * sizeof(__half), s->stream));
-    HIP_TRY(launch_rowp_pad(nr16, keep, want - keep, s->stream));
+    HIP_TRY(hipMemsetAsync(nx16 + keep16 * s->ld16, 0,
+                           ((want - keep16) * s->ld16 + kScan16TailPadHalves) * sizeof(__half), s->stream));
+    HIP_TRY(launch_rowp_pad(nr16, keep, want + kTileRows16 - keep, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->dX16) (void)hipFree(s->dX16);
     if (s->dRowp16) (void)hipFree(s->dRowp16);
@@ -750,26 +754,46 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
 int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k, uint64_t* d_ids,
               float* d_dist, uint32_t* d_count, bool f16, bool count_stats) {
   Engine& E = engine();
-  // Two passes (8-wave kernels): a SAMPLE pass over the first ~1/32 of the row tiles produces, per
-  // query, the k'-th best key of the sample — an upper bound of the global k'-th best — and the main
-  // pass over the remaining tiles starts from that threshold, so its slow path (candidate appends)
-  // runs ~10x less often than when every workgroup has to warm its thresholds up from +inf.
+  // A cascade of scan passes over growing row ranges (one tile per workgroup, then x8 per pass): after
+  // every pass the per-workgroup candidate lists are merged into the query's running best-64 and its
+  // k'-th best key — an upper bound of the final k'-th best — becomes the threshold the next pass starts
+  // from.  A pass over 8x the rows seen so far appends only ~7 k' candidates per query, so nearly every
+  // tile epilogue stays on its branch-free fast path; a single pass would have every workgroup warm its
+  // thresholds up from +inf (~k' ln(rows/k') appends per list).
   const uint32_t tile_rows = f16 ? kTileRows16 : kTileRows;
   const uint32_t n_tiles = (uint32_t)((s->n + tile_rows - 1) / tile_rows);
   const uint32_t lpc = f16 ? 2u : scan_lists_per_chunk();
-  uint32_t sample_tiles = 0;
-  if (lpc == 2 && (uint64_t)n_tiles * tile_rows >= 4096u * 128u) sample_tiles = (n_tiles / 32 + 255) / 256 * 256;
-  ScanPlan p = plan_scan((uint32_t)nq, n_tiles - sample_tiles, k, E.n_cus);   // main pass
-  ScanPlan ps = plan_scan((uint32_t)nq, sample_tiles, k, E.n_cus);            // sample pass
+  struct Pass {
+    uint32_t tile0;
+    ScanPlan plan;
+  };
+  std::vector<Pass> passes;
+  {
+    const ScanPlan whole = plan_scan((uint32_t)nq, n_tiles, k, E.n_cus);
+    uint32_t done = 0;
+    if (lpc == 2 && n_tiles >= 16 * whole.n_chunks) {
+      uint32_t cum = whole.n_chunks;  // pass 0: one tile per workgroup
+      while (cum * 2 < n_tiles) {
+        passes.push_back({done, plan_scan((uint32_t)nq, cum - done, k, E.n_cus)});
+        done = cum;
+        cum *= 8;
+      }
+    }
+    passes.push_back({done, plan_scan((uint32_t)nq, n_tiles - done, k, E.n_cus)});
+  }
+  ScanPlan p = passes.back().plan;  // (q_tiles, q_rows, kprime are the same for every pass)
   if (f16) {
     // the filter keeps k' = k + 22 candidates (<= 56): the certification needs the k'-th lower bound to
     // clear the k-th exact distance by the fp16 error bound, so it wants more slack than the fp32 scan
     const uint32_t kp = k + 22 > 56 ? (k + 8 > 56 ? k + 8 : 56) : k + 22;
-    p.kprime = ps.kprime = kp;
+    for (auto& ps : passes) ps.plan.kprime = kp;
+    p.kprime = kp;
   }
-  const uint32_t lists_main = p.n_chunks * lpc, lists_sample = sample_tiles ? ps.n_chunks * lpc : 0;
-  const uint32_t lists_total = lists_main + lists_sample;
-  const uint32_t grid_max = p.grid > ps.grid ? p.grid : ps.grid;
+  uint32_t lists_total = 0, grid_max = 0;  // every pass reuses the same list slots
+  for (auto& ps : passes) {
+    lists_total = std::max(lists_total, ps.plan.n_chunks * lpc);
+    grid_max = std::max(grid_max, ps.plan.grid);
+  }
   int rc;
   if ((rc = s->dQ.ensure((size_t)p.q_rows * s->ld))) return rc;
   if ((rc = s->dCand.ensure((size_t)grid_max * 512 * kCandSlots))) return rc;
@@ -781,7 +805,7 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
     HIP_TRY(hipMemset(s->dUncert, 0, 2 * sizeof(unsigned long long)));
   }
   if (f16) {
-    if ((rc = s->dQ16.ensure((size_t)p.q_rows * s->ld16))) return rc;
+    if ((rc = s->dQ16.ensure(scanq16_halves(p.q_rows, s->ld16)))) return rc;
     if ((rc = s->dQgamma.ensure(p.q_rows))) return rc;
     if ((rc = s->dQuv.ensure(p.q_rows))) return rc;
     if ((rc = s->dUflags.ensure(p.q_rows))) return rc;
@@ -856,18 +880,17 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
     hipEvent_t* pr = s->ring[s->ring_count % ehx_space::kRing];
     HIP_TRY(hipEventRecord(s->ev[1], st));
     HIP_TRY(hipEventRecord(pr[0], st));
-    if (sample_tiles) {
-      HIP_TRY(scan(ps, 0, lists_main));
-      // threshold = k'-th best of the merged sample lists
-      HIP_TRY(launch_flat_merge(s->dPart.p + (size_t)lists_main * p.kprime, (uint32_t)nq, lists_sample, p.kprime,
-                                s->dMerged.p, st, lists_total));
-      HIP_TRY(launch_set_gthr(s->dMerged.p, (uint32_t)nq, p.kprime, (unsigned long long*)s->dGthr.p, st));
+    for (size_t i = 0; i < passes.size(); ++i) {
+      const bool last = i + 1 == passes.size();
+      HIP_TRY(scan(passes[i].plan, passes[i].tile0, 0));
+      if (last) {  // (the final merge is outside the timed scan phase)
+        HIP_TRY(hipEventRecord(pr[1], st));
+        HIP_TRY(hipEventRecord(s->ev[2], st));
+        s->ring_count++;
+      }
+      HIP_TRY(launch_flat_merge(s->dPart.p, (uint32_t)nq, passes[i].plan.n_chunks * lpc, p.kprime, s->dMerged.p, st,
+                                lists_total, i > 0, last ? nullptr : (unsigned long long*)s->dGthr.p));
     }
-    HIP_TRY(scan(p, sample_tiles, 0));
-    HIP_TRY(hipEventRecord(pr[1], st));
-    HIP_TRY(hipEventRecord(s->ev[2], st));
-    s->ring_count++;
-    HIP_TRY(launch_flat_merge(s->dPart.p, (uint32_t)nq, lists_total, p.kprime, s->dMerged.p, st, lists_total));
   }
   RerankArgs r;
   r.Q = s->dQ.p;
@@ -1060,7 +1083,7 @@ int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metri
     const char* env = getenv("EHX_SCAN");  // "f32": every space scans in fp32 (A/B runs, profiling)
     const bool env_f32 = env && strcmp(env, "f32") == 0;
     s->use16 = s->params.mode == EHX_MODE_FLAT && !s->x_half && s->params.scan != EHX_SCAN_F32 && !env_f32;
-    s->ld16 = (uint32_t)round_up(dims, 32);
+    s->ld16 = (uint32_t)round_up(dims, 128);
     if (s->use16) {
       HIP_TRY(hipMalloc((void**)&s->dUnsafe, sizeof(unsigned long long)));
       HIP_TRY(hipMemset(s->dUnsafe, 0, sizeof(unsigned long long)));

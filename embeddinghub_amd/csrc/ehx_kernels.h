@@ -194,8 +194,8 @@ hipError_t launch_flat_scan8(const ScanArgs& a, hipStream_t st);  // k_flat8.hip
 
 // ---- fp16-MFMA filter scan (k_flat16.hip) ----
 struct ScanArgs16 {
-  const __half* Q;       // [q_tiles*256][ld] unit-normalised queries, binary16 (zero padded)
-  const __half* X;       // [cap][ld] scan copy: unit-normalised rows, binary16; cap % 256 == 0
+  const __half* Q;       // [q_tiles*256][ld] unit-normalised queries, binary16 (zero padded), scan16_index layout
+  const __half* X;       // [cap][ld] scan copy: unit-normalised rows, binary16, scan16_index layout; cap % 256 == 0
   const float2* rowp;    // [cap] (a_r, b_r): S = b_r*gamma_q + a_r*dot;  padding rows (0, +inf)
   const float* qgamma;   // [q_tiles*256] gamma_q
   float eps;             // accumulator start value: bound of |dot16 - true dot|
@@ -203,12 +203,34 @@ struct ScanArgs16 {
   uint64_t* cand;
   uint64_t* part;
   uint32_t n;
-  uint32_t ld;           // row stride in halves, % 32 == 0
+  uint32_t ld;           // row stride in halves, % 128 == 0 (a tile = a whole number of LDS ring revolutions)
   uint32_t tile0, n_tiles, list0, lists_total, q_tiles, n_chunks, tiles_per_chunk, kprime;
   uint32_t* err;
   unsigned long long* gthr;
   uint32_t xcd_map;
 };
+// Stage-blocked layout of the fp16 scan copy and of the fp16 query tiles: the matrix is cut into tiles of
+// 256 rows and stages of 32 columns; one (tile, stage) block is 256 rows x 64 bytes = 16 KiB, stored
+// contiguously in exactly the image the kernel wants in LDS (16-byte chunk c of row r at physical chunk
+// c ^ ((r>>2)&3)), blocks ordered [tile][stage].  A stage's DMA is then a linear 16-KiB copy: every
+// global->LDS instruction moves 1 KiB = 8 full cache lines.  Index (in halves) of element (row, col):
+__host__ __device__ inline size_t scan16_index(uint64_t row, uint32_t col, uint32_t ld16) {
+  const uint64_t tile = row >> 8;
+  const uint32_t rr = (uint32_t)(row & 255u), kt = col >> 5, cc = col & 31u;
+  const uint32_t chunk = (cc >> 3) ^ ((rr >> 2) & 3u);
+  return ((size_t)(tile * (ld16 >> 5) + kt) * 256u + rr) * 32u + chunk * 8u + (cc & 7u);
+}
+// The fp16 query tiles use the same blocks, [q_tile][stage], with stages 0..2 of every tile stored once more
+// after its last stage (the kernel's DMA runs three stages ahead and wraps into the next row tile without
+// re-basing its query pointer mid-tile): (ld16/32 + 3) blocks per query tile.
+__host__ __device__ inline size_t scanq16_index(uint64_t row, uint32_t stage, uint32_t cc, uint32_t ld16) {
+  const uint64_t tile = row >> 8;
+  const uint32_t rr = (uint32_t)(row & 255u);
+  const uint32_t chunk = (cc >> 3) ^ ((rr >> 2) & 3u);
+  return ((size_t)(tile * ((ld16 >> 5) + 3u) + stage) * 256u + rr) * 32u + chunk * 8u + (cc & 7u);
+}
+inline size_t scanq16_halves(uint32_t q_rows, uint32_t ld16) { return (size_t)(q_rows >> 8) * ((ld16 >> 5) + 3u) * 256u * 32u; }
+constexpr size_t kScan16TailPadHalves = 3u * 256u * 32u;  // X16 tail padding: three stage blocks (DMA read-ahead)
 size_t scan16_lds_bytes();
 hipError_t launch_flat_scan16(const ScanArgs16& a, hipStream_t st);
 // bound of |<fp16(q^), fp16(x^)> accumulated in fp32 - <q^, x^>| for unit vectors of `dims` elements
@@ -228,8 +250,10 @@ hipError_t launch_set_gthr(const uint64_t* merged, uint32_t nq, uint32_t kprime,
 
 // one wave per query: k-way merge of the per-chunk sorted key lists -> top-kprime keys
 // (merges `n_chunks` consecutive lists of each query; a query's lists are `lists_stride` apart)
+// seed: start from the keys already in `merged` (earlier passes); gthr (optional): publish the k'-th best
 hipError_t launch_flat_merge(const uint64_t* part, uint32_t nq, uint32_t n_chunks, uint32_t kprime,
-                             uint64_t* merged /*[nq][64]*/, hipStream_t st, uint32_t lists_stride);
+                             uint64_t* merged /*[nq][64]*/, hipStream_t st, uint32_t lists_stride, bool seed = false,
+                             unsigned long long* gthr = nullptr);
 
 // canonical (oracle-order) distances of the merged candidates, sort by (dist, id), emit top-k.
 struct RerankArgs {

@@ -463,13 +463,17 @@ hipError_t launch_flat_scan4(const ScanArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 // merge of the per-chunk sorted key lists: one wave per query
 // ---------------------------------------------------------------------------------------------
+// seed != 0: `merged` already holds the 64 best keys of earlier passes and is merged with the new lists.
+// gthr != nullptr: also publish the k'-th best key so far (an upper bound of the query's final k'-th
+// best) as the threshold the next scan pass starts from.
 __global__ __launch_bounds__(64) void flat_merge_kernel(const uint64_t* __restrict__ part, uint32_t n_chunks,
                                                         uint32_t kprime, uint64_t* __restrict__ merged,
-                                                        uint32_t lists_stride) {
+                                                        uint32_t lists_stride, uint32_t seed,
+                                                        unsigned long long* __restrict__ gthr) {
   const int lane = threadIdx.x;
   const uint32_t q = blockIdx.x;
   const uint64_t* p = part + (size_t)q * lists_stride * kprime;
-  uint64_t best = kKeyInf;
+  uint64_t best = seed ? merged[(size_t)q * 64 + lane] : kKeyInf;
   for (uint32_t c = 0; c < n_chunks; ++c) {
     const uint64_t v = lane < (int)kprime ? p[(size_t)c * kprime + lane] : kKeyInf;  // ascending
     const uint64_t rv = __shfl(v, 63 - lane, 64);                                     // descending
@@ -477,6 +481,7 @@ __global__ __launch_bounds__(64) void flat_merge_kernel(const uint64_t* __restri
     best = wave_bitonic_merge64(m, lane);
   }
   merged[(size_t)q * 64 + lane] = best;
+  if (gthr && lane == (int)kprime - 1) gthr[q] = best;
 }
 
 // after the sample pass: the k'-th best key of the merged sample lists is an upper bound of the
@@ -493,8 +498,10 @@ hipError_t launch_set_gthr(const uint64_t* merged, uint32_t nq, uint32_t kprime,
 }
 
 hipError_t launch_flat_merge(const uint64_t* part, uint32_t nq, uint32_t n_chunks, uint32_t kprime,
-                             uint64_t* merged, hipStream_t st, uint32_t lists_stride) {
-  hipLaunchKernelGGL(flat_merge_kernel, dim3(nq), dim3(64), 0, st, part, n_chunks, kprime, merged, lists_stride);
+                             uint64_t* merged, hipStream_t st, uint32_t lists_stride, bool seed,
+                             unsigned long long* gthr) {
+  hipLaunchKernelGGL(flat_merge_kernel, dim3(nq), dim3(64), 0, st, part, n_chunks, kprime, merged, lists_stride,
+                     seed ? 1u : 0u, gthr);
   return hipGetLastError();
 }
 

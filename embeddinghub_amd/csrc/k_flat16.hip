@@ -72,6 +72,13 @@ __device__ __forceinline__ f16x8 frag16(const char* p) {
   f16x8 v = {1, 2, 3, 4, 5, 6, 7, 8};
   asm volatile("" : "+v"(v));
   return v;
+#elif (EHX_ABL & 128)
+  // issue the read, never use its result: the MFMAs run on constants
+  f16x8 r = *(const volatile f16x8*)p;
+  asm volatile("" ::"v"(r));
+  f16x8 v = {1, 2, 3, 4, 5, 6, 7, 8};
+  asm volatile("" : "+v"(v));
+  return v;
 #else
   return *(const f16x8*)p;
 #endif
@@ -140,56 +147,45 @@ __global__ __launch_bounds__(kThreads16, 2) void flat_scan16_kernel(const ScanAr
   if (tile_end > a.tile0 + a.n_tiles) tile_end = a.tile0 + a.n_tiles;
   const uint32_t my_tiles = tile_end > tile_begin ? tile_end - tile_begin : 0u;
   const uint32_t ktiles = a.ld / kBK16;
-  const uint32_t total_steps = my_tiles * ktiles;
 
-  // ---- DMA duty of this wave: X pieces w, w+8 and Q pieces w, w+8 of the 16 + 16 of a stage.
-  // piece `ins` = 16 stage rows x 64 B; lane L -> row 16*ins + (L>>2), physical chunk p = L&3 holds
-  // logical chunk p ^ ((row>>2)&3) = p ^ ((L>>4)&3): one lane offset serves every piece.
-  const uint32_t row_bytes = a.ld * 2u;
-  const uint32_t lane_off = (uint32_t)(lane >> 2) * row_bytes + (((uint32_t)lane & 3u) ^ (((uint32_t)lane >> 4) & 3u)) * 16u;
-  const uint32_t piece_stride = 16u * row_bytes;
-  const uint32_t lane_off8 = lane_off + 8u * piece_stride;  // the wave's second piece of a stage: rows +128
-  const size_t tile_stride = (size_t)kTileRows16 * row_bytes;
-  // uniform source pointers of the next stage to issue: advanced by 64 B per stage, X hops to the next tile
-  const char* xsrc = (const char*)a.X + (size_t)tile_begin * tile_stride + (size_t)w * piece_stride;
-  const char* qsrc = (const char*)a.Q + (size_t)qt * kTileQ * row_bytes + (size_t)w * piece_stride;
+  // ---- DMA duty of this wave: 1-KiB pieces w and w+8 of the X stage block and of the Q stage block.
+  // The blocks are stored in HBM in the LDS image (scan16_index), so a piece is a linear copy: lane L
+  // moves 16 bytes at piece*1024 + L*16.  Sources are uniform 64-bit pointers (SGPR pair) advanced by one
+  // 16-KiB block per stage: X runs linearly through its [tile][stage] blocks — past the end of the chunk
+  // for the three stages issued ahead at the very end (valid memory: the next chunk's tiles or the
+  // buffer's tail padding, never read from LDS) — and Q restarts at stage 3 of its tile every tile, its
+  // tile being stored with stages 0..2 repeated after the last one.
+  const uint32_t voff = (uint32_t)lane * 16u;
+  const uint32_t voff8 = voff + 8u * 1024u;
+  const size_t tile_bytes = (size_t)ktiles * kXStage16;
+  const char* xsrc = (const char*)a.X + (size_t)tile_begin * tile_bytes + (size_t)w * 1024;
+  const char* qbase = (const char*)a.Q + (size_t)qt * ((size_t)(ktiles + 3) * kQStage16) + (size_t)w * 1024;
+  const char* qsrc = qbase;
   const char* rsrc = (const char*)(a.rowp + (size_t)tile_begin * kTileRows16) + (size_t)(w & 1) * 1024;
-  const size_t x_wrap = tile_stride - (size_t)(ktiles - 1) * kRowB16;  // last stage of a tile -> first of the next
-  const uint32_t q_wrap = (ktiles - 1) * kRowB16;
-  uint32_t pre_kt = 0, pre_t = 0, pre_buf = 0, issued = 0;
+  const uint32_t xdst = kXOff16 + (uint32_t)w * 1024u;  // + slot*16384 (+8192 for the second piece)
+  const uint32_t qdst = kQOff16 + (uint32_t)w * 1024u;
+  const uint32_t rdst = kRowpOff16 + (uint32_t)(w & 1) * 1024u;  // + (tile&3)*2048
 
-  // one stage of this wave's DMA duty, in four parts so the main loop can spread them between MFMAs
-#define EHX_ISSUE_A()                                                                                      \
+  // one 1-KiB piece: M0 = LDS byte address of the piece, source = uniform base + per-lane offset
+#define EHX_DMA(DST_BASE, DST_IMM, VOFF, SRC)                                                              \
   do {                                                                                                     \
-    if (!ABL16_NO_DMA) {                                                                                   \
-      if (pre_kt == 0 && w < 2) /* the tile's row parameters (2 KiB): first = oldest piece of the stage */ \
-        glds16_8(rsrc + lane * 16, smem + kRowpOff16 + (pre_t & 3u) * 2048u + w * 1024);                   \
-      glds16_8(xsrc + lane_off, smem + kXOff16 + pre_buf * kXStage16 + w * 1024);                          \
-    }                                                                                                      \
+    if (!ABL16_NO_DMA)                                                                                     \
+      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"                     \
+                   :                                                                                       \
+                   : "s"(DST_BASE), "n"(DST_IMM), "v"(VOFF), "s"(SRC)                                      \
+                   : "memory", "scc");                                                                     \
   } while (0)
-#define EHX_ISSUE_B()                                                                                      \
-  do {                                                                                                     \
-    if (!ABL16_NO_DMA) glds16_8(qsrc + lane_off, smem + kQOff16 + pre_buf * kQStage16 + w * 1024);         \
-  } while (0)
-#define EHX_ISSUE_C()                                                                                      \
-  do {                                                                                                     \
-    if (!ABL16_NO_DMA) glds16_8(xsrc + lane_off8, smem + kXOff16 + pre_buf * kXStage16 + (w + 8) * 1024);  \
-  } while (0)
-#define EHX_ISSUE_D()                                                                                      \
-  do {                                                                                                     \
-    if (!ABL16_NO_DMA) glds16_8(qsrc + lane_off8, smem + kQOff16 + pre_buf * kQStage16 + (w + 8) * 1024);  \
-    if (++pre_kt == ktiles) {                                                                              \
-      pre_kt = 0;                                                                                          \
-      ++pre_t;                                                                                             \
-      xsrc += x_wrap;                                                                                      \
-      qsrc -= q_wrap;                                                                                      \
-      rsrc += kTileRows16 * 8;                                                                             \
-    } else {                                                                                               \
-      xsrc += kRowB16;                                                                                     \
-      qsrc += kRowB16;                                                                                     \
-    }                                                                                                      \
-    pre_buf = (pre_buf + 1) & (kRing16 - 1);                                                               \
-    ++issued;                                                                                              \
+  // this wave's four pieces of the next stage, into ring slot SLOT
+#define EHX_DMA_X0(SLOT) EHX_DMA(xdst, (SLOT) * 16384, voff, xsrc)
+#define EHX_DMA_Q0(SLOT) EHX_DMA(qdst, (SLOT) * 16384, voff, qsrc)
+#define EHX_DMA_X1(SLOT) EHX_DMA(xdst, (SLOT) * 16384 + 8192, voff8, xsrc)
+#define EHX_DMA_Q1(SLOT)                              \
+  do {                                                \
+    EHX_DMA(qdst, (SLOT) * 16384 + 8192, voff8, qsrc); \
+    if (!(EHX_ABL & 64)) {                            \
+      xsrc += kXStage16;                              \
+      qsrc += kQStage16;                              \
+    }                                                 \
   } while (0)
 
   // ---- fragment read offsets: k-step j (0/1) of a stage row is its logical chunks 2j (lanes 0-31) and
@@ -294,73 +290,83 @@ __global__ __launch_bounds__(kThreads16, 2) void flat_scan16_kernel(const ScanAr
     }
   };
 
-  // ---- prologue: every wave issues its share of the first (up to) three stages ----
-  while (issued < total_steps && issued < kRing16 - 1) {
-    EHX_ISSUE_A();
-    EHX_ISSUE_B();
-    EHX_ISSUE_C();
-    EHX_ISSUE_D();
-  }
-  if (issued >= 3) wait_vmcnt<8>();       // stage 0 landed <=> at most stages 1, 2 in flight
-  else if (issued == 2) wait_vmcnt<4>();
-  else wait_vmcnt<0>();
-  __syncthreads();  // B_0 (also publishes the state init)
+  __syncthreads();  // state init visible
+  if (my_tiles > 0) {  // (a chunk past the end of the pass has nothing to scan and must not touch memory)
+  // ---- prologue: row parameters of tile 0, stages 0..2 into ring slots 0..2 ----
+  if (w < 2) EHX_DMA(rdst, 0, voff, rsrc);
+  EHX_DMA_X0(0); EHX_DMA_Q0(0); EHX_DMA_X1(0); EHX_DMA_Q1(0);
+  EHX_DMA_X0(1); EHX_DMA_Q0(1); EHX_DMA_X1(1); EHX_DMA_Q1(1);
+  EHX_DMA_X0(2); EHX_DMA_Q0(2); EHX_DMA_X1(2); EHX_DMA_Q1(2);
+  wait_vmcnt<8>();  // stage 0 (and the row parameters, older) landed <=> at most stages 1, 2 in flight
+  lds_barrier();  // B_0
 
-  // Fragments: the four row fragments A[rb] are replaced in place, each right after its two MFMAs of a
-  // k-step; the two query fragments alternate between B0 (k-step 0) and B1 (k-step 1).
-  f16x8 fa[4], fb0[2], fb1[2];
+  // Fragments are double-buffered: set 0 feeds k-step 0, set 1 feeds k-step 1; the six fragment reads of
+  // the next k-step are issued ahead of the current k-step's 8 MFMAs and land in their shadow.
+  f16x8 fa0[4], fb0[2], fa1[4], fb1[2];
 #pragma unroll
-  for (int rb = 0; rb < 4; ++rb) fa[rb] = frag16(smem + a_off0 + rb * 2048);
+  for (int rb = 0; rb < 4; ++rb) fa0[rb] = frag16(smem + a_off0 + rb * 2048);
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) fb0[cb] = frag16(smem + b_off0 + cb * 2048);
 
-  uint32_t kt = 0, t = 0, buf = 0;
-  for (uint32_t step = 0; step < total_steps; ++step) {
-    const uint32_t nbuf = (buf + 1) & (kRing16 - 1);
-    const char* sb = smem + buf * kXStage16;    // (X and Q stages have the same size)
-    const char* sn = smem + nbuf * kXStage16;
-    const bool dma = issued < total_steps;  // stage step+3: its ring slot was released by the previous barrier
-    // ---- k-step 0 of stage `step`: MFMAs on (A, B0); A and B1 move on to k-step 1 ----
-    fb1[0] = frag16(sb + b_off1);
-    fb1[1] = frag16(sb + b_off1 + 2048);
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      acc[rb][0] = EHX_MFMA16(fa[rb], fb0[0], acc[rb][0]);
-      acc[rb][1] = EHX_MFMA16(fa[rb], fb0[1], acc[rb][1]);
-      fa[rb] = frag16(sb + a_off1 + rb * 2048);
-      if (dma) {
-        if (rb == 0) EHX_ISSUE_A();
-        if (rb == 1) EHX_ISSUE_B();
-        if (rb == 2) EHX_ISSUE_C();
-        if (rb == 3) EHX_ISSUE_D();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- stage barrier: stage step+1 landed (own pieces counted: only the two younger stages may still
-    // be in flight) and visible; every wave is done reading stage `step` ----
-    if (step + 1 < total_steps) {
-      if (!ABL16_NO_VMWAIT) {
-        const uint32_t younger = issued - (step + 2);  // stages issued beyond step+1: 2, 1 or 0
-        if (younger >= 2) wait_vmcnt<8>();
-        else if (younger == 1) wait_vmcnt<4>();
-        else wait_vmcnt<0>();
-      }
-      if (!ABL16_NO_BARRIER) lds_barrier();
-    }
-    // ---- k-step 1: MFMAs on (A, B1); A and B0 move on to k-step 0 of the next stage (garbage after the
-    // last stage: never used) ----
-    fb0[0] = frag16(sn + b_off0);
-    fb0[1] = frag16(sn + b_off0 + 2048);
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      acc[rb][0] = EHX_MFMA16(fa[rb], fb1[0], acc[rb][0]);
-      acc[rb][1] = EHX_MFMA16(fa[rb], fb1[1], acc[rb][1]);
-      fa[rb] = frag16(sn + a_off0 + rb * 2048);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    buf = nbuf;
-    if (++kt == ktiles) {
-      kt = 0;
+  // One stage, ring slot S (compile-time): no branches, no address arithmetic — fragment reads are
+  // base register + immediate, the DMA of stage +3 goes to slot S+3, one counted wait + one barrier.
+#define EHX_STAGE16(S)                                                                                   \
+  do {                                                                                                   \
+    constexpr uint32_t so = (uint32_t)(S) * kXStage16, sn = (uint32_t)(((S) + 1) & 3) * kXStage16;       \
+    constexpr int sd = ((S) + 3) & 3;                                                                    \
+    /* k-step 0: read set 1 (k-step 1 of this stage), 8 MFMAs on set 0, DMA pieces in between */       \
+    fb1[0] = frag16(smem + b_off1 + so);                                                                 \
+    fb1[1] = frag16(smem + b_off1 + so + 2048);                                                          \
+    _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) fa1[rb] = frag16(smem + a_off1 + so + rb * 2048);   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    acc[0][0] = EHX_MFMA16(fa0[0], fb0[0], acc[0][0]);                                                   \
+    acc[0][1] = EHX_MFMA16(fa0[0], fb0[1], acc[0][1]);                                                   \
+    EHX_DMA_X0(sd);                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    acc[1][0] = EHX_MFMA16(fa0[1], fb0[0], acc[1][0]);                                                   \
+    acc[1][1] = EHX_MFMA16(fa0[1], fb0[1], acc[1][1]);                                                   \
+    EHX_DMA_Q0(sd);                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    acc[2][0] = EHX_MFMA16(fa0[2], fb0[0], acc[2][0]);                                                   \
+    acc[2][1] = EHX_MFMA16(fa0[2], fb0[1], acc[2][1]);                                                   \
+    EHX_DMA_X1(sd);                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    acc[3][0] = EHX_MFMA16(fa0[3], fb0[0], acc[3][0]);                                                   \
+    acc[3][1] = EHX_MFMA16(fa0[3], fb0[1], acc[3][1]);                                                   \
+    EHX_DMA_Q1(sd);                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    /* stage barrier: the next stage landed (own pieces counted: only the two younger stages may still   \
+       be in flight) and is visible; every wave is done reading this stage */                            \
+    if (!ABL16_NO_VMWAIT) wait_vmcnt<8>();                                                               \
+    if (!ABL16_NO_BARRIER) lds_barrier();                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    /* k-step 1: read set 0 of the next stage, 8 MFMAs on set 1 */                                       \
+    fb0[0] = frag16(smem + b_off0 + sn);                                                                 \
+    fb0[1] = frag16(smem + b_off0 + sn + 2048);                                                          \
+    _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) fa0[rb] = frag16(smem + a_off0 + sn + rb * 2048);   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) {                                                   \
+      acc[rb][0] = EHX_MFMA16(fa1[rb], fb1[0], acc[rb][0]);                                              \
+      acc[rb][1] = EHX_MFMA16(fa1[rb], fb1[1], acc[rb][1]);                                              \
+    }                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  } while (0)
+
+  // One flat loop over groups of four stages (= one revolution of the ring; ld % 128 == 0 makes a tile a
+  // whole number of them); the tile boundary work hangs off a counter inside it.
+  const uint32_t kquads = ktiles >> 2;
+  const uint32_t total_quads = my_tiles * kquads;
+  // row parameters of tile 1 (consumed by its epilogue, a whole tile from now)
+  rsrc += kTileRows16 * 8;
+  if (w < 2) EHX_DMA(rdst, 2048, voff, rsrc);
+  uint32_t kq = 0, t = 0;
+  for (uint32_t q = 0; q < total_quads; ++q) {
+    EHX_STAGE16(0);
+    EHX_STAGE16(1);
+    EHX_STAGE16(2);
+    EHX_STAGE16(3);
+    if (++kq == kquads) {
+      kq = 0;
       if (!ABL16_NO_EPILOGUE) epilogue(t);
       else {
         for (int rb = 0; rb < 4; ++rb)
@@ -373,12 +379,23 @@ __global__ __launch_bounds__(kThreads16, 2) void flat_scan16_kernel(const ScanAr
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[rb][cb][r] = acc0;
       ++t;
+      // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
+      // parameters of the tile after it (past the last tile: the array's tail padding)
+      qsrc = qbase + 3 * kQStage16;
+      rsrc += kTileRows16 * 8;
+      if (w < 2) {
+        const uint32_t rd = rdst + ((t + 1) & 3u) * 2048u;
+        EHX_DMA(rd, 0, voff, rsrc);
+      }
     }
   }
-#undef EHX_ISSUE_A
-#undef EHX_ISSUE_B
-#undef EHX_ISSUE_C
-#undef EHX_ISSUE_D
+  }  // my_tiles > 0
+#undef EHX_STAGE16
+#undef EHX_DMA_X0
+#undef EHX_DMA_Q0
+#undef EHX_DMA_X1
+#undef EHX_DMA_Q1
+#undef EHX_DMA
 
   // ---- final: sort this wave's 64 lists and publish them: part[q][chunk*2 + wr][k'] ----
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

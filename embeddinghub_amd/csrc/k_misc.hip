@@ -118,8 +118,7 @@ __global__ __launch_bounds__(256) void make_scan16_kernel(const float* __restric
   const bool ok = norm_ok(ss);
   const float nr = ok ? __builtin_sqrtf(ss) : 0.0f;
   const float inv = nr > 0.0f ? 1.0f / nr : 0.0f;
-  __half* o = X16 + r * ld16;
-  for (uint32_t c = lane; c < ld16; c += 64) o[c] = __float2half_rn(c < dims ? x[c] * inv : 0.0f);
+  for (uint32_t c = lane; c < ld16; c += 64) X16[scan16_index(r, c, ld16)] = __float2half_rn(c < dims ? x[c] * inv : 0.0f);
   if (lane == 0) {
     float2 p;
     if (!ok) {
@@ -149,9 +148,14 @@ __global__ __launch_bounds__(64) void prep_queries16_kernel(const float* __restr
                                                             float* __restrict__ qgamma, float2* __restrict__ quv) {
   const uint32_t row = blockIdx.x;
   const int lane = threadIdx.x;
-  __half* out = Q16 + (size_t)row * ld16;
+  const uint32_t kts = ld16 >> 5;
+  auto put = [&](uint32_t c, float v) {  // stages 0..2 are stored a second time after the last stage
+    const __half hv = __float2half_rn(v);
+    Q16[scanq16_index(row, c >> 5, c & 31u, ld16)] = hv;
+    if (c < 96) Q16[scanq16_index(row, kts + (c >> 5), c & 31u, ld16)] = hv;
+  };
   if (row >= nq) {
-    for (uint32_t c = lane; c < ld16; c += 64) out[c] = __float2half_rn(0.0f);
+    for (uint32_t c = lane; c < ld16; c += 64) put(c, 0.0f);
     if (lane == 0) {
       qgamma[row] = 1.0f;
       quv[row] = make_float2(1.0f, 0.0f);
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(64) void prep_queries16_kernel(const float* __restr
   const bool ok = norm_ok(ss);
   const float beta = ok ? __builtin_sqrtf(ss) : 0.0f;
   const float inv = beta > 0.0f ? 1.0f / beta : 0.0f;
-  for (uint32_t c = lane; c < ld16; c += 64) out[c] = __float2half_rn(c < dims ? in[c] * inv : 0.0f);
+  for (uint32_t c = lane; c < ld16; c += 64) put(c, c < dims ? in[c] * inv : 0.0f);
   if (lane == 0) {
     float g = 1.0f, u = 1.0f, v = 0.0f;
     if (beta > 0.0f) {
