@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense (no sparsity)
 METRIC_NAME = "kNN queries/sec at recall@10>=0.95, 10Mx768 cosine, batch=1024"
 
 
@@ -40,6 +41,10 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--rows-dtype", choices=["f32", "f16"], default="f32",
                     help="row storage in HBM (f16 = BASELINE configs[5] storage; arithmetic stays fp32)")
+    ap.add_argument("--scan", choices=["auto", "f32"], default="auto",
+                    help="scan engine of the timed run: auto = fp16 matrix-core filter + certified fp32 re-rank "
+                         "(default), f32 = fp32 matrix-core scan only; results are identical")
+    ap.add_argument("--no-f32-engine", action="store_true", help="skip the short A/B leg on the fp32-only engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=16000)
     ap.add_argument("--cpu-sample-queries", type=int, default=256)
@@ -134,52 +139,91 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    space.stats_reset()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if G > 1:
-        dist.barrier()
+    def timed(steps, warmup):
+        """warmup untimed steps, then exactly `steps` timed ones; returns (seconds, stats)"""
+        for i in range(warmup):
+            step(i % n_batches)
+        barrier()
+        space.stats_reset()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step((warmup + i) % n_batches)
         torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if G > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if G > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if G > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, space.stats()  # stats: per-batch scan-phase durations from HIP events on the launch stream
 
-    st = space.stats()  # per-launch scan-kernel durations from HIP events on the launch stream
+    f16_rows = args.rows_dtype == "f16"
+    filt = args.scan == "auto" and not f16_rows and os.environ.get("EHX_SCAN", "") != "f32"
+    if not filt and not f16_rows:
+        space.set_scan(ehx.SCAN_F32)
+    elapsed, st = timed(args.steps, args.warmup)
     scan_ms = st["scan_ms_mean"]
-    flops_per_launch = 2.0 * B * shard * d                    # 2*B*N*d per batch (this shard)
-    achieved = flops_per_launch / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+    flops_per_batch = 2.0 * B * shard * d                    # SURVEY §8d: 2*B*N*d per batch (this shard)
+    achieved = flops_per_batch / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+    peak = MFMA_F16_PEAK_TFLOPS if filt else MFMA_F32_PEAK_TFLOPS
+    row_bytes = 2 if (filt or f16_rows) else 4                # bytes per element the scan streams from HBM
+    algo_bytes = shard * d * row_bytes + B * d * 4 + B * k * 12
+    traffic = None  # measured HBM bytes per batch (PMC pass, gfx950-corrected) when this exact workload was profiled
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            key = "%s:%dx%d:b%d:g%d" % ("filter" if filt else "f32", args.rows, d, B, G)
+            traffic = json.load(f).get(key)
+    except (OSError, ValueError):
+        pass
+    engine = ("fp16 matrix-core filter scan (lower-bound scores, k'=k+22 candidates) + canonical fp32 re-rank with "
+              "per-query certification; uncertified queries re-scanned in fp32" if filt else
+              "fp32 matrix-core scan + canonical fp32 re-rank")
     out = {
         "metric": METRIC_NAME, "value": round(args.steps * B / elapsed, 1), "unit": "queries/s",
         "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f16 filter -> f32 exact results" if filt else "f32", "data": "synthetic",
         "config": {
-            "workload": "%dx%d cosine (EHX-GAUSS-1 seed %d), batch=%d, k=%d; exhaustive fp32 MFMA scan + "
-                        "canonical re-rank = exact kNN (recall@10 = 1.0 vs exhaustive by construction)" % (
-                            args.rows, d, ehx.SEED_CORPUS, B, k),
-            "rows_total": args.rows, "rows_per_gpu": shard, "rows_dtype": args.rows_dtype, "dims": d, "batch": B, "k": k, "path": "flat",
+            "workload": "%dx%d cosine (EHX-GAUSS-1 seed %d), batch=%d, k=%d; exhaustive scan = exact kNN "
+                        "(recall@10 = 1.0 vs exhaustive by construction; ids and distances bit-identical to the "
+                        "fp32 oracle)" % (args.rows, d, ehx.SEED_CORPUS, B, k),
+            "engine": engine,
+            "rows_total": args.rows, "rows_per_gpu": shard, "rows_dtype": args.rows_dtype, "dims": d, "batch": B,
+            "k": k, "path": "flat",
             "parallelism": "row-shard x%d + all-gather top-k merge" % G if G > 1 else "single GPU",
             "fill_seconds": round(t_fill, 2),
         },
         "recall_at_10": 1.0,
         "roofline": {
-            "bound": "mfma", "kernel": "flat_scan8_kernel (sample-pass launch + main-pass launch per batch)",
-            "achieved": round(achieved, 2),
-            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-            "traffic": None,  # PMC pass (profiles/r01_e_*): FETCH_SIZE x2 (gfx950 correction) = 68 GB/batch vs 30.7 GB algorithmic
-            "kernel_ms": round(scan_ms, 4), "launches_timed": int(st["scan_launches"]),
-            "flops_per_launch": flops_per_launch,
-            "hbm_frac_of_8TBps": round((shard * d * (2 if args.rows_dtype == "f16" else 4) + B * d * 4 + B * k * 12) / (scan_ms * 1e-3) / 8e12, 4) if scan_ms > 0 else None,
+            "bound": "mfma",
+            "kernel": ("flat_scan16_kernel: the cascade of scan passes of one batch (launches + inter-pass merges)"
+                       if filt else "flat_scan8_kernel: the scan passes of one batch"),
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "traffic": traffic,
+            "kernel_ms": round(scan_ms, 4), "batches_timed": int(st["scan_launches"]),
+            "flops_per_batch": flops_per_batch, "algorithmic_bytes_per_batch": algo_bytes,
+            "hbm_frac_of_8TBps": round(algo_bytes / (scan_ms * 1e-3) / 8e12, 4) if scan_ms > 0 else None,
+            "note": ("fp16 MFMA on real data is power-limited on this part: scripts/ubench/mfma_f16_data.hip "
+                     "sustains 1.27-1.65 PFLOP/s on unit-vector data vs 2.46 on constants "
+                     "(profiles/r01_g_mfma_data_ubench.txt)") if filt else None,
         },
         "n_uncertified": int(st["n_uncertified"]),
+        "filter_fallback_queries": int(st["n_filter_fallback"]),
     }
+    if filt and not args.no_f32_engine:
+        # A/B leg: the same space, same queries, fp32-only engine (identical results by construction)
+        space.set_scan(ehx.SCAN_F32)
+        el2, st2 = timed(2, 1)
+        ms2 = st2["scan_ms_mean"]
+        ach2 = flops_per_batch / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0
+        out["f32_scan_engine"] = {
+            "value": round(2 * B / el2, 1), "unit": "queries/s", "ms_per_step": round(el2 / 2 * 1e3, 3),
+            "kernel_ms": round(ms2, 4), "achieved": round(ach2, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+            "frac": round(ach2 / MFMA_F32_PEAK_TFLOPS, 4), "n_uncertified": int(st2["n_uncertified"]),
+        }
+        space.set_scan(ehx.SCAN_AUTO)
     if rank == 0 and G == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

@@ -58,6 +58,7 @@ SYMBOLS = {
     "ehx_space_dims": (C.c_int, [_vp, _u32p]),
     "ehx_space_reserve": (C.c_int, [_vp, C.c_uint64]),
     "ehx_space_set_ef": (C.c_int, [_vp, C.c_uint32]),
+    "ehx_space_set_scan": (C.c_int, [_vp, C.c_uint32]),
     "ehx_set": (C.c_int, [_vp, C.c_char_p, C.c_size_t, _f32p]),
     "ehx_set_batch": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), _f32p]),
     "ehx_get": (C.c_int, [_vp, C.c_char_p, C.c_size_t, _f32p]),

@@ -275,9 +275,9 @@ int grow(ehx_space* s, uint64_t rows) {
   if (s->use16) {
     __half* nx16 = nullptr;
     float2* nr16 = nullptr;
-    // (+ tail padding: the scan's DMA reads three stage blocks / one tile of row parameters ahead)
+    // (+ tail padding: the scan's DMA reads three stage blocks / two tiles of row parameters ahead)
     hipError_t e3 = hipMalloc((void**)&nx16, (want * s->ld16 + kScan16TailPadHalves) * sizeof(__half));
-    hipError_t e4 = hipMalloc((void**)&nr16, (want + kTileRows16) * sizeof(float2));
+    hipError_t e4 = hipMalloc((void**)&nr16, (want + 2 * kTileRows16) * sizeof(float2));
     if (e3 != hipSuccess || e4 != hipSuccess) {
       if (nx16) (void)hipFree(nx16);
       if (nr16) (void)hipFree(nr16);
@@ -295,7 +295,7 @@ int grow(ehx_space* s, uint64_t rows) {
     }
     HIP_TRY(hipMemsetAsync(nx16 + keep16 * s->ld16, 0,
                            ((want - keep16) * s->ld16 + kScan16TailPadHalves) * sizeof(__half), s->stream));
-    HIP_TRY(launch_rowp_pad(nr16, keep, want + kTileRows16 - keep, s->stream));
+    HIP_TRY(launch_rowp_pad(nr16, keep, want + 2 * kTileRows16 - keep, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->dX16) (void)hipFree(s->dX16);
     if (s->dRowp16) (void)hipFree(s->dRowp16);
@@ -1155,6 +1155,16 @@ int ehx_space_set_ef(ehx_space* s, uint32_t ef) {
   if (!valid_space(s) || ef == 0) return fail(EHX_EINVAL, "bad argument");
   std::unique_lock<std::shared_mutex> wl(s->mu);
   s->params.ef = ef;
+  return EHX_OK;
+}
+
+int ehx_space_set_scan(ehx_space* s, uint32_t scan) {
+  if (!valid_space(s) || scan > EHX_SCAN_F32) return fail(EHX_EINVAL, "bad argument");
+  std::unique_lock<std::shared_mutex> wl(s->mu);
+  if (scan == EHX_SCAN_AUTO && !s->dX16)
+    return fail(EHX_EUNSUPPORTED, "space '%s' was created without the fp16 scan copy", s->name.c_str());
+  s->params.scan = scan;
+  s->use16 = scan == EHX_SCAN_AUTO;
   return EHX_OK;
 }
 

@@ -46,9 +46,14 @@ constexpr uint32_t kBK16 = 32;                                       // halves p
 constexpr uint32_t kRowB16 = 64;                                     // bytes per stage row
 constexpr uint32_t kXStage16 = kTileRows16 * kRowB16;                // 16 KiB
 constexpr uint32_t kQStage16 = kTileQ * kRowB16;                     // 16 KiB
+#if (EHX_ABL & 1024)
+constexpr uint32_t kQOff16 = 0;
+constexpr uint32_t kXOff16 = kRing16 * kQStage16;
+#else
 constexpr uint32_t kXOff16 = 0;
 constexpr uint32_t kQOff16 = kRing16 * kXStage16;                    // 64 KiB
-constexpr uint32_t kThrKeyOff16 = kQOff16 + kRing16 * kQStage16;     // u64 thr_key[512]
+#endif
+constexpr uint32_t kThrKeyOff16 = 2 * kRing16 * kQStage16;            // u64 thr_key[512]
 constexpr uint32_t kThrFOff16 = kThrKeyOff16 + kLists8 * 8;          // f32 thr_f[512]
 constexpr uint32_t kCntOff16 = kThrFOff16 + kLists8 * 4;             // i32 cnt[512]
 constexpr uint32_t kRowpOff16 = kCntOff16 + kLists8 * 4;             // float2 rowp_lds[4][256]
@@ -84,6 +89,21 @@ __device__ __forceinline__ f16x8 frag16(const char* p) {
 #endif
 }
 
+__device__ __forceinline__ f16x8 frag16_const() {
+  f16x8 v = {1, 2, 3, 4, 5, 6, 7, 8};
+  asm volatile("" : "+v"(v));
+  return v;
+}
+#if (EHX_ABL & 256)
+#define frag16a(P) frag16_const()
+#else
+#define frag16a(P) frag16(P)
+#endif
+#if (EHX_ABL & 512)
+#define frag16b(P) frag16_const()
+#else
+#define frag16b(P) frag16(P)
+#endif
 #if (EHX_ABL & 16)
 __device__ __forceinline__ f32x16 EHX_MFMA16(f16x8 a, f16x8 b, f32x16 c) {
   asm volatile("" : "+v"(c) : "v"(a), "v"(b));
@@ -304,9 +324,9 @@ __global__ __launch_bounds__(kThreads16, 2) void flat_scan16_kernel(const ScanAr
   // the next k-step are issued ahead of the current k-step's 8 MFMAs and land in their shadow.
   f16x8 fa0[4], fb0[2], fa1[4], fb1[2];
 #pragma unroll
-  for (int rb = 0; rb < 4; ++rb) fa0[rb] = frag16(smem + a_off0 + rb * 2048);
+  for (int rb = 0; rb < 4; ++rb) fa0[rb] = frag16a(smem + a_off0 + rb * 2048);
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) fb0[cb] = frag16(smem + b_off0 + cb * 2048);
+  for (int cb = 0; cb < 2; ++cb) fb0[cb] = frag16b(smem + b_off0 + cb * 2048);
 
   // One stage, ring slot S (compile-time): no branches, no address arithmetic — fragment reads are
   // base register + immediate, the DMA of stage +3 goes to slot S+3, one counted wait + one barrier.
@@ -314,43 +334,34 @@ __global__ __launch_bounds__(kThreads16, 2) void flat_scan16_kernel(const ScanAr
   do {                                                                                                   \
     constexpr uint32_t so = (uint32_t)(S) * kXStage16, sn = (uint32_t)(((S) + 1) & 3) * kXStage16;       \
     constexpr int sd = ((S) + 3) & 3;                                                                    \
-    /* k-step 0: read set 1 (k-step 1 of this stage), 8 MFMAs on set 0, DMA pieces in between */       \
-    fb1[0] = frag16(smem + b_off1 + so);                                                                 \
-    fb1[1] = frag16(smem + b_off1 + so + 2048);                                                          \
-    _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) fa1[rb] = frag16(smem + a_off1 + so + rb * 2048);   \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    acc[0][0] = EHX_MFMA16(fa0[0], fb0[0], acc[0][0]);                                                   \
-    acc[0][1] = EHX_MFMA16(fa0[0], fb0[1], acc[0][1]);                                                   \
-    EHX_DMA_X0(sd);                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    acc[1][0] = EHX_MFMA16(fa0[1], fb0[0], acc[1][0]);                                                   \
-    acc[1][1] = EHX_MFMA16(fa0[1], fb0[1], acc[1][1]);                                                   \
-    EHX_DMA_Q0(sd);                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    acc[2][0] = EHX_MFMA16(fa0[2], fb0[0], acc[2][0]);                                                   \
-    acc[2][1] = EHX_MFMA16(fa0[2], fb0[1], acc[2][1]);                                                   \
-    EHX_DMA_X1(sd);                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    acc[3][0] = EHX_MFMA16(fa0[3], fb0[0], acc[3][0]);                                                   \
-    acc[3][1] = EHX_MFMA16(fa0[3], fb0[1], acc[3][1]);                                                   \
-    EHX_DMA_Q1(sd);                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    /* stage barrier: the next stage landed (own pieces counted: only the two younger stages may still   \
-       be in flight) and is visible; every wave is done reading this stage */                            \
-    if (!ABL16_NO_VMWAIT) wait_vmcnt<8>();                                                               \
+    /* Every gap between two MFMAs carries exactly one other instruction of this wave (a fragment read or \
+       a DMA piece): bunched together they would leave the matrix pipe idle while they issue. */         \
+    /* k-step 0: MFMAs on set 0; reads of set 1 (k-step 1 of this stage); first two DMA pieces */        \
+    EHX_MF(fa0, fb0, 0, 0); fb1[0] = frag16b(smem + b_off1 + so);            EHX_SB();                    \
+    EHX_MF(fa0, fb0, 0, 1); fb1[1] = frag16b(smem + b_off1 + so + 2048);     EHX_SB();                    \
+    EHX_MF(fa0, fb0, 1, 0); fa1[0] = frag16a(smem + a_off1 + so);            EHX_SB();                    \
+    EHX_MF(fa0, fb0, 1, 1); fa1[1] = frag16a(smem + a_off1 + so + 2048);     EHX_SB();                    \
+    EHX_MF(fa0, fb0, 2, 0); fa1[2] = frag16a(smem + a_off1 + so + 4096);     EHX_SB();                    \
+    EHX_MF(fa0, fb0, 2, 1); fa1[3] = frag16a(smem + a_off1 + so + 6144);     EHX_SB();                    \
+    EHX_MF(fa0, fb0, 3, 0); EHX_DMA_X0(sd);                                 EHX_SB();                    \
+    EHX_MF(fa0, fb0, 3, 1); EHX_DMA_Q0(sd);                                 EHX_SB();                    \
+    /* stage barrier: the next stage landed (own pieces counted: the younger stage and the two pieces    \
+       just issued may still be in flight) and is visible; every wave is done reading this stage */      \
+    if (!ABL16_NO_VMWAIT) wait_vmcnt<6>();                                                               \
     if (!ABL16_NO_BARRIER) lds_barrier();                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    /* k-step 1: read set 0 of the next stage, 8 MFMAs on set 1 */                                       \
-    fb0[0] = frag16(smem + b_off0 + sn);                                                                 \
-    fb0[1] = frag16(smem + b_off0 + sn + 2048);                                                          \
-    _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) fa0[rb] = frag16(smem + a_off0 + sn + rb * 2048);   \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) {                                                   \
-      acc[rb][0] = EHX_MFMA16(fa1[rb], fb1[0], acc[rb][0]);                                              \
-      acc[rb][1] = EHX_MFMA16(fa1[rb], fb1[1], acc[rb][1]);                                              \
-    }                                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    EHX_SB();                                                                                            \
+    /* k-step 1: MFMAs on set 1; reads of set 0 of the next stage; last two DMA pieces */                \
+    EHX_MF(fa1, fb1, 0, 0); fb0[0] = frag16b(smem + b_off0 + sn);            EHX_SB();                    \
+    EHX_MF(fa1, fb1, 0, 1); fb0[1] = frag16b(smem + b_off0 + sn + 2048);     EHX_SB();                    \
+    EHX_MF(fa1, fb1, 1, 0); fa0[0] = frag16a(smem + a_off0 + sn);            EHX_SB();                    \
+    EHX_MF(fa1, fb1, 1, 1); fa0[1] = frag16a(smem + a_off0 + sn + 2048);     EHX_SB();                    \
+    EHX_MF(fa1, fb1, 2, 0); fa0[2] = frag16a(smem + a_off0 + sn + 4096);     EHX_SB();                    \
+    EHX_MF(fa1, fb1, 2, 1); fa0[3] = frag16a(smem + a_off0 + sn + 6144);     EHX_SB();                    \
+    EHX_MF(fa1, fb1, 3, 0); EHX_DMA_X1(sd);                                 EHX_SB();                    \
+    EHX_MF(fa1, fb1, 3, 1); EHX_DMA_Q1(sd);                                 EHX_SB();                    \
   } while (0)
+#define EHX_MF(A, B, RB, CB) acc[RB][CB] = EHX_MFMA16(A[RB], B[CB], acc[RB][CB])
+#define EHX_SB() __builtin_amdgcn_sched_barrier(0)
 
   // One flat loop over groups of four stages (= one revolution of the ring; ld % 128 == 0 makes a tile a
   // whole number of them); the tile boundary work hangs off a counter inside it.
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(kThreads16, 2) void flat_scan16_kernel(const ScanAr
           for (int r = 0; r < 16; ++r) acc[rb][cb][r] = acc0;
       ++t;
       // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
-      // parameters of the tile after it (past the last tile: the array's tail padding)
+      // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
       qsrc = qbase + 3 * kQStage16;
       rsrc += kTileRows16 * 8;
       if (w < 2) {
@@ -391,6 +402,8 @@ __global__ __launch_bounds__(kThreads16, 2) void flat_scan16_kernel(const ScanAr
   }
   }  // my_tiles > 0
 #undef EHX_STAGE16
+#undef EHX_MF
+#undef EHX_SB
 #undef EHX_DMA_X0
 #undef EHX_DMA_Q0
 #undef EHX_DMA_X1

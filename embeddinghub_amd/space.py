@@ -128,6 +128,9 @@ class Space:
     def set_ef(self, ef):
         check(self._L.ehx_space_set_ef(self._h, ef))
 
+    def set_scan(self, scan):
+        check(self._L.ehx_space_set_scan(self._h, scan))
+
     def fill_synthetic(self, seed, row0, n_rows, normalize):
         check(self._L.ehx_fill_synthetic(self._h, seed, row0, n_rows, int(bool(normalize))))
 

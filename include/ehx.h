@@ -133,6 +133,9 @@ int ehx_space_size(ehx_space* s, uint64_t* n); /* number of distinct keys       
 int ehx_space_dims(ehx_space* s, uint32_t* dims);
 int ehx_space_reserve(ehx_space* s, uint64_t rows);
 int ehx_space_set_ef(ehx_space* s, uint32_t ef);
+/* flat fp32 spaces: switch between EHX_SCAN_AUTO (fp16 filter + fp32 certified re-rank, the default) and
+ * EHX_SCAN_F32 (fp32 scan only).  Results are identical; A/B measurement and diagnosis. */
+int ehx_space_set_scan(ehx_space* s, uint32_t scan);
 
 /* ---- writes: Set/MultiSet (server.cc:113-149 -> Version::set -> ANNIndex::set, index.cc:20-37),
  *      OnlineStoreTable.Set / BatchOnlineTable.BatchSet (online.go:50-53,66-70) ---- */

@@ -1,16 +1,25 @@
 #!/bin/bash
-# rocprofv3 passes for the bench workload: kernel trace + stats, then PMC passes (own runs).
+# rocprofv3 passes for the bench workload: kernel trace, then PMC passes (each its own run, kernel-trace
+# only).  Summaries (text) land in gpurun_out/prof/*.txt; copy the ones to keep into profiles/.
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 R=$(pwd)
-echo "== bench (default flags)"; timeout 600 python bench.py > gpurun_out/bench_default.log 2>&1; tail -1 gpurun_out/bench_default.log
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-f32-engine $BENCH_ARGS"
+echo "== bench (default flags)"; timeout 900 python bench.py > gpurun_out/bench_default.log 2>&1; tail -1 gpurun_out/bench_default.log
 echo "== kernel trace"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace -o trace -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof/trace.log 2>&1); tail -2 gpurun_out/prof/trace.log
-echo "== pmc FETCH_SIZE"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/prof/pmc_fetch -o fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof/pmc_fetch.log 2>&1); tail -1 gpurun_out/prof/pmc_fetch.log
-echo "== pmc WRITE_SIZE"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof/pmc_write -o write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof/pmc_write.log 2>&1); tail -1 gpurun_out/prof/pmc_write.log
+rm -rf gpurun_out/prof/trace
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace -o trace -- python $R/bench.py $ARGS > $R/gpurun_out/prof/trace.log 2>&1); tail -1 gpurun_out/prof/trace.log | cut -c1-300
+python scripts/rocpd_summary.py gpurun_out/prof/trace > gpurun_out/prof/trace_summary.txt 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  echo "== pmc $c"
+  rm -rf gpurun_out/prof/pmc_$c
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/prof/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-engine $BENCH_ARGS > $R/gpurun_out/prof/pmc_$c.log 2>&1)
+  python scripts/rocpd_summary.py gpurun_out/prof/pmc_$c > gpurun_out/prof/pmc_${c}_summary.txt 2>&1
+done
 echo "== pmc SQ"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $R/gpurun_out/prof/pmc_sq -o sq -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof/pmc_sq.log 2>&1); tail -1 gpurun_out/prof/pmc_sq.log
-find gpurun_out/prof -type f | head -50; du -sh gpurun_out/prof
+rm -rf gpurun_out/prof/pmc_sq
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE -d $R/gpurun_out/prof/pmc_sq -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-engine $BENCH_ARGS > $R/gpurun_out/prof/pmc_sq.log 2>&1)
+python scripts/rocpd_summary.py gpurun_out/prof/pmc_sq > gpurun_out/prof/pmc_sq_summary.txt 2>&1
+head -30 gpurun_out/prof/trace_summary.txt | cut -c1-170
+grep -h "flat_scan" gpurun_out/prof/pmc_*_summary.txt | cut -c1-170
+find gpurun_out/prof -name "*.db" -size +20M -delete; du -sh gpurun_out/prof
