@@ -1,0 +1,262 @@
+"""The embeddingstore gRPC service over the MI355X engine.
+
+Replaces embeddinghub/embeddingstore/server.cc:65-268 (EmbeddingHubService) — same nine RPCs, same
+status codes and messages — with the engine's spaces behind it instead of RocksDB + hnswlib:
+
+  * unknown space -> NOT_FOUND "Not found" (server.cc:88, 103, 122, 140, 160, 178, 222);
+  * NearestNeighbor: exactly one of key / embedding, else INVALID_ARGUMENT with the reference's texts
+    (server.cc:183-189); by key: ask for num+1, drop the key itself, else drop the last (198-207);
+  * writes to a frozen space -> FAILED_PRECONDITION "Cannot write to immutable space" (125-127, 144-146);
+  * Get / MultiGet of a key that is not there -> OK with an empty embedding (storage.cc:28-36 ignores the
+    lookup status); CreateSpace of an existing name returns the existing space (embedding_store.cc:33-36);
+    DeleteSpace of an unknown name is OK (64-69); Download streams in key order (RocksDB iteration order).
+Divergences, all where the reference has undefined behaviour: an embedding whose length is not the
+space's dims -> INVALID_ARGUMENT; NearestNeighbor by a key that is not stored -> NOT_FOUND; fewer
+stored rows than `num` -> a shorter list.
+
+The reference serialises every handler with one process-wide mutex (server.cc:67 etc.); here handlers
+run concurrently on the gRPC thread pool and concurrent NearestNeighbor calls are coalesced into one
+device batch by the engine's micro-batcher (ehx_knn), which is where batch=1024 comes from when the
+callers are single-query RPCs.
+
+The servicer talks to a *store* (create_space / get_space / delete_space returning space objects with
+set / set_batch / get / freeze / len / key_of / nearest); `EngineStore` is the engine-backed one.
+"""
+import argparse
+import sys
+import threading
+from concurrent import futures
+
+import grpc
+import numpy as np
+
+from . import embedding_store_pb2 as pb
+from . import embedding_store_pb2_grpc as pb_grpc
+
+
+class SpaceNotWritable(Exception):
+    pass
+
+
+class KeyNotFound(Exception):
+    pass
+
+
+class EngineSpace:
+    """One embeddingstore space (its single 'initial' version, server.cc:28) on the engine."""
+
+    def __init__(self, space):
+        self._s = space
+        self.dims = space.dims
+
+    def set(self, key, vec):
+        self.set_batch([key], [vec])
+
+    def set_batch(self, keys, vecs):
+        from .. import _lib
+        try:
+            self._s.set_batch(keys, np.asarray(vecs, dtype=np.float32).reshape(len(keys), self.dims))
+        except _lib.EhxError as e:
+            if e.code == _lib.EIMMUTABLE:
+                raise SpaceNotWritable()
+            raise
+
+    def get(self, key):
+        from .. import _lib
+        try:
+            return self._s.get(key)
+        except _lib.EhxError as e:
+            if e.code == _lib.ENOTFOUND:
+                return None
+            raise
+
+    def freeze(self):
+        self._s.freeze()
+
+    def __len__(self):
+        return len(self._s)
+
+    def keys_sorted(self):
+        ks = [self._s.key_of(i) for i in range(len(self._s))]
+        return sorted(ks, key=lambda k: k.encode())
+
+    def nearest(self, num, key="", embedding=None):
+        from ..space import nearest_neighbor_rpc
+        code, keys = nearest_neighbor_rpc(self._s, num, key=key, embedding=embedding)
+        if code == 5:
+            raise KeyNotFound()
+        return keys
+
+    def drop(self):
+        self._s.drop()
+
+
+class EngineStore:
+    """name -> space, in the engine's process-global registry (ehx_space_create / open / drop)."""
+
+    def __init__(self, metric=None, **space_kw):
+        import embeddinghub_amd as ehx
+        self._ehx = ehx
+        self._metric = ehx.METRIC_L2SQ if metric is None else metric  # index.cc:13: the embeddingstore is L2
+        self._kw = space_kw
+        self._mu = threading.Lock()
+        self._spaces = {}
+
+    def create_space(self, name, dims):
+        with self._mu:
+            if name in self._spaces:
+                return self._spaces[name]
+            sp = EngineSpace(self._ehx.Space(name, dims, metric=self._metric, **self._kw))
+            self._spaces[name] = sp
+            return sp
+
+    def get_space(self, name):
+        with self._mu:
+            return self._spaces.get(name)
+
+    def delete_space(self, name):
+        with self._mu:
+            sp = self._spaces.pop(name, None)
+        if sp is not None:
+            sp.drop()
+
+
+def _values(embedding):
+    return np.fromiter(embedding.values, dtype=np.float32, count=len(embedding.values))
+
+
+class EmbeddingHubService(pb_grpc.EmbeddingHubServicer):
+    MULTISET_CHUNK = 4096  # rows handed to the engine per set_batch while a MultiSet stream is consumed
+
+    def __init__(self, store):
+        self._store = store
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def _space(self, name, context):
+        sp = self._store.get_space(name)
+        if sp is None:
+            context.abort(grpc.StatusCode.NOT_FOUND, "Not found")
+        return sp
+
+    def _checked(self, sp, embedding, context):
+        v = _values(embedding)
+        if v.shape[0] != sp.dims:
+            context.abort(grpc.StatusCode.INVALID_ARGUMENT,
+                          "embedding has %d values, space has %d dims" % (v.shape[0], sp.dims))
+        return v
+
+    @staticmethod
+    def _write(fn, context):
+        try:
+            fn()
+        except SpaceNotWritable:
+            context.abort(grpc.StatusCode.FAILED_PRECONDITION, "Cannot write to immutable space")
+
+    # ---- the nine RPCs (server.h:24-59) ----------------------------------------------------------
+    def CreateSpace(self, request, context):
+        if request.dims == 0:
+            context.abort(grpc.StatusCode.INVALID_ARGUMENT, "dims must be positive")
+        self._store.create_space(request.name, request.dims)
+        return pb.CreateSpaceResponse()
+
+    def DeleteSpace(self, request, context):
+        self._store.delete_space(request.name)
+        return pb.DeleteSpaceResponse()
+
+    def FreezeSpace(self, request, context):
+        self._space(request.name, context).freeze()
+        return pb.FreezeSpaceResponse()
+
+    def Set(self, request, context):
+        sp = self._space(request.space, context)
+        v = self._checked(sp, request.embedding, context)
+        self._write(lambda: sp.set(request.key, v), context)
+        return pb.SetResponse()
+
+    def Get(self, request, context):
+        sp = self._space(request.space, context)
+        v = sp.get(request.key)
+        return pb.GetResponse(embedding=pb.Embedding(values=[] if v is None else v.tolist()))
+
+    def MultiSet(self, request_iterator, context):
+        # the stream may interleave spaces (server.cc:134-150 looks the space up per message); rows are
+        # handed to the engine in chunks per space, in arrival order, so a repeated key keeps its last value
+        pending = {}
+
+        def flush(name):
+            sp, keys, vecs = pending.pop(name)
+            if keys:
+                self._write(lambda: sp.set_batch(keys, vecs), context)
+
+        for req in request_iterator:
+            entry = pending.get(req.space)
+            if entry is None:
+                entry = pending[req.space] = (self._space(req.space, context), [], [])
+            sp, keys, vecs = entry
+            vecs.append(self._checked(sp, req.embedding, context))
+            keys.append(req.key)
+            if len(keys) >= self.MULTISET_CHUNK:
+                flush(req.space)
+        for name in list(pending):
+            flush(name)
+        return pb.MultiSetResponse()
+
+    def MultiGet(self, request_iterator, context):
+        for req in request_iterator:
+            v = self._space(req.space, context).get(req.key)
+            yield pb.MultiGetResponse(embedding=pb.Embedding(values=[] if v is None else v.tolist()))
+
+    def NearestNeighbor(self, request, context):
+        sp = self._space(request.space, context)
+        has_key = request.key != ""
+        has_vec = len(request.embedding.values) != 0
+        if has_key and has_vec:
+            context.abort(grpc.StatusCode.INVALID_ARGUMENT, "Key and embedding cannot both be set")
+        if not has_key and not has_vec:
+            context.abort(grpc.StatusCode.INVALID_ARGUMENT, "Key or embedding must be set")
+        if request.num < 0:
+            context.abort(grpc.StatusCode.INVALID_ARGUMENT, "num must not be negative")
+        try:
+            if has_key:
+                keys = sp.nearest(request.num, key=request.key)
+            else:
+                keys = sp.nearest(request.num, embedding=self._checked(sp, request.embedding, context))
+        except KeyNotFound:
+            context.abort(grpc.StatusCode.NOT_FOUND, "Not found")
+        return pb.NearestNeighborResponse(keys=keys)
+
+    def Download(self, request, context):
+        sp = self._space(request.space, context)
+        for key in sp.keys_sorted():
+            v = sp.get(key)
+            if v is not None:
+                yield pb.DownloadResponse(key=key, embedding=pb.Embedding(values=v.tolist()))
+
+
+def make_server(store, address, max_workers=64):
+    """gRPC sync server with `max_workers` handler threads: that many NearestNeighbor calls can be inside the
+    engine at once and get coalesced into one device batch."""
+    server = grpc.server(futures.ThreadPoolExecutor(max_workers=max_workers),
+                         options=(("grpc.max_receive_message_length", 64 << 20),
+                                  ("grpc.max_send_message_length", 64 << 20)))
+    pb_grpc.add_EmbeddingHubServicer_to_server(EmbeddingHubService(store), server)
+    port = server.add_insecure_port(address)  # no authentication, like the reference (server.cc:258)
+    return server, port
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="embeddingstore gRPC service on the MI355X engine")
+    ap.add_argument("address", nargs="?", default="0.0.0.0:7462")  # main.cc: default port of the reference
+    ap.add_argument("--metric", choices=["l2", "ip", "cosine"], default="l2")
+    ap.add_argument("--workers", type=int, default=64)
+    args = ap.parse_args(argv)
+    import embeddinghub_amd as ehx
+    metric = {"l2": ehx.METRIC_L2SQ, "ip": ehx.METRIC_IP, "cosine": ehx.METRIC_COSINE}[args.metric]
+    server, port = make_server(EngineStore(metric=metric), args.address, args.workers)
+    server.start()
+    print("Server listening on %s" % args.address, flush=True)
+    server.wait_for_termination()
+
+
+if __name__ == "__main__":
+    sys.exit(main())

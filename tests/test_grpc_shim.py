@@ -1,0 +1,236 @@
+"""The embeddingstore gRPC shim (embeddinghub_amd/rpc): the reference's own end-to-end tests
+(embeddinghub/test/integration.py:44-123) and the RPC semantics of server.cc:65-268, restated against
+the shim.
+
+CPU leg (`not gpu`): the servicer, wire contract and client run over a store backed by the ORACLE
+(tests may use the oracle; the product never does) — this pins the gRPC layer itself.  GPU leg: the
+same suite over the engine-backed store, plus parity of NearestNeighbor with the oracle and the
+coalescing of concurrent single-query RPCs into device batches."""
+import threading
+import uuid
+
+import grpc
+import numpy as np
+import pytest
+
+from embeddinghub_amd.rpc import embedding_store_pb2 as pb
+from embeddinghub_amd.rpc import server as srv
+from embeddinghub_amd.rpc.client import EmbeddingHubClient
+from oracle import pyoracle
+
+
+# ---- an oracle-backed store (test double for the CPU leg) ------------------------------------------
+class OracleSpace:
+    def __init__(self, dims):
+        self.dims = dims
+        self._idx = pyoracle.AnnIndex(dims)
+        self._vals = {}
+        self._frozen = False
+
+    def set(self, key, vec):
+        self.set_batch([key], [vec])
+
+    def set_batch(self, keys, vecs):
+        if self._frozen:
+            raise srv.SpaceNotWritable()
+        for k, v in zip(keys, vecs):
+            v = np.asarray(v, dtype=np.float32)
+            self._idx.set(k, v)
+            self._vals[k] = v
+
+    def get(self, key):
+        return self._vals.get(key)
+
+    def freeze(self):
+        self._frozen = True
+
+    def __len__(self):
+        return len(self._vals)
+
+    def keys_sorted(self):
+        return sorted(self._vals, key=lambda k: k.encode())
+
+    def nearest(self, num, key="", embedding=None):
+        if key:
+            if key not in self._vals:
+                raise srv.KeyNotFound()
+            got = self._idx.approx_nearest(self._vals[key], min(num + 1, len(self._vals)))
+            if key in got:
+                got.remove(key)
+            else:
+                got = got[:-1]
+            return got[:num]
+        return self._idx.approx_nearest(np.asarray(embedding, dtype=np.float32), min(num, len(self._vals)))
+
+
+class OracleStore:
+    def __init__(self):
+        self._spaces = {}
+
+    def create_space(self, name, dims):
+        return self._spaces.setdefault(name, OracleSpace(dims))
+
+    def get_space(self, name):
+        return self._spaces.get(name)
+
+    def delete_space(self, name):
+        self._spaces.pop(name, None)
+
+
+def _serve(store):
+    server, port = srv.make_server(store, "127.0.0.1:0", max_workers=48)
+    server.start()
+    client = EmbeddingHubClient(host="127.0.0.1", port=port)
+    return server, client
+
+
+@pytest.fixture
+def oracle_client():
+    server, client = _serve(OracleStore())
+    yield client
+    client.close()
+    server.stop(0)
+
+
+@pytest.fixture
+def engine_client():
+    pytest.importorskip("embeddinghub_amd")
+    server, client = _serve(srv.EngineStore())
+    yield client
+    client.close()
+    server.stop(0)
+
+
+# ---- the suite (runs on both legs) -------------------------------------------------------------------
+def check_set_get(c):  # integration.py:44-49
+    space = uuid.uuid4()
+    c.create_space(space, 3)
+    c.set(space, "a", [1, 2, 3])
+    assert c.get(space, "a") == [1, 2, 3]
+
+
+def check_immutable_set(c):  # integration.py:52-61
+    space = uuid.uuid4()
+    c.create_space(space, 3)
+    c.set(space, "a", [1, 2, 3])
+    assert c.get(space, "a") == [1, 2, 3]
+    c.freeze_space(space)
+    with pytest.raises(TypeError):
+        c.set(space, "a", [1, 2, 3])
+    with pytest.raises(grpc.RpcError) as e:  # MultiSet maps to the same status (server.cc:144-146)
+        c.multiset(space, {"b": [1, 1, 1]})
+    assert e.value.code() == grpc.StatusCode.FAILED_PRECONDITION
+    assert e.value.details() == "Cannot write to immutable space"
+
+
+def check_multiset_get_multiget_download(c):  # integration.py:64-123
+    space = uuid.uuid4()
+    embs = {"a": [1, 2, 3], "b": [3, 2, 1]}
+    c.create_space(space, 3)
+    c.multiset(space, embs)
+    for key, emb in embs.items():
+        assert c.get(space, key) == emb
+    assert dict(zip(embs.keys(), c.multiget(space, embs.keys()))) == embs
+    assert {k: v for k, v in c.download(space)} == embs
+    assert [k for k, _ in c.download(space)] == sorted(embs)  # RocksDB iteration order
+
+
+def check_multi_space(c):  # integration.py:91-106
+    tag = str(uuid.uuid4())
+    embs = {"a" + tag: [1, 2, 3], "b" + tag: [3, 2, 1]}
+    for space in embs:
+        c.create_space(space, 3)
+    for space, emb in embs.items():
+        c.set(space, "key", emb)
+    for space, emb in embs.items():
+        assert c.get(space, "key") == emb
+
+
+def check_status_codes(c):  # server.cc:88, 178, 183-189; storage.cc:28-36; embedding_store.cc:33-36, 64-69
+    space = str(uuid.uuid4())
+    for call in (lambda: c.get("no-such-space", "a"), lambda: c.set("no-such-space", "a", [1.0]),
+                 lambda: c.freeze_space("no-such-space"), lambda: c.nearest_neighbor("no-such-space", 1, key="a"),
+                 lambda: list(c.download("no-such-space")), lambda: list(c.multiget("no-such-space", ["a"]))):
+        with pytest.raises(grpc.RpcError) as e:
+            call()
+        assert e.value.code() == grpc.StatusCode.NOT_FOUND and e.value.details() == "Not found"
+    c.create_space(space, 3)
+    c.create_space(space, 3)  # idempotent: returns the existing space
+    c.set(space, "a", [0, 1, 0])
+    assert list(c.get(space, "missing")) == []  # OK with an empty embedding
+    with pytest.raises(grpc.RpcError) as e:
+        c.nearest_neighbor(space, 1, key="a", embedding=[0, 1, 0])
+    assert e.value.code() == grpc.StatusCode.INVALID_ARGUMENT
+    assert e.value.details() == "Key and embedding cannot both be set"
+    with pytest.raises(grpc.RpcError) as e:
+        c.nearest_neighbor(space, 1)
+    assert e.value.code() == grpc.StatusCode.INVALID_ARGUMENT and e.value.details() == "Key or embedding must be set"
+    with pytest.raises(grpc.RpcError) as e:
+        c.set(space, "b", [1, 2])  # wrong length: undefined behaviour in the reference, an error here
+    assert e.value.code() == grpc.StatusCode.INVALID_ARGUMENT
+    c.delete_space(space)
+    c.delete_space(space)  # unknown name: still OK
+    with pytest.raises(grpc.RpcError) as e:
+        c.get(space, "a")
+    assert e.value.code() == grpc.StatusCode.NOT_FOUND
+
+
+def check_nearest_neighbor(c):  # index_test.cc:17-49 data through the RPC; server.cc:193-207 by key
+    space = uuid.uuid4()
+    c.create_space(space, 3)
+    c.multiset(space, {"a": [0, 1, 0], "b": [1, 1, 0], "c": [1, 0, 0]})
+    assert list(c.nearest_neighbor(space, 1, embedding=[0, 1, 0])) == ["a"]
+    assert list(c.nearest_neighbor(space, 2, embedding=[0, 1, 0])) == ["a", "b"]
+    assert list(c.nearest_neighbor(space, 2, key="a")) == ["b", "c"]  # the key itself is removed
+    fut = c.nearest_neighbor(space, 1, key="c", wait=False)
+    assert list(fut.result()) == ["b"]
+    c.set(space, "a", [0, -1, 0])  # update in place (index_test.cc:39-49)
+    assert list(c.nearest_neighbor(space, 1, embedding=[0, 1, 0])) == ["b"]
+
+
+SUITE = [check_set_get, check_immutable_set, check_multiset_get_multiget_download, check_multi_space,
+         check_status_codes, check_nearest_neighbor]
+
+
+@pytest.mark.parametrize("check", SUITE, ids=lambda f: f.__name__)
+def test_shim_over_oracle_store(oracle_client, check):
+    check(oracle_client)
+
+
+def test_wire_contract_matches_the_reference_proto():
+    # field numbers / types of embedding_store.proto:84-112 as bytes on the wire
+    r = pb.NearestNeighborRequest(num=5, space="s", key="k", embedding=pb.Embedding(values=[1.0, 2.0]))
+    assert r.SerializeToString() == (b"\x08\x05" b"\x12\x01s" b"\x1a\x01k" b"\x22\x0a\x0a\x08" +
+                                     np.array([1.0, 2.0], dtype="<f4").tobytes())
+    assert pb.Embedding(values=[1.5]).SerializeToString() == b"\x0a\x04" + np.float32(1.5).tobytes()  # packed
+    assert pb.DESCRIPTOR.package == "featureform.embedding.proto"
+    assert sorted(m.name for m in pb.DESCRIPTOR.services_by_name["EmbeddingHub"].methods) == sorted(pb.METHODS)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("check", SUITE, ids=lambda f: f.__name__)
+def test_shim_over_engine_store(engine_client, check):
+    check(engine_client)
+
+
+@pytest.mark.gpu
+def test_engine_nearest_neighbor_matches_oracle_and_coalesces(engine_client):
+    import embeddinghub_amd as ehx
+    c = engine_client
+    rng = np.random.default_rng(11)
+    n, d = 3000, 64
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    space = "rpc-parity-%s" % uuid.uuid4()
+    c.create_space(space, d)
+    c.multiset(space, ((("k%d" % i), X[i].tolist()) for i in range(n)))
+    Q = rng.standard_normal((96, d)).astype(np.float32)
+    oids, _, _ = pyoracle.exhaustive(X, Q, 10, pyoracle.METRIC_L2)
+    # 96 single-query RPCs in flight at once
+    futs = [c.nearest_neighbor(space, 10, embedding=q.tolist(), wait=False) for q in Q]
+    got = [list(f.result()) for f in futs]
+    assert got == [["k%d" % i for i in row] for row in oids]
+    by_key = list(c.nearest_neighbor(space, 5, key="k7"))
+    o7, _, _ = pyoracle.exhaustive(X, X[7:8], 6, pyoracle.METRIC_L2)
+    assert by_key == ["k%d" % i for i in o7[0] if i != 7][:5]
+    st = ehx.Space.open(space).stats()
+    assert st["n_queries"] >= 96
