@@ -146,7 +146,7 @@ struct ehx_space {
   unsigned long long* dUncert = nullptr;
   // filter scratch: fp16 queries, per-query (gamma, u, v), per-query certification flags, re-run buffers
   DevBuf<__half> dQ16;
-  DevBuf<float> dQgamma, dFbQ, dFbDist;
+  DevBuf<float> dQgamma, dFbQ, dFbDist, dSample;
   DevBuf<float2> dQuv;
   DevBuf<uint32_t> dUflags, dFbCnt;
   DevBuf<uint64_t> dFbIds;
@@ -192,6 +192,7 @@ struct ehx_space {
     if (dUncert16) (void)hipFree(dUncert16);
     dQ16.release();
     dQgamma.release();
+    dSample.release();
     dFbQ.release();
     dFbDist.release();
     dQuv.release();
@@ -767,11 +768,25 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
     uint32_t tile0;
     ScanPlan plan;
   };
+  // Filter scan: a SAMPLE pass first — the first 8 tiles (2048 rows) are scanned in dump mode (all scores to
+  // HBM, no candidate lists) and sample_select turns them into the k'-th best score per query, so not even
+  // the first real pass has to warm its lists up from +inf (which costs ~3 list compactions per list).
+  constexpr uint32_t kSampleTiles = 8;
+  const bool sample = f16 && n_tiles >= 256;
   std::vector<Pass> passes;
   {
     const ScanPlan whole = plan_scan((uint32_t)nq, n_tiles, k, E.n_cus);
     uint32_t done = 0;
-    if (lpc == 2 && n_tiles >= 16 * whole.n_chunks) {
+    if (sample) {
+      // the filter scan gets its first thresholds from the sample pass below, so its cascade can start
+      // wide (128 tiles) and grow x16: three scan launches at 10 M rows
+      uint32_t cum = 128;
+      while (cum * 2 < n_tiles) {
+        passes.push_back({done, plan_scan((uint32_t)nq, cum - done, k, E.n_cus)});
+        done = cum;
+        cum *= 16;
+      }
+    } else if (lpc == 2 && n_tiles >= 16 * whole.n_chunks) {
       uint32_t cum = whole.n_chunks;  // pass 0: one tile per workgroup
       while (cum * 2 < n_tiles) {
         passes.push_back({done, plan_scan((uint32_t)nq, cum - done, k, E.n_cus)});
@@ -809,6 +824,7 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
     if ((rc = s->dQgamma.ensure(p.q_rows))) return rc;
     if ((rc = s->dQuv.ensure(p.q_rows))) return rc;
     if ((rc = s->dUflags.ensure(p.q_rows))) return rc;
+    if (sample && (rc = s->dSample.ensure((size_t)kSampleTiles * kTileRows16 * p.q_rows))) return rc;
     if (!s->dUncert16) {
       HIP_TRY(hipMalloc((void**)&s->dUncert16, sizeof(unsigned long long)));
       HIP_TRY(hipMemset(s->dUncert16, 0, sizeof(unsigned long long)));
@@ -880,6 +896,15 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
     hipEvent_t* pr = s->ring[s->ring_count % ehx_space::kRing];
     HIP_TRY(hipEventRecord(s->ev[1], st));
     HIP_TRY(hipEventRecord(pr[0], st));
+    if (sample) {
+      ScanPlan sp = plan_scan((uint32_t)nq, kSampleTiles, k, E.n_cus);
+      sp.kprime = p.kprime;
+      h.dump = s->dSample.p;
+      HIP_TRY(scan(sp, 0, 0));
+      h.dump = nullptr;
+      HIP_TRY(launch_sample_select(s->dSample.p, kSampleTiles * kTileRows16, p.q_rows, (uint32_t)nq, p.kprime,
+                                   (unsigned long long*)s->dGthr.p, st));
+    }
     for (size_t i = 0; i < passes.size(); ++i) {
       const bool last = i + 1 == passes.size();
       HIP_TRY(scan(passes[i].plan, passes[i].tile0, 0));

@@ -200,6 +200,7 @@ struct ScanArgs16 {
   const float* qgamma;   // [q_tiles*256] gamma_q
   float eps;             // accumulator start value: bound of |dot16 - true dot|
   uint32_t cos;          // 1: every valid row has (a, b) = (-1, 1) and gamma = 1 (cosine): fast phase 1
+  float* dump = nullptr; // sample pass: write every score to dump[row - tile0*256][q_tiles*256] instead of keeping lists
   uint64_t* cand;
   uint64_t* part;
   uint32_t n;
@@ -235,6 +236,11 @@ size_t scan16_lds_bytes();
 hipError_t launch_flat_scan16(const ScanArgs16& a, hipStream_t st);
 // bound of |<fp16(q^), fp16(x^)> accumulated in fp32 - <q^, x^>| for unit vectors of `dims` elements
 inline float scan16_eps(uint32_t dims) { return 1.0e-3f + 2.0e-7f * (float)dims; }
+
+// sample pass -> starting thresholds: gthr[q] = key of the kprime-th smallest of scores[0..n_rows)[q] (id part
+// 0xFFFFFFFF, so a row that ties the threshold still passes); one wave per query
+hipError_t launch_sample_select(const float* scores, uint32_t n_rows, uint32_t q_rows, uint32_t nq, uint32_t kprime,
+                                unsigned long long* gthr, hipStream_t st);
 
 // scan copy of rows [row0, row0+n): X16 = fp16(x/|x|), rowp16 = (a_r, b_r) per metric.  Rows the filter
 // cannot bound (non-finite or denormal-range norms) are counted in *n_unsafe (the space then stays on

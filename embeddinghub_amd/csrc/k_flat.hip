@@ -484,6 +484,36 @@ __global__ __launch_bounds__(64) void flat_merge_kernel(const uint64_t* __restri
   if (gthr && lane == (int)kprime - 1) gthr[q] = best;
 }
 
+// sample pass of the fp16 filter scan: scores[row][q] of the first n_rows rows -> gthr[q] = the kprime-th
+// smallest score (as a key with the largest id, so ties with it still pass the scan's `key < threshold`).
+// It is the kprime-th best of a subset of the rows, hence an upper bound of the query's final kprime-th best.
+__global__ __launch_bounds__(64) void sample_select_kernel(const float* __restrict__ scores, uint32_t n_rows,
+                                                           uint32_t q_rows, uint32_t kprime,
+                                                           unsigned long long* __restrict__ gthr) {
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  uint64_t best = kKeyInf;  // ascending best-64 so far
+  for (uint32_t r0 = 0; r0 < n_rows; r0 += 64) {
+    const uint32_t r = r0 + lane;
+    uint64_t key = kKeyInf;
+    if (r < n_rows) {
+      const float sc = scores[(size_t)r * q_rows + q];
+      if (sc == sc) key = ((uint64_t)f32_to_ordered(sc) << 32) | 0xFFFFFFFFull;
+    }
+    key = wave_sort64(key, lane);
+    const uint64_t rv = __shfl(key, 63 - lane, 64);
+    const uint64_t m = best < rv ? best : rv;
+    best = wave_bitonic_merge64(m, lane);
+  }
+  if (lane == (int)kprime - 1) gthr[q] = best;
+}
+
+hipError_t launch_sample_select(const float* scores, uint32_t n_rows, uint32_t q_rows, uint32_t nq, uint32_t kprime,
+                                unsigned long long* gthr, hipStream_t st) {
+  hipLaunchKernelGGL(sample_select_kernel, dim3(nq), dim3(64), 0, st, scores, n_rows, q_rows, kprime, gthr);
+  return hipGetLastError();
+}
+
 // after the sample pass: the k'-th best key of the merged sample lists is an upper bound of the
 // query's global k'-th best -> initial threshold of the main pass
 __global__ __launch_bounds__(256) void set_gthr_kernel(const uint64_t* __restrict__ merged, uint32_t nq, uint32_t kprime,

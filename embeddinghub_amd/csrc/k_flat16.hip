@@ -123,7 +123,9 @@ __device__ __forceinline__ void lds_barrier() {
 
 size_t scan16_lds_bytes() { return kLdsBytes16; }
 
-template <bool COS>
+// DUMP: the sample pass — no candidate lists; every score of the scanned tiles is written to
+// a.dump[row - tile0*256][q] and sample_select_kernel (k_flat.hip) turns them into starting thresholds.
+template <bool COS, bool DUMP>
 __global__ __launch_bounds__(kThreads16, 2) void flat_scan16_kernel(const ScanArgs16 a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -229,6 +231,22 @@ __global__ __launch_bounds__(kThreads16, 2) void flat_scan16_kernel(const ScanAr
   auto epilogue = [&](uint32_t t) {
     const uint32_t tile_row0 = (tile_begin + t) * kTileRows16;
     const float2* rp = rowp_lds + (t & 3u) * kTileRows16;
+    if (DUMP) {
+      const size_t qcol = (size_t)qt * kTileQ + wc * 64 + i31;
+      const size_t q_rows = (size_t)a.q_tiles * kTileQ;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const uint32_t r = (uint32_t)(wr * 128 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
+          const float2 ab = rp[r];
+          float* o = a.dump + (size_t)(tile_row0 - a.tile0 * kTileRows16 + r) * q_rows + qcol;
+          o[0] = __builtin_fmaf(ab.x, acc[rb][0][reg], ab.y * gam0);
+          o[32] = __builtin_fmaf(ab.x, acc[rb][1][reg], ab.y * gam1);
+        }
+      }
+      return;
+    }
     const int lbase = w * 64 + i31;  // + cb*32
     const float thrf0 = thr_f[lbase], thrf1 = thr_f[lbase + 32];
     // ---- phase 1: one min score per 32x32 block and lane ----
@@ -412,6 +430,7 @@ __global__ __launch_bounds__(kThreads16, 2) void flat_scan16_kernel(const ScanAr
 
   // ---- final: sort this wave's 64 lists and publish them: part[q][chunk*2 + wr][k'] ----
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (DUMP) return;
   for (int ql = 0; ql < 64; ++ql) {
     const int list = w * 64 + ql;
     const int cq = cnt[list];
@@ -426,17 +445,18 @@ __global__ __launch_bounds__(kThreads16, 2) void flat_scan16_kernel(const ScanAr
 hipError_t launch_flat_scan16(const ScanArgs16& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)flat_scan16_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes16);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)flat_scan16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kLdsBytes16);
-    if (e != hipSuccess) return e;
+    const void* fns[3] = {(const void*)flat_scan16_kernel<false, false>, (const void*)flat_scan16_kernel<true, false>,
+                          (const void*)flat_scan16_kernel<false, true>};
+    for (const void* f : fns) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes16);
+      if (e != hipSuccess) return e;
+    }
     attr_set = true;
   }
   const uint32_t grid = a.q_tiles * a.n_chunks;
-  if (a.cos) hipLaunchKernelGGL(flat_scan16_kernel<true>, dim3(grid), dim3(kThreads16), kLdsBytes16, st, a);
-  else hipLaunchKernelGGL(flat_scan16_kernel<false>, dim3(grid), dim3(kThreads16), kLdsBytes16, st, a);
+  if (a.dump) hipLaunchKernelGGL((flat_scan16_kernel<false, true>), dim3(grid), dim3(kThreads16), kLdsBytes16, st, a);
+  else if (a.cos) hipLaunchKernelGGL((flat_scan16_kernel<true, false>), dim3(grid), dim3(kThreads16), kLdsBytes16, st, a);
+  else hipLaunchKernelGGL((flat_scan16_kernel<false, false>), dim3(grid), dim3(kThreads16), kLdsBytes16, st, a);
   return hipGetLastError();
 }
 
