@@ -44,6 +44,11 @@ def parse():
     ap.add_argument("--scan", choices=["auto", "f32"], default="auto",
                     help="scan engine of the timed run: auto = fp16 matrix-core filter + certified fp32 re-rank "
                          "(default), f32 = fp32 matrix-core scan only; results are identical")
+    ap.add_argument("--metric-kind", choices=["cosine", "l2", "ip"], default="cosine",
+                    help="distance of the timed space (the headline metric is cosine; l2/ip: other BASELINE configs)")
+    ap.add_argument("--set-stream", type=int, default=0, metavar="ROWS",
+                    help="also time ehx_set_batch of ROWS fresh rows from host memory into a second space of the same "
+                         "shape (BASELINE configs[4]: streamed Set); reported as set_stream")
     ap.add_argument("--no-f32-engine", action="store_true", help="skip the short A/B leg on the fp32-only engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=16000)
@@ -116,7 +121,8 @@ def main():
     row0, shard = shard_range(args.rows, G, rank)
     B, d, k = args.batch, args.dims, args.k
     t_fill = time.time()
-    space = ehx.Space("bench-r%d" % rank, d, metric=ehx.METRIC_COSINE, initial_capacity=shard,
+    metric = {"cosine": ehx.METRIC_COSINE, "l2": ehx.METRIC_L2SQ, "ip": ehx.METRIC_IP}[args.metric_kind]
+    space = ehx.Space("bench-r%d" % rank, d, metric=metric, initial_capacity=shard,
                       dtype=ehx.DTYPE_F16 if args.rows_dtype == "f16" else ehx.DTYPE_F32)
     space.fill_synthetic(ehx.SEED_CORPUS, row0, shard, True)
     torch.cuda.synchronize()
@@ -160,8 +166,8 @@ def main():
         return el, space.stats()  # stats: per-batch scan-phase durations from HIP events on the launch stream
 
     f16_rows = args.rows_dtype == "f16"
-    filt = args.scan == "auto" and not f16_rows and os.environ.get("EHX_SCAN", "") != "f32"
-    if not filt and not f16_rows:
+    filt = args.scan == "auto" and os.environ.get("EHX_SCAN", "") != "f32"
+    if not filt:
         space.set_scan(ehx.SCAN_F32)
     elapsed, st = timed(args.steps, args.warmup)
     scan_ms = st["scan_ms_mean"]
@@ -186,9 +192,9 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f16 filter -> f32 exact results" if filt else "f32", "data": "synthetic",
         "config": {
-            "workload": "%dx%d cosine (EHX-GAUSS-1 seed %d), batch=%d, k=%d; exhaustive scan = exact kNN "
+            "workload": "%dx%d %s (EHX-GAUSS-1 seed %d), batch=%d, k=%d; exhaustive scan = exact kNN "
                         "(recall@10 = 1.0 vs exhaustive by construction; ids and distances bit-identical to the "
-                        "fp32 oracle)" % (args.rows, d, ehx.SEED_CORPUS, B, k),
+                        "fp32 oracle)" % (args.rows, d, args.metric_kind, ehx.SEED_CORPUS, B, k),
             "engine": engine,
             "rows_total": args.rows, "rows_per_gpu": shard, "rows_dtype": args.rows_dtype, "dims": d, "batch": B,
             "k": k, "path": "flat",
@@ -224,6 +230,23 @@ def main():
             "frac": round(ach2 / MFMA_F32_PEAK_TFLOPS, 4), "n_uncertified": int(st2["n_uncertified"]),
         }
         space.set_scan(ehx.SCAN_AUTO)
+    if args.set_stream and rank == 0:
+        # streamed Set: host rows -> engine (pinned staging, H2D, per-row statistics, scan copy), while nothing
+        # else runs; rows/s as a cgo caller of ehx_set_batch would see it
+        import numpy as np
+        m = args.set_stream
+        rows = np.random.default_rng(1).standard_normal((m, d)).astype(np.float32)
+        keys = ["s%d" % i for i in range(m)]
+        w = ehx.Space("bench-set-r%d" % rank, d, metric=metric, initial_capacity=m,
+                      dtype=ehx.DTYPE_F16 if args.rows_dtype == "f16" else ehx.DTYPE_F32)
+        chunk = 65536
+        t0 = time.perf_counter()
+        for i0 in range(0, m, chunk):
+            w.set_batch(keys[i0:i0 + chunk], rows[i0:i0 + chunk])
+        dt = time.perf_counter() - t0
+        out["set_stream"] = {"rows": m, "rows_per_s": round(m / dt, 1), "GB_per_s_host": round(m * d * 4 / dt / 1e9, 3),
+                             "chunk_rows": chunk}
+        w.drop()
     if rank == 0 and G == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

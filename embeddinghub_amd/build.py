@@ -12,7 +12,10 @@ LIB = os.path.join(LIB_DIR, "libehx%s.so" % os.environ.get("EHX_LIB_SUFFIX", "")
 SOURCES = ["ehx_api.cpp", "k_flat.hip", "k_flat8.hip", "k_flat16.hip", "k_misc.hip", "k_graph.hip", "k_insert.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc", "-ffp-contract=off", "-I", os.path.join(ROOT, "include")]
+         "-fno-gpu-rdc", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+         # host side only: F16C/AVX2 for the fp32 -> binary16 conversion of rows written to fp16 spaces (every
+         # x86 host of an MI355X has them; without F16C the conversion is a software routine, ~10x slower)
+         "-Xarch_host", "-mf16c", "-Xarch_host", "-mavx2"]
 
 
 def _stale():

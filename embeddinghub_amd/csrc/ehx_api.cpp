@@ -1107,7 +1107,7 @@ int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metri
   {
     const char* env = getenv("EHX_SCAN");  // "f32": every space scans in fp32 (A/B runs, profiling)
     const bool env_f32 = env && strcmp(env, "f32") == 0;
-    s->use16 = s->params.mode == EHX_MODE_FLAT && !s->x_half && s->params.scan != EHX_SCAN_F32 && !env_f32;
+    s->use16 = s->params.mode == EHX_MODE_FLAT && s->params.scan != EHX_SCAN_F32 && !env_f32;
     s->ld16 = (uint32_t)round_up(dims, 128);
     if (s->use16) {
       HIP_TRY(hipMalloc((void**)&s->dUnsafe, sizeof(unsigned long long)));
@@ -1225,8 +1225,8 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
 // (re)build the fp16 scan copy of rows [row0, row0+n) after they were written; must follow row_stats
 static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n) {
   if (!s->use16 || n == 0) return EHX_OK;
-  HIP_TRY(launch_make_scan16(s->xf32(), row0, n, s->dims, s->ld, s->ld16, s->metric, s->dX16, s->dRowp16, s->dUnsafe,
-                             s->stream));
+  HIP_TRY(launch_make_scan16(s->dX, s->x_half, row0, n, s->dims, s->ld, s->ld16, s->metric, s->dX16, s->dRowp16,
+                             s->dUnsafe, s->stream));
   unsigned long long u = 0;
   HIP_TRY(hipMemcpyAsync(&u, s->dUnsafe, sizeof(u), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));

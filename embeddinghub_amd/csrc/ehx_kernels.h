@@ -245,8 +245,9 @@ hipError_t launch_sample_select(const float* scores, uint32_t n_rows, uint32_t q
 // scan copy of rows [row0, row0+n): X16 = fp16(x/|x|), rowp16 = (a_r, b_r) per metric.  Rows the filter
 // cannot bound (non-finite or denormal-range norms) are counted in *n_unsafe (the space then stays on
 // the fp32 scan).
-hipError_t launch_make_scan16(const float* X, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld, uint32_t ld16,
-                              int metric, __half* X16, float2* rowp16, unsigned long long* n_unsafe, hipStream_t st);
+hipError_t launch_make_scan16(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
+                              uint32_t ld16, int metric, __half* X16, float2* rowp16, unsigned long long* n_unsafe,
+                              hipStream_t st);
 // filter-side query preparation: Q16 = fp16(q/|q|) padded to [q_rows][ld16]; qgamma[q]; quv[q] = (u, v) with
 // D = u*S + v.  Queries the filter cannot bound get u = NaN (never certified -> fp32 re-run).
 hipError_t launch_prep_queries16(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld16, uint32_t q_rows,

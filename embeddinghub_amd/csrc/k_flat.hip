@@ -474,11 +474,22 @@ __global__ __launch_bounds__(64) void flat_merge_kernel(const uint64_t* __restri
   const uint32_t q = blockIdx.x;
   const uint64_t* p = part + (size_t)q * lists_stride * kprime;
   uint64_t best = seed ? merged[(size_t)q * 64 + lane] : kKeyInf;
-  for (uint32_t c = 0; c < n_chunks; ++c) {
-    const uint64_t v = lane < (int)kprime ? p[(size_t)c * kprime + lane] : kKeyInf;  // ascending
-    const uint64_t rv = __shfl(v, 63 - lane, 64);                                     // descending
-    const uint64_t m = best < rv ? best : rv;  // the 64 smallest of the union, bitonic
-    best = wave_bitonic_merge64(m, lane);
+  // Most lists have nothing to contribute (empty — all-INF — in the later passes of the cascade, or
+  // entirely above the current 64th best): look at 64 list heads at a time, one per lane, and visit only
+  // the lists whose head beats the 64th best so far.
+  for (uint32_t base = 0; base < n_chunks; base += 64) {
+    const uint32_t c_l = base + lane;
+    const uint64_t head = c_l < n_chunks ? p[(size_t)c_l * kprime] : kKeyInf;
+    uint64_t todo = __ballot(head < __shfl(best, 63, 64));
+    while (todo) {
+      const uint32_t c = base + (uint32_t)__builtin_ctzll(todo);
+      todo &= todo - 1;
+      const uint64_t v = lane < (int)kprime ? p[(size_t)c * kprime + lane] : kKeyInf;  // ascending
+      if (__shfl(v, 0, 64) >= __shfl(best, 63, 64)) continue;  // (the bar has risen since the ballot)
+      const uint64_t rv = __shfl(v, 63 - lane, 64);                                     // descending
+      const uint64_t m = best < rv ? best : rv;  // the 64 smallest of the union, bitonic
+      best = wave_bitonic_merge64(m, lane);
+    }
   }
   merged[(size_t)q * 64 + lane] = best;
   if (gthr && lane == (int)kprime - 1) gthr[q] = best;

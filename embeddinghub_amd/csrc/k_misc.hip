@@ -103,7 +103,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ bool norm_ok(float sumsq) { return sumsq == 0.0f || (sumsq > 1e-24f && sumsq < 1e30f); }
 }  // namespace
 
-__global__ __launch_bounds__(256) void make_scan16_kernel(const float* __restrict__ X, uint64_t row0, uint64_t n,
+template <typename XT>
+__global__ __launch_bounds__(256) void make_scan16_kernel(const XT* __restrict__ X, uint64_t row0, uint64_t n,
                                                           uint32_t dims, uint32_t ld, uint32_t ld16, int metric,
                                                           __half* __restrict__ X16, float2* __restrict__ rowp16,
                                                           unsigned long long* __restrict__ n_unsafe) {
@@ -111,14 +112,14 @@ __global__ __launch_bounds__(256) void make_scan16_kernel(const float* __restric
   const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   const uint64_t r = row0 + i;
-  const float* x = X + r * ld;
+  const XT* x = X + r * ld;
   float ss = 0.0f;
-  for (uint32_t c = lane; c < dims; c += 64) ss += x[c] * x[c];
+  for (uint32_t c = lane; c < dims; c += 64) ss += ld_row(x, c) * ld_row(x, c);
   ss = wave_sum(ss);
   const bool ok = norm_ok(ss);
   const float nr = ok ? __builtin_sqrtf(ss) : 0.0f;
   const float inv = nr > 0.0f ? 1.0f / nr : 0.0f;
-  for (uint32_t c = lane; c < ld16; c += 64) X16[scan16_index(r, c, ld16)] = __float2half_rn(c < dims ? x[c] * inv : 0.0f);
+  for (uint32_t c = lane; c < ld16; c += 64) X16[scan16_index(r, c, ld16)] = __float2half_rn(c < dims ? ld_row(x, c) * inv : 0.0f);
   if (lane == 0) {
     float2 p;
     if (!ok) {
@@ -135,11 +136,17 @@ __global__ __launch_bounds__(256) void make_scan16_kernel(const float* __restric
   }
 }
 
-hipError_t launch_make_scan16(const float* X, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld, uint32_t ld16,
-                              int metric, __half* X16, float2* rowp16, unsigned long long* n_unsafe, hipStream_t st) {
+hipError_t launch_make_scan16(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
+                              uint32_t ld16, int metric, __half* X16, float2* rowp16, unsigned long long* n_unsafe,
+                              hipStream_t st) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(make_scan16_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, X, row0, n, dims, ld, ld16,
-                     metric, X16, rowp16, n_unsafe);
+  const dim3 grid((uint32_t)((n + 3) / 4));
+  if (x_half)
+    hipLaunchKernelGGL(make_scan16_kernel<__half>, grid, dim3(256), 0, st, (const __half*)X, row0, n, dims, ld, ld16,
+                       metric, X16, rowp16, n_unsafe);
+  else
+    hipLaunchKernelGGL(make_scan16_kernel<float>, grid, dim3(256), 0, st, (const float*)X, row0, n, dims, ld, ld16,
+                       metric, X16, rowp16, n_unsafe);
   return hipGetLastError();
 }
 

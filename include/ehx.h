@@ -63,7 +63,7 @@ enum {
   EHX_DTYPE_F32 = 0, /* rows stored as given (the reference's std::vector<float>, index.h:14)                     */
   EHX_DTYPE_F16 = 1  /* flat mode only: rows rounded to IEEE binary16 (nearest-even) when written and widened
                         exactly to fp32 wherever they are read — results are those of an F32 space fed the
-                        rounded rows; halves the HBM footprint and the scan's bytes (BASELINE.json configs[5]);
+                        rounded rows; halves the footprint of the stored rows (BASELINE.json configs[5]);
                         the API still speaks fp32 (Get returns the widened stored values)                         */
 };
 enum {
@@ -89,7 +89,7 @@ typedef struct ehx_params {
   uint32_t build_batch;     /* graph mode: rows inserted concurrently per round by bulk loads
                                (ehx_fill_synthetic); 0 = auto, 1 = strictly sequential (hnswlib order).
                                ehx_set / ehx_set_batch always insert sequentially.                     */
-  uint32_t scan;            /* flat mode, fp32 rows: EHX_SCAN_AUTO (0) = fp16 matrix-core filter scan in front of
+  uint32_t scan;            /* flat mode: EHX_SCAN_AUTO (0) = fp16 matrix-core filter scan in front of
                                the canonical fp32 re-rank, with an fp32 re-scan of every query the filter cannot
                                certify — results identical to EHX_SCAN_F32 (1) = fp32 matrix-core scan only.   */
   uint32_t reserved[6];

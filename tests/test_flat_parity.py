@@ -260,12 +260,13 @@ def test_nan_and_inf_rows_do_not_poison_results():
     (70000, 64, 64, 10),     # many tiles per chunk
 ])
 @pytest.mark.parametrize("em,om", METRICS)
-def test_fp16_rows_parity(n, d, nq, k, em, om):
+@pytest.mark.parametrize("scan", [ehx.SCAN_AUTO, ehx.SCAN_F32])
+def test_fp16_rows_parity(n, d, nq, k, em, om, scan):
     rng = np.random.default_rng(n * 17 + d)
     X = rng.standard_normal((n, d)).astype(np.float32)
     Q = rng.standard_normal((nq, d)).astype(np.float32)
     Xh = X.astype(np.float16).astype(np.float32)
-    s = ehx.Space.unique("h16", d, metric=em, dtype=ehx.DTYPE_F16)
+    s = ehx.Space.unique("h16", d, metric=em, dtype=ehx.DTYPE_F16, scan=scan)
     s.set_batch(_keys(n), X)
     _check(s, Xh, Q, k, om)
     assert s.get("k7").tobytes() == Xh[7].tobytes()  # Get returns the stored (rounded) row
