@@ -37,7 +37,8 @@ class Stats(C.Structure):
                 ("n_uncertified", C.c_uint64), ("bytes_algorithmic", C.c_uint64),
                 ("last_scan_ms", C.c_double), ("last_total_ms", C.c_double),
                 ("scan_ms_mean", C.c_double), ("scan_launches", C.c_uint64),
-                ("n_filter_queries", C.c_uint64), ("n_filter_fallback", C.c_uint64)]
+                ("n_filter_queries", C.c_uint64), ("n_filter_fallback", C.c_uint64),
+                ("n_exhaustive", C.c_uint64)]
 
 
 # every symbol include/ehx.h declares: name -> (restype, argtypes)

@@ -151,7 +151,7 @@ struct ehx_space {
   DevBuf<uint32_t> dUflags, dFbCnt;
   DevBuf<uint64_t> dFbIds;
   unsigned long long* dUncert16 = nullptr;  // queries the filter pass could not certify
-  std::atomic<uint64_t> n_filter_queries{0}, n_filter_fallback{0};
+  std::atomic<uint64_t> n_filter_queries{0}, n_filter_fallback{0}, n_exhaustive{0}, n_uncertified_final{0};
   float* hStage = nullptr;  // pinned staging (Set / Get / query upload)
   size_t hStageBytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -819,16 +819,16 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
     HIP_TRY(hipMalloc((void**)&s->dUncert, 2 * sizeof(unsigned long long)));  // [0] uncertified, [1] scan error
     HIP_TRY(hipMemset(s->dUncert, 0, 2 * sizeof(unsigned long long)));
   }
+  if ((rc = s->dUflags.ensure(p.q_rows))) return rc;
+  if (!s->dUncert16) {
+    HIP_TRY(hipMalloc((void**)&s->dUncert16, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(s->dUncert16, 0, sizeof(unsigned long long)));
+  }
   if (f16) {
     if ((rc = s->dQ16.ensure(scanq16_halves(p.q_rows, s->ld16)))) return rc;
     if ((rc = s->dQgamma.ensure(p.q_rows))) return rc;
     if ((rc = s->dQuv.ensure(p.q_rows))) return rc;
-    if ((rc = s->dUflags.ensure(p.q_rows))) return rc;
     if (sample && (rc = s->dSample.ensure((size_t)kSampleTiles * kTileRows16 * p.q_rows))) return rc;
-    if (!s->dUncert16) {
-      HIP_TRY(hipMalloc((void**)&s->dUncert16, sizeof(unsigned long long)));
-      HIP_TRY(hipMemset(s->dUncert16, 0, sizeof(unsigned long long)));
-    }
   }
   // scratch buffers are shared by all callers: order this pipeline after the previous one even
   // when it was enqueued on a different stream
@@ -926,7 +926,7 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
   r.out_ids = d_ids;
   r.out_dist = d_dist;
   r.out_count = d_count;
-  r.n_uncertified = f16 ? s->dUncert16 : s->dUncert;
+  r.n_uncertified = s->dUncert16;  // verdict counter of this pass (the caller reads and clears it)
   r.nq = (uint32_t)nq;
   r.k = k;
   r.kprime = p.kprime;
@@ -934,10 +934,8 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
   r.dims = s->dims;
   r.ld = s->ld;
   r.metric = s->metric;
-  if (f16) {
-    r.quv = s->dQuv.p;
-    r.uncert_flags = s->dUflags.p;
-  }
+  if (f16) r.quv = s->dQuv.p;
+  r.uncert_flags = s->dUflags.p;
   HIP_TRY(launch_rerank(r, st));
   HIP_TRY(hipEventRecord(s->ev[3], st));
   s->ev_valid = true;
@@ -952,55 +950,137 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
   return EHX_OK;
 }
 
-// device pipeline of a flat space.  fp32 spaces scan with the fp16 filter first; the (rare) queries
-// whose top-k the filter cannot certify are re-run through the fp32 scan, so the results are always
-// those of the fp32 scan + canonical re-rank.
+// Last-resort pass: canonical distance of every row for `nq` queries (k_flat.hip: exhaustive_kernel), merged
+// and emitted through the re-rank with the certification switched off (the keys are exact).
+int exhaustive_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k, uint64_t* d_ids,
+                    float* d_dist, uint32_t* d_count) {
+  constexpr uint32_t kRowsPerBlock = 8192;
+  const uint32_t n_blocks = (uint32_t)((s->n + kRowsPerBlock - 1) / kRowsPerBlock);
+  int rc;
+  if ((rc = s->dQ.ensure(nq * s->ld))) return rc;
+  if ((rc = s->dPart.ensure(nq * n_blocks * 64))) return rc;
+  if ((rc = s->dMerged.ensure(nq * 64))) return rc;
+  if ((rc = s->dUflags.ensure(nq))) return rc;
+  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
+  HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, (uint32_t)nq, s->metric, s->dQ.p, st));
+  HIP_TRY(launch_exhaustive(s->dQ.p, s->dX, s->x_half, s->dInv, (uint32_t)s->n, s->dims, s->ld, s->metric,
+                            kRowsPerBlock, n_blocks, (uint32_t)nq, s->dPart.p, st));
+  HIP_TRY(launch_flat_merge(s->dPart.p, (uint32_t)nq, n_blocks, 64, s->dMerged.p, st, n_blocks));
+  RerankArgs r;
+  r.Q = s->dQ.p;
+  r.X = s->dX;
+  r.x_half = (uint32_t)s->x_half;
+  r.inv_norm = s->dInv;
+  r.merged = s->dMerged.p;
+  r.out_ids = d_ids;
+  r.out_dist = d_dist;
+  r.out_count = d_count;
+  r.n_uncertified = s->dUncert16;
+  r.nq = (uint32_t)nq;
+  r.k = k;
+  r.kprime = 64;
+  r.n = (uint32_t)s->n;
+  r.dims = s->dims;
+  r.ld = s->ld;
+  r.metric = s->metric;
+  r.uncert_flags = s->dUflags.p;
+  r.exact_keys = 1;
+  HIP_TRY(launch_rerank(r, st));
+  HIP_TRY(hipEventRecord(s->ev[3], st));
+  s->ev_valid = true;
+  s->n_dist += (uint64_t)nq * s->n;
+  return EHX_OK;
+}
+
+// Device pipeline of a flat space: up to three stages, each run only for the queries the previous one
+// could not certify, so the answer is always the exhaustive fp32 answer in the oracle's arithmetic:
+//   1. fp16 matrix-core filter scan + certified re-rank      (all queries; spaces with the scan copy)
+//   2. fp32 matrix-core scan + certified re-rank              (what stage 1 could not certify / fp32-only spaces)
+//   3. canonical distance of every row                        (what stage 2 could not certify: near-ties finer
+//                                                              than fp32 rounding; at most kMaxExhaustive queries
+//                                                              per call, the rest is reported in n_uncertified)
+// One host round trip (8 bytes) per stage to read its verdict.
 int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k,
                       uint64_t* d_ids, float* d_dist, uint32_t* d_count) {
   if (k == 0 || nq == 0) return EHX_OK;
   if (k > EHX_MAX_K) return fail(EHX_EUNSUPPORTED, "k=%u exceeds EHX_MAX_K=%u", k, EHX_MAX_K);
   if (nq > (1u << 24)) return fail(EHX_EINVAL, "too many queries in one call: %zu", nq);
   if (s->params.mode == EHX_MODE_GRAPH) return knn_graph_locked(s, st, nq, d_queries, k, d_ids, d_dist, d_count);
-  const bool f16 = s->use16 && s->h_unsafe == 0 && s->n > 0;
-  if (!f16) return flat_pass(s, st, nq, d_queries, k, d_ids, d_dist, d_count, false, true);
-  int rc = flat_pass(s, st, nq, d_queries, k, d_ids, d_dist, d_count, true, true);
-  if (rc) return rc;
-  s->n_filter_queries += nq;
-  // certification verdict of the filter pass (the only host round trip of the pipeline)
-  unsigned long long n_unc = 0;
-  HIP_TRY(hipMemcpyAsync(&n_unc, s->dUncert16, sizeof(n_unc), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  constexpr size_t kMaxExhaustive = 32;
+  enum { kFilter, kF32, kExhaustive };
+  int rc;
+  // run one stage on `subset` (nullptr = every query); *unc = global indices it could not certify
+  auto stage = [&](int kind, const std::vector<uint32_t>* subset, bool count_stats, std::vector<uint32_t>* unc) -> int {
+    const size_t m = subset ? subset->size() : nq;
+    const float* q = d_queries;
+    uint64_t* oi = d_ids;
+    float* od = d_dist;
+    uint32_t* oc = d_count;
+    if (subset) {
+      if ((rc = s->dFbQ.ensure(m * s->dims))) return rc;
+      if ((rc = s->dFbIds.ensure(m * k))) return rc;
+      if ((rc = s->dFbDist.ensure(m * k))) return rc;
+      if ((rc = s->dFbCnt.ensure(m))) return rc;
+      for (size_t j = 0; j < m; ++j)
+        HIP_TRY(hipMemcpyAsync(s->dFbQ.p + j * s->dims, d_queries + (size_t)(*subset)[j] * s->dims,
+                               s->dims * sizeof(float), hipMemcpyDeviceToDevice, st));
+      q = s->dFbQ.p;
+      oi = s->dFbIds.p;
+      od = s->dFbDist.p;
+      oc = s->dFbCnt.p;
+    }
+    if (kind == kExhaustive) rc = exhaustive_pass(s, st, m, q, k, oi, od, oc);
+    else rc = flat_pass(s, st, m, q, k, oi, od, oc, kind == kFilter, count_stats);
+    if (rc) return rc;
+    if (subset) {
+      for (size_t j = 0; j < m; ++j) {
+        const size_t g = (*subset)[j];
+        HIP_TRY(hipMemcpyAsync(d_ids + g * k, oi + j * k, k * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_dist + g * k, od + j * k, k * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_count + g, oc + j, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+      }
+      HIP_TRY(hipEventRecord(s->ev[3], st));
+    }
+    // verdict
+    unc->clear();
+    unsigned long long n_unc = 0;
+    HIP_TRY(hipMemcpyAsync(&n_unc, s->dUncert16, sizeof(n_unc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
 #if defined(EHX_ABL) && EHX_ABL
-  return EHX_OK;  // profiling builds with ablated (wrong-by-construction) kernels: time the filter only
+    return EHX_OK;  // profiling builds with ablated (wrong-by-construction) kernels: time the first stage only
 #endif
-  if (n_unc == 0) return EHX_OK;
-  HIP_TRY(hipMemsetAsync(s->dUncert16, 0, sizeof(unsigned long long), st));
-  std::vector<uint32_t> flags(nq);
-  HIP_TRY(hipMemcpyAsync(flags.data(), s->dUflags.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  std::vector<uint32_t> redo;
-  for (size_t i = 0; i < nq; ++i)
-    if (flags[i]) redo.push_back((uint32_t)i);
-  s->n_filter_fallback += redo.size();
-  if (redo.empty()) return EHX_OK;
-  if (redo.size() * 2 > nq)  // most of the batch: just run it all through the fp32 scan
-    return flat_pass(s, st, nq, d_queries, k, d_ids, d_dist, d_count, false, false);
-  const size_t m = redo.size();
-  if ((rc = s->dFbQ.ensure(m * s->dims))) return rc;
-  if ((rc = s->dFbIds.ensure(m * k))) return rc;
-  if ((rc = s->dFbDist.ensure(m * k))) return rc;
-  if ((rc = s->dFbCnt.ensure(m))) return rc;
-  for (size_t j = 0; j < m; ++j)
-    HIP_TRY(hipMemcpyAsync(s->dFbQ.p + j * s->dims, d_queries + (size_t)redo[j] * s->dims, s->dims * sizeof(float),
-                           hipMemcpyDeviceToDevice, st));
-  if ((rc = flat_pass(s, st, m, s->dFbQ.p, k, s->dFbIds.p, s->dFbDist.p, s->dFbCnt.p, false, false))) return rc;
-  for (size_t j = 0; j < m; ++j) {
-    const size_t q = redo[j];
-    HIP_TRY(hipMemcpyAsync(d_ids + q * k, s->dFbIds.p + j * k, k * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_dist + q * k, s->dFbDist.p + j * k, k * sizeof(float), hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_count + q, s->dFbCnt.p + j, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    if (n_unc == 0) return EHX_OK;
+    HIP_TRY(hipMemsetAsync(s->dUncert16, 0, sizeof(unsigned long long), st));
+    std::vector<uint32_t> flags(m);
+    HIP_TRY(hipMemcpyAsync(flags.data(), s->dUflags.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t j = 0; j < m; ++j)
+      if (flags[j]) unc->push_back(subset ? (*subset)[j] : (uint32_t)j);
+    return EHX_OK;
+  };
+
+  std::vector<uint32_t> todo, next;
+  bool all = true;  // `todo` = every query
+  bool counted = false;
+  if (s->use16 && s->h_unsafe == 0 && s->n > 0) {
+    if ((rc = stage(kFilter, nullptr, true, &next))) return rc;
+    counted = true;
+    s->n_filter_queries += nq;
+    s->n_filter_fallback += next.size();
+    if (next.empty()) return EHX_OK;
+    todo.swap(next);
+    all = todo.size() * 2 > nq;  // most of the batch: just run it all through the fp32 scan
   }
-  HIP_TRY(hipEventRecord(s->ev[3], st));
+  if ((rc = stage(kF32, all ? nullptr : &todo, !counted, &next))) return rc;
+  if (next.empty()) return EHX_OK;
+  todo.swap(next);
+  if (todo.size() > kMaxExhaustive) {
+    s->n_uncertified_final += todo.size();
+    return EHX_OK;
+  }
+  if ((rc = stage(kExhaustive, &todo, false, &next))) return rc;
+  s->n_exhaustive += todo.size();
+  s->n_uncertified_final += next.size();  // (always 0: exact keys are not certified)
   return EHX_OK;
 }
 
@@ -1739,6 +1819,8 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
   out->bytes_algorithmic = s->bytes_algo;
   out->n_filter_queries = s->n_filter_queries;
   out->n_filter_fallback = s->n_filter_fallback;
+  out->n_exhaustive = s->n_exhaustive;
+  out->n_uncertified = s->n_uncertified_final;
   if (s->dGraphCounters) {
     unsigned long long g[3] = {0, 0, 0};
     HIP_TRY(hipMemcpy(g, s->dGraphCounters, sizeof(g), hipMemcpyDeviceToHost));
@@ -1750,7 +1832,7 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
   if (s->dUncert) {
     unsigned long long u[2] = {0, 0};
     HIP_TRY(hipMemcpy(u, s->dUncert, sizeof(u), hipMemcpyDeviceToHost));
-    out->n_uncertified = u[0];
+    (void)u[0];
     if (u[1]) return fail(EHX_EINTERNAL, "scan kernel tripped its bounded-retry guard %llu times", u[1]);
   }
   if (s->ev_valid) {
@@ -1782,6 +1864,8 @@ int ehx_stats_reset(ehx_space* s) {
   s->bytes_algo = 0;
   s->n_filter_queries = 0;
   s->n_filter_fallback = 0;
+  s->n_exhaustive = 0;
+  s->n_uncertified_final = 0;
   s->ring_count = 0;
   if (s->dUncert) HIP_TRY(hipMemset(s->dUncert, 0, 2 * sizeof(unsigned long long)));
   if (s->dGraphCounters) HIP_TRY(hipMemset(s->dGraphCounters, 0, 3 * sizeof(unsigned long long)));

@@ -279,8 +279,13 @@ struct RerankArgs {
   // nullptr for the fp32 scan.
   const float2* quv = nullptr;
   uint32_t* uncert_flags = nullptr;  // [nq] 1 = not certified (optional)
+  uint32_t exact_keys = 0;           // keys come from launch_exhaustive (exact distances): skip the certification
 };
 hipError_t launch_rerank(const RerankArgs& a, hipStream_t st);
+// canonical distance of every row for each of nq prepared queries: out[q][block][64] best (distance, id) keys
+hipError_t launch_exhaustive(const float* Q, const void* X, int x_half, const float* inv_norm, uint32_t n, uint32_t dims,
+                             uint32_t ld, int metric, uint32_t rows_per_block, uint32_t n_blocks, uint32_t nq,
+                             uint64_t* out, hipStream_t st);
 
 // prepared queries: copy into the padded [q_rows][ld] buffer, L2-normalise for cosine
 hipError_t launch_prep_queries(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld,

@@ -593,7 +593,9 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
     // provably the exhaustive top-k.  margin bounds the fp32 rounding gap between the MFMA-order
     // score and the canonical-order distance.  (Skipped when every row is a candidate.)
     bool uncert = false;
-    if (a.n > a.kprime && cnt == a.k && a.k > 0) {
+    if (a.exact_keys) {
+      // the keys are canonical distances of every row (exhaustive pass): nothing to certify
+    } else if (a.n > a.kprime && cnt == a.k && a.k > 0) {
       float worst = -__builtin_inff();
       for (int j = 0; j < 64; ++j)
         if (approx[j] != __builtin_inff() && approx[j] > worst) worst = approx[j];
@@ -622,6 +624,60 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
       if (a.uncert_flags) a.uncert_flags[q] = uncert ? 1u : 0u;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Last resort for a query whose top-k not even the fp32 scan can certify (near-ties finer than the
+// fp32 rounding of the scan's arithmetic): the canonical distance of EVERY row, exactly as the re-rank
+// computes it, best 64 keys (distance, id) per block of `rows_per_block` rows.  HBM-bound and slow
+// (the whole shard per query) — the engine runs it for a handful of queries per batch at most.
+// Grid (n_blocks, n_queries); the keys are exact, so their merge + re-rank needs no certification.
+// ---------------------------------------------------------------------------------------------
+template <typename XT>
+__global__ __launch_bounds__(256) void exhaustive_kernel(const float* __restrict__ Q, const XT* __restrict__ X,
+                                                         const float* __restrict__ inv_norm, uint32_t n, uint32_t dims,
+                                                         uint32_t ld, int metric, uint32_t rows_per_block,
+                                                         uint64_t* __restrict__ out) {
+  __shared__ uint64_t keys[64];
+  const int tid = threadIdx.x;
+  const uint32_t b = blockIdx.x, j = blockIdx.y;
+  const int g = tid >> 2, sub = tid & 3;
+  const float* qv = Q + (size_t)j * ld;
+  const bool scale_x = metric == 2;
+  const uint32_t r0 = b * rows_per_block;
+  const uint32_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  uint64_t best = kKeyInf;
+  for (uint32_t base = r0; base < r1; base += 64) {
+    const uint32_t id = base + (uint32_t)g;
+    float d = __builtin_inff();
+    if (id < r1) {
+      const float xs = scale_x ? inv_norm[id] : 1.0f;
+      d = canon_dist(metric == 0 ? 0 : 1, qv, X + (size_t)id * ld, xs, scale_x, dims, sub);
+    }
+    if (sub == 0) keys[g] = id < r1 ? (((uint64_t)f32_to_ordered(d) << 32) | id) : kKeyInf;
+    __syncthreads();
+    if (tid < 64) {
+      const uint64_t key = wave_sort64(keys[tid], tid);
+      const uint64_t rv = __shfl(key, 63 - tid, 64);
+      const uint64_t m = best < rv ? best : rv;
+      best = wave_bitonic_merge64(m, tid);
+    }
+    __syncthreads();
+  }
+  if (tid < 64) out[((size_t)j * gridDim.x + b) * 64 + tid] = best;
+}
+
+hipError_t launch_exhaustive(const float* Q, const void* X, int x_half, const float* inv_norm, uint32_t n, uint32_t dims,
+                             uint32_t ld, int metric, uint32_t rows_per_block, uint32_t n_blocks, uint32_t nq,
+                             uint64_t* out, hipStream_t st) {
+  const dim3 grid(n_blocks, nq);
+  if (x_half)
+    hipLaunchKernelGGL(exhaustive_kernel<__half>, grid, dim3(256), 0, st, Q, (const __half*)X, inv_norm, n, dims, ld,
+                       metric, rows_per_block, out);
+  else
+    hipLaunchKernelGGL(exhaustive_kernel<float>, grid, dim3(256), 0, st, Q, (const float*)X, inv_norm, n, dims, ld,
+                       metric, rows_per_block, out);
+  return hipGetLastError();
 }
 
 hipError_t launch_rerank(const RerankArgs& a, hipStream_t st) {

@@ -103,7 +103,8 @@ typedef struct ehx_stats_t {
   uint64_t n_dist;           /* distances actually evaluated (one per vector row fetched)            */
   uint64_t n_hops;           /* graph nodes expanded (graph mode)                                    */
   uint64_t n_rerank;         /* candidates re-ranked in canonical order                              */
-  uint64_t n_uncertified;    /* queries whose top-k could not be certified exact by the slack bound  */
+  uint64_t n_uncertified;    /* queries whose top-k could not be certified exact by any stage (only when
+                                more than 32 queries of one call need the exhaustive stage)         */
   uint64_t bytes_algorithmic;/* SURVEY §8d algorithmic bytes of the scans/searches served            */
   double   last_scan_ms;     /* device time of the last scan/search kernel (HIP events)              */
   double   last_total_ms;    /* device time of the last full ehx_knn* pipeline                       */
@@ -111,6 +112,7 @@ typedef struct ehx_stats_t {
   uint64_t scan_launches;    /* number of launches averaged in scan_ms_mean                          */
   uint64_t n_filter_queries; /* queries answered through the fp16 filter scan                        */
   uint64_t n_filter_fallback;/* ... of which the filter could not certify and the fp32 scan re-ran   */
+  uint64_t n_exhaustive;     /* queries answered by the exhaustive canonical pass (fp32 scan uncertified) */
 } ehx_stats_t;
 
 /* ---- process / device ---- */

@@ -203,6 +203,19 @@ def test_filter_scale_invariance_and_fallback(em, om):
     if em != ehx.METRIC_IP:  # (raw inner products of these rows are spread far enough for the filter)
         assert st["n_filter_fallback"] >= 1
     s.drop()
+    # 200 rows within 1e-4 of each other: their distances to the query differ by less than the fp32 rounding
+    # of ANY matrix-core arithmetic, so not even the fp32 scan can certify — the exhaustive canonical pass
+    # has to produce the oracle's answer
+    Z = rng.standard_normal((3000, d)).astype(np.float32)
+    Z[:200] = base * (1.0 + 1e-4 * rng.standard_normal((200, d)).astype(np.float32))
+    s = ehx.Space.unique("neardups", d, metric=em)
+    s.set_batch(_keys(3000), Z)
+    _check(s, Z, np.stack([base, Z[5]]), 10, om)
+    st = s.stats()
+    assert st["n_uncertified"] == 0
+    if em != ehx.METRIC_IP:
+        assert st["n_exhaustive"] >= 1
+    s.drop()
 
 
 def test_incremental_set_update_and_growth_match_oracle():
