@@ -1632,17 +1632,27 @@ int ehx_knn_by_key(ehx_space* s, const char* key, size_t klen, uint32_t k, uint6
   return EHX_OK;
 }
 
-int ehx_merge_topk_device(void* stream, size_t n_queries, uint32_t k, uint32_t n_lists, const uint64_t* d_ids,
-                          const float* d_dist, const uint32_t* d_count, uint64_t* d_out_ids, float* d_out_dist,
-                          uint32_t* d_out_count) {
+int ehx_merge_topk_strided_device(void* stream, size_t n_queries, uint32_t k, uint32_t n_lists, const uint64_t* d_ids,
+                                  size_t ids_stride, const float* d_dist, size_t dist_stride, const uint32_t* d_count,
+                                  size_t count_stride, uint64_t* d_out_ids, float* d_out_dist,
+                                  uint32_t* d_out_count) {
   if (n_queries == 0 || k == 0) return EHX_OK;
   if (k > 64) return fail(EHX_EUNSUPPORTED, "merge supports k <= 64");
   if (!d_ids || !d_dist || !d_out_ids || !d_out_dist) return fail(EHX_EINVAL, "NULL device pointer");
+  if (ids_stride % 8 || dist_stride % 4 || count_stride % 4) return fail(EHX_EINVAL, "misaligned list stride");
   int rc = ehx_init(nullptr, 0);
   if (rc) return rc;
   HIP_TRY(launch_merge_lists(d_ids, d_dist, d_count, (uint32_t)n_queries, k, n_lists, d_out_ids, d_out_dist,
-                             d_out_count, (hipStream_t)stream));
+                             d_out_count, (hipStream_t)stream, ids_stride, dist_stride, count_stride));
   return EHX_OK;
+}
+
+int ehx_merge_topk_device(void* stream, size_t n_queries, uint32_t k, uint32_t n_lists, const uint64_t* d_ids,
+                          const float* d_dist, const uint32_t* d_count, uint64_t* d_out_ids, float* d_out_dist,
+                          uint32_t* d_out_count) {
+  return ehx_merge_topk_strided_device(stream, n_queries, k, n_lists, d_ids, n_queries * k * sizeof(uint64_t), d_dist,
+                                       n_queries * k * sizeof(float), d_count, n_queries * sizeof(uint32_t),
+                                       d_out_ids, d_out_dist, d_out_count);
 }
 
 int ehx_gen_rows_device(void* stream, uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims, int normalize,

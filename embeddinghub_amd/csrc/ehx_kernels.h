@@ -350,8 +350,9 @@ hipError_t launch_insert_link(const InsertArgs& a, uint32_t n_items, const uint3
                               const uint32_t* kind, const uint32_t* inc_off, const uint32_t* inc_ids, hipStream_t st);
 
 // k-way merge of per-shard (dist, id) result lists [n_lists][nq][k] -> [nq][k]
-hipError_t launch_merge_lists(const uint64_t* ids, const float* dist, const uint32_t* count,
-                              uint32_t nq, uint32_t k, uint32_t n_lists, uint64_t* out_ids,
-                              float* out_dist, uint32_t* out_count, hipStream_t st);
+hipError_t launch_merge_lists(const uint64_t* ids, const float* dist, const uint32_t* count, uint32_t nq,
+                              uint32_t k, uint32_t n_lists, uint64_t* out_ids, float* out_dist,
+                              uint32_t* out_count, hipStream_t st, size_t ids_stride, size_t dist_stride,
+                              size_t count_stride);
 
 }  // namespace ehx

@@ -692,7 +692,8 @@ hipError_t launch_rerank(const RerankArgs& a, hipStream_t st) {
 __global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t* __restrict__ ids,
                                                          const float* __restrict__ dist,
                                                          const uint32_t* __restrict__ count, uint32_t nq,
-                                                         uint32_t k, uint32_t n_lists,
+                                                         uint32_t k, uint32_t n_lists, size_t ids_stride,
+                                                         size_t dist_stride, size_t count_stride,
                                                          uint64_t* __restrict__ out_ids,
                                                          float* __restrict__ out_dist,
                                                          uint32_t* __restrict__ out_count) {
@@ -705,11 +706,13 @@ __global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t* __restr
   uint64_t bi = ~0ull;
   uint32_t total = 0;
   for (uint32_t l = 0; l < n_lists; ++l) {
-    const size_t base = ((size_t)l * nq + q) * k;
-    const uint32_t c = count ? count[(size_t)l * nq + q] : k;
+    // list l of each array starts l * stride BYTES after list 0 (natural layout or one packed gather buffer)
+    const uint64_t* il = (const uint64_t*)((const char*)ids + l * ids_stride) + (size_t)q * k;
+    const float* dl = (const float*)((const char*)dist + l * dist_stride) + (size_t)q * k;
+    const uint32_t c = count ? ((const uint32_t*)((const char*)count + l * count_stride))[q] : k;
     total += c;
-    float d = (lane < (int)k && (uint32_t)lane < c) ? dist[base + lane] : __builtin_inff();
-    uint64_t i = (lane < (int)k && (uint32_t)lane < c) ? ids[base + lane] : ~0ull;
+    float d = (lane < (int)k && (uint32_t)lane < c) ? dl[lane] : __builtin_inff();
+    uint64_t i = (lane < (int)k && (uint32_t)lane < c) ? il[lane] : ~0ull;
     // reverse incoming list, elementwise min by (dist, id), bitonic merge on the pair
     const float rd = __shfl(d, 63 - lane, 64);
     const uint64_t ri = __shfl(i, 63 - lane, 64);
@@ -741,9 +744,10 @@ __global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t* __restr
 
 hipError_t launch_merge_lists(const uint64_t* ids, const float* dist, const uint32_t* count, uint32_t nq,
                               uint32_t k, uint32_t n_lists, uint64_t* out_ids, float* out_dist,
-                              uint32_t* out_count, hipStream_t st) {
-  hipLaunchKernelGGL(merge_lists_kernel, dim3(nq), dim3(64), 0, st, ids, dist, count, nq, k, n_lists,
-                     out_ids, out_dist, out_count);
+                              uint32_t* out_count, hipStream_t st, size_t ids_stride, size_t dist_stride,
+                              size_t count_stride) {
+  hipLaunchKernelGGL(merge_lists_kernel, dim3(nq), dim3(64), 0, st, ids, dist, count, nq, k, n_lists, ids_stride,
+                     dist_stride, count_stride, out_ids, out_dist, out_count);
   return hipGetLastError();
 }
 

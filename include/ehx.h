@@ -178,6 +178,12 @@ int ehx_knn_device(ehx_space* s, void* stream, size_t n_queries, const float* d_
 int ehx_merge_topk_device(void* stream, size_t n_queries, uint32_t k, uint32_t n_lists,
                           const uint64_t* d_ids, const float* d_dist, const uint32_t* d_count,
                           uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count);
+/* Same, with list l of each array starting l * stride BYTES after list 0 — e.g. the three arrays of every
+ * shard packed into one buffer so that ONE all-gather moves them (embeddinghub_amd/sharded.py). */
+int ehx_merge_topk_strided_device(void* stream, size_t n_queries, uint32_t k, uint32_t n_lists,
+                                  const uint64_t* d_ids, size_t ids_stride, const float* d_dist, size_t dist_stride,
+                                  const uint32_t* d_count, size_t count_stride, uint64_t* d_out_ids,
+                                  float* d_out_dist, uint32_t* d_out_count);
 
 /* ---- synthetic workload (EHX-GAUSS-1, include/ehx_datagen.h) ---- */
 /* Appends rows [row0, row0+n_rows) of dataset `seed` to the space, generated on the device;

@@ -118,3 +118,34 @@ def test_gpu_merge_kernel_matches_numpy():
         c = e_cnt[q]
         np.testing.assert_array_equal(o_ids.cpu().numpy()[q, :c], e_ids[q, :c])
         np.testing.assert_array_equal(o_dist.cpu().numpy()[q, :c], e_dist[q, :c])
+
+
+@pytest.mark.gpu
+def test_gpu_packed_gather_buffer_merges_like_the_natural_layout():
+    """The engine-side merge of ShardedSearcher reads ids/dist/count straight out of the packed all-gather
+    buffer (list stride = packed size): same result as the natural [G][nq][k] layout."""
+    from embeddinghub_amd.sharded import ShardedSearcher, _engine_merge
+    rng = np.random.default_rng(4)
+    G, nq, k = 4, 77, 10
+    ss = ShardedSearcher(0, nq, k, "cuda", local_search=lambda *a: None, merge=lambda *a: None)
+    ss.world = G  # build the gather-side views by hand (no process group in this test)
+    g_pack = torch.zeros(G * ss._P, dtype=torch.uint8, device="cuda")
+    g_ids, g_dst, g_cnt = ss._views(g_pack.view(G, ss._P))
+    dist = np.sort(rng.standard_normal((G, nq, k)).astype(np.float32), axis=2)
+    ids = np.arange(G * nq * k, dtype=np.int64).reshape(G, nq, k)
+    cnt = rng.integers(0, k + 1, size=(G, nq)).astype(np.int32)
+    g_ids.copy_(torch.from_numpy(ids))
+    g_dst.copy_(torch.from_numpy(dist))
+    g_cnt.copy_(torch.from_numpy(cnt))
+    e_ids, e_dist, e_cnt = np.full((nq, k), -1, np.int64), np.full((nq, k), np.inf, np.float32), np.zeros(nq, np.int32)
+    _np_merge(ids, dist, cnt, k, e_ids, e_dist, e_cnt)
+    o_ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    o_dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    o_cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    _engine_merge(torch.cuda.current_stream().cuda_stream)(g_ids, g_dst, g_cnt, k, o_ids, o_dist, o_cnt)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(o_cnt.cpu().numpy(), e_cnt)
+    for q in range(nq):
+        c = e_cnt[q]
+        np.testing.assert_array_equal(o_ids.cpu().numpy()[q, :c], e_ids[q, :c])
+        np.testing.assert_array_equal(o_dist.cpu().numpy()[q, :c], e_dist[q, :c])
