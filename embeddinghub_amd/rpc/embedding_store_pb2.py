@@ -35,6 +35,10 @@ _MESSAGES = {
     "DownloadRequest": [("space", 1, _STRING, False, None)],
     "DownloadResponse": [("key", 1, _STRING, False, None), ("embedding", 2, _MESSAGE, False, _EMB)],
     "Embedding": [("values", 1, _FLOAT, True, None)],
+    # catalog entries of the reference's metadata store (embedding_store_meta.proto:9-19), used by the durable log
+    "SpaceEntry": [("path", 1, _STRING, False, None), ("name", 2, _STRING, False, None)],
+    "VersionEntry": [("path", 1, _STRING, False, None), ("space", 2, _STRING, False, None),
+                     ("name", 3, _STRING, False, None), ("dims", 4, _INT32, False, None)],
 }
 
 # rpc -> (request, response, client streaming, server streaming)   embedding_store.proto:9-19

@@ -249,10 +249,19 @@ def main(argv=None):
     ap.add_argument("address", nargs="?", default="0.0.0.0:7462")  # main.cc: default port of the reference
     ap.add_argument("--metric", choices=["l2", "ip", "cosine"], default="l2")
     ap.add_argument("--workers", type=int, default=64)
+    ap.add_argument("--data-dir", default=None,
+                    help="keep every space in append-only logs under this directory and rebuild them on start "
+                         "(the reference persists to RocksDB under ./embedding_store.dat, server.cc:249)")
+    ap.add_argument("--sync", action="store_true", help="fsync the logs on every write")
     args = ap.parse_args(argv)
     import embeddinghub_amd as ehx
     metric = {"l2": ehx.METRIC_L2SQ, "ip": ehx.METRIC_IP, "cosine": ehx.METRIC_COSINE}[args.metric]
-    server, port = make_server(EngineStore(metric=metric), args.address, args.workers)
+    store = EngineStore(metric=metric)
+    if args.data_dir:
+        from .durable import DurableStore
+        store = DurableStore(store, args.data_dir, sync=args.sync)
+        print("rebuilt %d rows from %s" % (store.rebuilt_rows, args.data_dir), flush=True)
+    server, port = make_server(store, args.address, args.workers)
     server.start()
     print("Server listening on %s" % args.address, flush=True)
     server.wait_for_termination()

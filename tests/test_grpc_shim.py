@@ -6,6 +6,7 @@ CPU leg (`not gpu`): the servicer, wire contract and client run over a store bac
 (tests may use the oracle; the product never does) — this pins the gRPC layer itself.  GPU leg: the
 same suite over the engine-backed store, plus parity of NearestNeighbor with the oracle and the
 coalescing of concurrent single-query RPCs into device batches."""
+import os
 import threading
 import uuid
 
@@ -234,3 +235,67 @@ def test_engine_nearest_neighbor_matches_oracle_and_coalesces(engine_client):
     assert by_key == ["k%d" % i for i in o7[0] if i != 7][:5]
     st = ehx.Space.open(space).stats()
     assert st["n_queries"] >= 96
+
+
+# ---- durable store + rebuild-on-load (embeddinghub_amd/rpc/durable.py) -------------------------------
+def _durable_roundtrip(make_inner, tmp_path, n=3000, d=24):
+    from embeddinghub_amd.rpc.durable import DurableStore, value_header
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    st = DurableStore(make_inner(), str(tmp_path))
+    server, port = srv.make_server(st, "127.0.0.1:0", max_workers=8)
+    server.start()
+    c = EmbeddingHubClient(host="127.0.0.1", port=port)
+    c.create_space("dur", d)
+    c.multiset("dur", ((("k%d" % i), X[i].tolist()) for i in range(n)))
+    X[7] = rng.standard_normal(d).astype(np.float32)
+    c.set("dur", "k7", X[7].tolist())  # upsert: the later record wins on replay
+    c.create_space("gone", d)
+    c.set("gone", "x", X[0].tolist())
+    c.delete_space("gone")
+    c.create_space("ice", d)
+    c.set("ice", "only", X[1].tolist())
+    c.freeze_space("ice")
+    before = [list(c.nearest_neighbor("dur", 5, embedding=X[i].tolist())) for i in (3, 7, 11)]
+    c.close()
+    server.stop(0)
+    st.close()
+    # the stored value is the reference's serialized Embedding (serializer.cc:19-26)
+    rec = open(os.path.join(st._space_dir("dur"), "values.dat"), "rb").read(len(value_header(d)) + 4 * d)
+    assert rec == pb.Embedding(values=X[0].tolist()).SerializeToString()
+    # a crash mid-append leaves a torn tail: cut back to the last complete record
+    with open(os.path.join(st._space_dir("dur"), "values.dat"), "ab") as f:
+        f.write(b"\x0a\x60garbage")
+    st2 = DurableStore(make_inner(), str(tmp_path))  # restart: rebuild through the bulk write path
+    assert st2.rebuilt_rows == n + 1 + 1
+    server, port = srv.make_server(st2, "127.0.0.1:0", max_workers=8)
+    server.start()
+    c = EmbeddingHubClient(host="127.0.0.1", port=port)
+    assert list(c.get("dur", "k7")) == X[7].tolist() and list(c.get("dur", "k2999")) == X[2999].tolist()
+    assert [list(c.nearest_neighbor("dur", 5, embedding=X[i].tolist())) for i in (3, 7, 11)] == before
+    with pytest.raises(grpc.RpcError) as e:
+        c.get("gone", "x")
+    assert e.value.code() == grpc.StatusCode.NOT_FOUND
+    with pytest.raises(TypeError):
+        c.set("ice", "only", X[2].tolist())  # still frozen after the restart
+    c.close()
+    server.stop(0)
+    st2.close()
+
+
+def test_durable_store_rebuilds_on_load_over_oracle_store(tmp_path):
+    _durable_roundtrip(OracleStore, tmp_path)
+
+
+@pytest.mark.gpu
+def test_durable_store_rebuilds_on_load_over_engine(tmp_path):
+    pytest.importorskip("embeddinghub_amd")
+    made = []
+
+    def make():
+        for s_ in made:  # "restart": the previous process's spaces are gone
+            for name in ("dur", "ice"):
+                s_.delete_space(name)
+        made.append(srv.EngineStore())
+        return made[-1]
+    _durable_roundtrip(make, tmp_path, n=20000, d=64)
