@@ -950,45 +950,62 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
   return EHX_OK;
 }
 
-// Last-resort pass: canonical distance of every row for `nq` queries (k_flat.hip: exhaustive_kernel), merged
-// and emitted through the re-rank with the certification switched off (the keys are exact).
+// Exhaustive canonical pass: the canonical distance of every row for `nq` queries (k_flat.hip:
+// exhaustive_kernel), merged and emitted through the re-rank with the certification switched off (the keys
+// are exact).  Serves (a) queries no matrix-core scan can certify and (b) requests with k > EHX_MAX_K, which
+// it answers in pages of 64 results (each page keeps the keys strictly above the previous page's last).
 int exhaustive_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k, uint64_t* d_ids,
                     float* d_dist, uint32_t* d_count) {
   constexpr uint32_t kRowsPerBlock = 8192;
   const uint32_t n_blocks = (uint32_t)((s->n + kRowsPerBlock - 1) / kRowsPerBlock);
+  const uint32_t pages = (k + 63) / 64;
   int rc;
   if ((rc = s->dQ.ensure(nq * s->ld))) return rc;
   if ((rc = s->dPart.ensure(nq * n_blocks * 64))) return rc;
   if ((rc = s->dMerged.ensure(nq * 64))) return rc;
   if ((rc = s->dUflags.ensure(nq))) return rc;
+  if (pages > 1 && (rc = s->dGthr.ensure(nq + 8))) return rc;
+  if (!s->dUncert16) {
+    HIP_TRY(hipMalloc((void**)&s->dUncert16, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(s->dUncert16, 0, sizeof(unsigned long long)));
+  }
   if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
+  HIP_TRY(hipEventRecord(s->ev[0], st));
   HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, (uint32_t)nq, s->metric, s->dQ.p, st));
-  HIP_TRY(launch_exhaustive(s->dQ.p, s->dX, s->x_half, s->dInv, (uint32_t)s->n, s->dims, s->ld, s->metric,
-                            kRowsPerBlock, n_blocks, (uint32_t)nq, s->dPart.p, st));
-  HIP_TRY(launch_flat_merge(s->dPart.p, (uint32_t)nq, n_blocks, 64, s->dMerged.p, st, n_blocks));
-  RerankArgs r;
-  r.Q = s->dQ.p;
-  r.X = s->dX;
-  r.x_half = (uint32_t)s->x_half;
-  r.inv_norm = s->dInv;
-  r.merged = s->dMerged.p;
-  r.out_ids = d_ids;
-  r.out_dist = d_dist;
-  r.out_count = d_count;
-  r.n_uncertified = s->dUncert16;
-  r.nq = (uint32_t)nq;
-  r.k = k;
-  r.kprime = 64;
-  r.n = (uint32_t)s->n;
-  r.dims = s->dims;
-  r.ld = s->ld;
-  r.metric = s->metric;
-  r.uncert_flags = s->dUflags.p;
-  r.exact_keys = 1;
-  HIP_TRY(launch_rerank(r, st));
+  HIP_TRY(hipEventRecord(s->ev[1], st));
+  for (uint32_t pg = 0; pg < pages; ++pg) {
+    const uint64_t* floor = pg ? s->dGthr.p : nullptr;
+    HIP_TRY(launch_exhaustive(s->dQ.p, s->dX, s->x_half, s->dInv, (uint32_t)s->n, s->dims, s->ld, s->metric,
+                              kRowsPerBlock, n_blocks, (uint32_t)nq, floor, s->dPart.p, st));
+    HIP_TRY(launch_flat_merge(s->dPart.p, (uint32_t)nq, n_blocks, 64, s->dMerged.p, st, n_blocks));
+    if (pg + 1 < pages) HIP_TRY(launch_set_floor(s->dMerged.p, (uint32_t)nq, s->dGthr.p, st));
+    RerankArgs r;
+    r.Q = s->dQ.p;
+    r.X = s->dX;
+    r.x_half = (uint32_t)s->x_half;
+    r.inv_norm = s->dInv;
+    r.merged = s->dMerged.p;
+    r.out_ids = d_ids;
+    r.out_dist = d_dist;
+    r.out_count = d_count;
+    r.n_uncertified = s->dUncert16;
+    r.nq = (uint32_t)nq;
+    r.k = std::min<uint32_t>(64, k - pg * 64);
+    r.kprime = 64;
+    r.n = (uint32_t)s->n;
+    r.dims = s->dims;
+    r.ld = s->ld;
+    r.metric = s->metric;
+    r.uncert_flags = s->dUflags.p;
+    r.exact_keys = 1;
+    r.out_stride = k;
+    r.out_offset = pg * 64;
+    HIP_TRY(launch_rerank(r, st));
+    if (pg + 1 == pages) HIP_TRY(hipEventRecord(s->ev[2], st));
+  }
   HIP_TRY(hipEventRecord(s->ev[3], st));
   s->ev_valid = true;
-  s->n_dist += (uint64_t)nq * s->n;
+  s->n_dist += (uint64_t)nq * s->n * pages;
   return EHX_OK;
 }
 
@@ -1003,9 +1020,27 @@ int exhaustive_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_quer
 int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k,
                       uint64_t* d_ids, float* d_dist, uint32_t* d_count) {
   if (k == 0 || nq == 0) return EHX_OK;
-  if (k > EHX_MAX_K) return fail(EHX_EUNSUPPORTED, "k=%u exceeds EHX_MAX_K=%u", k, EHX_MAX_K);
   if (nq > (1u << 24)) return fail(EHX_EINVAL, "too many queries in one call: %zu", nq);
-  if (s->params.mode == EHX_MODE_GRAPH) return knn_graph_locked(s, st, nq, d_queries, k, d_ids, d_dist, d_count);
+  if (s->params.mode == EHX_MODE_GRAPH) {
+    if (k > EHX_MAX_K) return fail(EHX_EUNSUPPORTED, "graph mode: k=%u exceeds EHX_MAX_K=%u", k, EHX_MAX_K);
+    return knn_graph_locked(s, st, nq, d_queries, k, d_ids, d_dist, d_count);
+  }
+  if (k > EHX_MAX_K) {
+    // beyond the candidate capacity of one scan pass: the exhaustive canonical pass, paged (exact, HBM-bound —
+    // the whole shard is read once per page of 64 results and per query)
+    if (k > EHX_MAX_K_PAGED) return fail(EHX_EUNSUPPORTED, "k=%u exceeds EHX_MAX_K_PAGED=%u", k, EHX_MAX_K_PAGED);
+    if (s->n == 0) {
+      HIP_TRY(hipMemsetAsync(d_count, 0, nq * sizeof(uint32_t), st));
+      return EHX_OK;
+    }
+    int rc2 = exhaustive_pass(s, st, nq, d_queries, k, d_ids, d_dist, d_count);
+    if (rc2) return rc2;
+    s->n_queries += nq;
+    s->n_exhaustive += nq;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemsetAsync(s->dUncert16, 0, sizeof(unsigned long long), st));
+    return EHX_OK;
+  }
   constexpr size_t kMaxExhaustive = 32;
   enum { kFilter, kF32, kExhaustive };
   int rc;
@@ -1861,6 +1896,7 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
     }
     out->scan_launches = got;
     out->scan_ms_mean = got ? sum / (double)got : 0.0;
+    (void)hipGetLastError();  // an event that was never recorded is not an error of the caller's next launch
   }
   return EHX_OK;
 }

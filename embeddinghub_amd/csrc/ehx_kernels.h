@@ -280,12 +280,15 @@ struct RerankArgs {
   const float2* quv = nullptr;
   uint32_t* uncert_flags = nullptr;  // [nq] 1 = not certified (optional)
   uint32_t exact_keys = 0;           // keys come from launch_exhaustive (exact distances): skip the certification
+  uint32_t out_stride = 0, out_offset = 0;  // paged output: row stride (0 = k) and first column of this page
 };
 hipError_t launch_rerank(const RerankArgs& a, hipStream_t st);
 // canonical distance of every row for each of nq prepared queries: out[q][block][64] best (distance, id) keys
+// (floor, optional: per query, only keys strictly above floor[q] are kept — paging for k > 64)
 hipError_t launch_exhaustive(const float* Q, const void* X, int x_half, const float* inv_norm, uint32_t n, uint32_t dims,
                              uint32_t ld, int metric, uint32_t rows_per_block, uint32_t n_blocks, uint32_t nq,
-                             uint64_t* out, hipStream_t st);
+                             const uint64_t* floor, uint64_t* out, hipStream_t st);
+hipError_t launch_set_floor(const uint64_t* merged, uint32_t nq, uint64_t* floor, hipStream_t st);
 
 // prepared queries: copy into the padded [q_rows][ld] buffer, L2-normalise for cosine
 hipError_t launch_prep_queries(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld,

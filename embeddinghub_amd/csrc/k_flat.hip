@@ -581,12 +581,15 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
     const uint64_t nvalid_mask = __ballot(key != kKeyInf);
     const uint32_t nvalid = __builtin_popcountll(nvalid_mask);
     const uint32_t cnt = nvalid < a.k ? nvalid : a.k;
+    // results go to columns [out_offset, out_offset + k) of a row of out_stride entries (paged large-k
+    // requests write one page per call; out_stride == 0: the plain [nq][k] layout)
+    const size_t ostride = a.out_stride ? a.out_stride : a.k;
     if (tid < (int)a.k) {
       const bool ok = (uint32_t)tid < cnt;
-      a.out_ids[(size_t)q * a.k + tid] = ok ? (uint64_t)(uint32_t)key : ~0ull;
-      a.out_dist[(size_t)q * a.k + tid] = ok ? ordered_to_f32((uint32_t)(key >> 32)) : __builtin_inff();
+      a.out_ids[(size_t)q * ostride + a.out_offset + tid] = ok ? (uint64_t)(uint32_t)key : ~0ull;
+      a.out_dist[(size_t)q * ostride + a.out_offset + tid] = ok ? ordered_to_f32((uint32_t)(key >> 32)) : __builtin_inff();
     }
-    if (tid == 0) a.out_count[q] = cnt;
+    if (tid == 0) a.out_count[q] = (a.out_offset ? a.out_count[q] : 0u) + cnt;
     // certification: every row that is NOT a candidate has approx score >= the worst candidate's
     // approx score A_last (for L2 the scan's score omits |q|^2, added back here).  If
     // A_last - margin > exact k-th distance, no outsider can beat the k-th result, so the top-k is
@@ -637,6 +640,7 @@ template <typename XT>
 __global__ __launch_bounds__(256) void exhaustive_kernel(const float* __restrict__ Q, const XT* __restrict__ X,
                                                          const float* __restrict__ inv_norm, uint32_t n, uint32_t dims,
                                                          uint32_t ld, int metric, uint32_t rows_per_block,
+                                                         const uint64_t* __restrict__ floor,
                                                          uint64_t* __restrict__ out) {
   __shared__ uint64_t keys[64];
   const int tid = threadIdx.x;
@@ -646,6 +650,9 @@ __global__ __launch_bounds__(256) void exhaustive_kernel(const float* __restrict
   const bool scale_x = metric == 2;
   const uint32_t r0 = b * rows_per_block;
   const uint32_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  // paging (k > 64): only keys strictly above the last key of the previous page count
+  const uint64_t fl = floor ? floor[j] : 0ull;
+  const bool paged = floor != nullptr;
   uint64_t best = kKeyInf;
   for (uint32_t base = r0; base < r1; base += 64) {
     const uint32_t id = base + (uint32_t)g;
@@ -654,7 +661,11 @@ __global__ __launch_bounds__(256) void exhaustive_kernel(const float* __restrict
       const float xs = scale_x ? inv_norm[id] : 1.0f;
       d = canon_dist(metric == 0 ? 0 : 1, qv, X + (size_t)id * ld, xs, scale_x, dims, sub);
     }
-    if (sub == 0) keys[g] = id < r1 ? (((uint64_t)f32_to_ordered(d) << 32) | id) : kKeyInf;
+    if (sub == 0) {
+      uint64_t key = id < r1 ? (((uint64_t)f32_to_ordered(d) << 32) | id) : kKeyInf;
+      if (paged && key <= fl) key = kKeyInf;
+      keys[g] = key;
+    }
     __syncthreads();
     if (tid < 64) {
       const uint64_t key = wave_sort64(keys[tid], tid);
@@ -667,16 +678,28 @@ __global__ __launch_bounds__(256) void exhaustive_kernel(const float* __restrict
   if (tid < 64) out[((size_t)j * gridDim.x + b) * 64 + tid] = best;
 }
 
+// next page's floor = the 64th (last) key of this page; exhausted queries get INF (nothing above it)
+__global__ __launch_bounds__(256) void set_floor_kernel(const uint64_t* __restrict__ merged, uint32_t nq,
+                                                        uint64_t* __restrict__ floor) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nq) floor[q] = merged[(size_t)q * 64 + 63];
+}
+
+hipError_t launch_set_floor(const uint64_t* merged, uint32_t nq, uint64_t* floor, hipStream_t st) {
+  hipLaunchKernelGGL(set_floor_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, merged, nq, floor);
+  return hipGetLastError();
+}
+
 hipError_t launch_exhaustive(const float* Q, const void* X, int x_half, const float* inv_norm, uint32_t n, uint32_t dims,
                              uint32_t ld, int metric, uint32_t rows_per_block, uint32_t n_blocks, uint32_t nq,
-                             uint64_t* out, hipStream_t st) {
+                             const uint64_t* floor, uint64_t* out, hipStream_t st) {
   const dim3 grid(n_blocks, nq);
   if (x_half)
     hipLaunchKernelGGL(exhaustive_kernel<__half>, grid, dim3(256), 0, st, Q, (const __half*)X, inv_norm, n, dims, ld,
-                       metric, rows_per_block, out);
+                       metric, rows_per_block, floor, out);
   else
     hipLaunchKernelGGL(exhaustive_kernel<float>, grid, dim3(256), 0, st, Q, (const float*)X, inv_norm, n, dims, ld,
-                       metric, rows_per_block, out);
+                       metric, rows_per_block, floor, out);
   return hipGetLastError();
 }
 

@@ -74,6 +74,9 @@ enum {
 enum { EHX_SCAN_AUTO = 0, EHX_SCAN_F32 = 1 };
 
 #define EHX_MAX_K 48u /* largest k served by one scan pass (k + 8 slack < 64 candidate slots) */
+#define EHX_MAX_K_PAGED 1024u /* flat mode serves EHX_MAX_K < k <= this exactly too, by the exhaustive canonical pass in
+                                  pages of 64 results: the whole shard is read once per page and query — fine for the
+                                  occasional large request, not a batch path */
 
 typedef struct ehx_space ehx_space; /* opaque; owned by the process-global registry */
 

@@ -245,9 +245,26 @@ def test_fewer_rows_than_k_and_empty_space():
     X = np.arange(24, dtype=np.float32).reshape(3, 8)
     s.set_batch(_keys(3), X)
     _check(s, X, Q, 5, pyoracle.METRIC_IP)  # count 3 < k
+    _check(s, X, Q, 49, pyoracle.METRIC_IP)  # k beyond one scan pass: the paged exhaustive pass, count 3
     with pytest.raises(ehx.EhxError) as e:
-        s.knn(Q, 49)
+        s.knn(Q, 1025)
     assert e.value.code == ehx._lib.EUNSUPPORTED
+
+
+@pytest.mark.parametrize("em,om", METRICS)
+@pytest.mark.parametrize("k", [49, 64, 65, 200])
+def test_large_k_is_served_by_the_paged_exhaustive_pass(em, om, k):
+    """EHX_MAX_K < k <= EHX_MAX_K_PAGED (the reference accepts any num, index.cc:39-52): exact, in pages of 64."""
+    rng = np.random.default_rng(k)
+    n, d = 20000, 40
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    X[100:140] = X[7]  # ties across a page boundary are ordered by id
+    Q = np.concatenate([X[7:8], rng.standard_normal((4, d)).astype(np.float32)])
+    s = ehx.Space.unique("bigk", d, metric=em)
+    s.set_batch(_keys(n), X)
+    _check(s, X, Q, k, om)
+    assert s.stats()["n_exhaustive"] == Q.shape[0]
+    s.drop()
 
 
 def test_nan_and_inf_rows_do_not_poison_results():
