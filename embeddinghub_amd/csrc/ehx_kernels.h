@@ -103,55 +103,105 @@ __device__ __forceinline__ float canon_dist(int metric, const float* __restrict_
 }
 
 // Same canonical arithmetic executed by ONE lane: the lane keeps the 4 SSE partial sums itself and
-// walks its row with 16-byte loads (q may live in LDS).  Used by the graph search, where every lane
-// owns one neighbour row.  Requires 16-byte aligned q and x (row stride ld % 4 == 0).
-__device__ __forceinline__ float canon_dist_lane(int metric, const float* __restrict__ q,
-                                                 const float* __restrict__ x, float xscale, bool scale_x,
-                                                 uint32_t dims) {
+// walks its row with 16-byte loads (q may live in LDS).  Used by the graph search and the graph
+// insertion, where every lane owns one neighbour row.  Requires 16-byte aligned q and x (row stride
+// ld % 4 == 0).
+//
+// The walk is HBM-latency bound unless many loads are in flight per lane (a row is ld*4 contiguous
+// bytes = ld/32 cache lines that nobody else touches): the body is cut into blocks of kLaneBlk
+// 16-byte loads and a ring of three register blocks keeps two blocks (32 loads = 512 B per lane,
+// 16-32 KiB per wave) in flight ahead of the block being accumulated.  The graph kernels run one
+// wave per SIMD, so the 192 ring registers are free.  The accumulation order is unchanged (block
+// after block, 16 bytes after 16 bytes), so the result is bit-identical to the plain loop.
+constexpr int kLaneBlk = 16;  // 16-byte loads per ring block (256 B = 2 cache lines per lane)
+
+template <int METRIC01, bool SCALE>
+__device__ __forceinline__ void canon_lane_step(float4 xv, const float4 qv, float xscale, float& p0, float& p1,
+                                                float& p2, float& p3) {
+  if (SCALE) {
+    xv.x = ex_mul(xv.x, xscale);
+    xv.y = ex_mul(xv.y, xscale);
+    xv.z = ex_mul(xv.z, xscale);
+    xv.w = ex_mul(xv.w, xscale);
+  }
+  if (METRIC01 == 0) {
+    const float d0 = ex_sub(qv.x, xv.x), d1 = ex_sub(qv.y, xv.y), d2 = ex_sub(qv.z, xv.z), d3 = ex_sub(qv.w, xv.w);
+    p0 = ex_add(p0, ex_mul(d0, d0));
+    p1 = ex_add(p1, ex_mul(d1, d1));
+    p2 = ex_add(p2, ex_mul(d2, d2));
+    p3 = ex_add(p3, ex_mul(d3, d3));
+  } else {
+    p0 = ex_add(p0, ex_mul(qv.x, xv.x));
+    p1 = ex_add(p1, ex_mul(qv.y, xv.y));
+    p2 = ex_add(p2, ex_mul(qv.z, xv.z));
+    p3 = ex_add(p3, ex_mul(qv.w, xv.w));
+  }
+}
+
+template <int METRIC01, bool SCALE, bool RING = true>
+__device__ __forceinline__ float canon_dist_lane_t(const float* __restrict__ q, const float* __restrict__ x,
+                                                   float xscale, uint32_t dims) {
   uint32_t body;
   if ((dims & 15u) == 0 || (dims & 3u) == 0) body = dims;
   else if (dims > 16) body = dims & ~15u;
   else if (dims > 4) body = dims & ~3u;
   else body = 0;
   float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
-  if (metric == 0) {
-    for (uint32_t m = 0; m < body; m += 4) {
-      float4 xv = *(const float4*)(x + m);
-      const float4 qv = *(const float4*)(q + m);
-      if (scale_x) {
-        xv.x = ex_mul(xv.x, xscale);
-        xv.y = ex_mul(xv.y, xscale);
-        xv.z = ex_mul(xv.z, xscale);
-        xv.w = ex_mul(xv.w, xscale);
-      }
-      const float d0 = ex_sub(qv.x, xv.x), d1 = ex_sub(qv.y, xv.y), d2 = ex_sub(qv.z, xv.z), d3 = ex_sub(qv.w, xv.w);
-      p0 = ex_add(p0, ex_mul(d0, d0));
-      p1 = ex_add(p1, ex_mul(d1, d1));
-      p2 = ex_add(p2, ex_mul(d2, d2));
-      p3 = ex_add(p3, ex_mul(d3, d3));
+  constexpr int BL = kLaneBlk;
+  const uint32_t nblk = RING ? body / (4u * BL) : 0u;  // !RING: few registers, four loads in flight
+  float4 r0[BL], r1[BL], r2[BL];
+  const float4* x4 = (const float4*)x;
+  const float4* q4 = (const float4*)q;
+#define EHX_LANE_LOAD(R, B)                                        \
+  _Pragma("unroll") for (int i_ = 0; i_ < BL; ++i_) R[i_] = x4[(size_t)(B) * BL + i_];
+#define EHX_LANE_ACC(R, B)                                         \
+  _Pragma("unroll") for (int i_ = 0; i_ < BL; ++i_)                \
+      canon_lane_step<METRIC01, SCALE>(R[i_], q4[(size_t)(B) * BL + i_], xscale, p0, p1, p2, p3);
+  uint32_t b = 0;
+  if (nblk >= 2) {
+    EHX_LANE_LOAD(r0, 0)
+    EHX_LANE_LOAD(r1, 1)
+    // steady state: three blocks accumulated per trip, every load two blocks ahead of its use, no branches
+    for (; b + 5 <= nblk; b += 3) {
+      EHX_LANE_LOAD(r2, b + 2)
+      EHX_LANE_ACC(r0, b)
+      EHX_LANE_LOAD(r0, b + 3)
+      EHX_LANE_ACC(r1, b + 1)
+      EHX_LANE_LOAD(r1, b + 4)
+      EHX_LANE_ACC(r2, b + 2)
     }
-  } else {
-    for (uint32_t m = 0; m < body; m += 4) {
-      float4 xv = *(const float4*)(x + m);
-      const float4 qv = *(const float4*)(q + m);
-      if (scale_x) {
-        xv.x = ex_mul(xv.x, xscale);
-        xv.y = ex_mul(xv.y, xscale);
-        xv.z = ex_mul(xv.z, xscale);
-        xv.w = ex_mul(xv.w, xscale);
-      }
-      p0 = ex_add(p0, ex_mul(qv.x, xv.x));
-      p1 = ex_add(p1, ex_mul(qv.y, xv.y));
-      p2 = ex_add(p2, ex_mul(qv.z, xv.z));
-      p3 = ex_add(p3, ex_mul(qv.w, xv.w));
+    const uint32_t rem = nblk - b;  // 2, 3 or 4 blocks left; r0 / r1 hold blocks b / b+1
+    if (rem >= 3) { EHX_LANE_LOAD(r2, b + 2) }
+    EHX_LANE_ACC(r0, b)
+    if (rem == 4) { EHX_LANE_LOAD(r0, b + 3) }
+    EHX_LANE_ACC(r1, b + 1)
+    if (rem >= 3) { EHX_LANE_ACC(r2, b + 2) }
+    if (rem == 4) { EHX_LANE_ACC(r0, b + 3) }
+  } else if (nblk == 1) {
+    EHX_LANE_LOAD(r0, 0)
+    EHX_LANE_ACC(r0, 0)
+  }
+#undef EHX_LANE_LOAD
+#undef EHX_LANE_ACC
+  // the 16-byte pieces after the last full block (fewer than kLaneBlk), four loads at a time
+  {
+    uint32_t m = nblk * BL;
+    const uint32_t m1 = body / 4u;
+    for (; m + 4 <= m1; m += 4) {
+      const float4 t0 = x4[m], t1 = x4[m + 1], t2 = x4[m + 2], t3 = x4[m + 3];
+      canon_lane_step<METRIC01, SCALE>(t0, q4[m], xscale, p0, p1, p2, p3);
+      canon_lane_step<METRIC01, SCALE>(t1, q4[m + 1], xscale, p0, p1, p2, p3);
+      canon_lane_step<METRIC01, SCALE>(t2, q4[m + 2], xscale, p0, p1, p2, p3);
+      canon_lane_step<METRIC01, SCALE>(t3, q4[m + 3], xscale, p0, p1, p2, p3);
     }
+    for (; m < m1; ++m) canon_lane_step<METRIC01, SCALE>(x4[m], q4[m], xscale, p0, p1, p2, p3);
   }
   float res = ex_add(ex_add(ex_add(p0, p1), p2), p3);
   if (body != dims) {
     float tail = 0.0f;
     for (uint32_t m = body; m < dims; ++m) {
-      const float xv = scale_x ? ex_mul(x[m], xscale) : x[m];
-      if (metric == 0) {
+      const float xv = SCALE ? ex_mul(x[m], xscale) : x[m];
+      if (METRIC01 == 0) {
         const float diff = ex_sub(q[m], xv);
         tail = ex_add(tail, ex_mul(diff, diff));
       } else {
@@ -160,8 +210,18 @@ __device__ __forceinline__ float canon_dist_lane(int metric, const float* __rest
     }
     res = body ? ex_add(res, tail) : tail;
   }
-  if (metric != 0) res = ex_sub(1.0f, res);
+  if (METRIC01 != 0) res = ex_sub(1.0f, res);
   return res;
+}
+
+// runtime-dispatch form (metric: 0 = L2^2, 1 = 1 - inner product; scale_x: cosine rows), without the
+// register ring: used by the insertion kernels, which keep several waves per SIMD resident
+__device__ __forceinline__ float canon_dist_lane(int metric, const float* __restrict__ q,
+                                                 const float* __restrict__ x, float xscale, bool scale_x,
+                                                 uint32_t dims) {
+  if (metric == 0) return canon_dist_lane_t<0, false, false>(q, x, xscale, dims);
+  if (scale_x) return canon_dist_lane_t<1, true, false>(q, x, xscale, dims);
+  return canon_dist_lane_t<1, false, false>(q, x, xscale, dims);
 }
 
 struct ScanArgs {

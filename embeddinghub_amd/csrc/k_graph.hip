@@ -63,6 +63,7 @@ __device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* a, uint32_t 
 // LDS: q[ld] floats | R[ef_cap] u64 | R2[ef_cap] u64 | batch[64] u64 | ids[64] u32
 size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap) { return (size_t)ld * 4 + (size_t)ef_cap * 16 + 64 * 8 + 64 * 4; }
 
+template <int METRIC01, bool SCALE>
 __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
@@ -77,8 +78,6 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   for (uint32_t i = lane; i < a.ld; i += 64) qs[i] = a.Q[(size_t)qi * a.ld + i];
   __syncthreads();
 
-  const int metric01 = a.metric == 0 ? 0 : 1;
-  const bool scale_x = a.metric == 2;
   unsigned long long n_dist = 0, n_hops0 = 0, n_hops_up = 0;
 
   // canonical distance of row ids_l[lane] for lane < count: every lane owns one neighbour row and
@@ -86,8 +85,8 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   auto lane_dist = [&](uint32_t count) -> float {
     if ((uint32_t)lane >= count) return __builtin_inff();
     const uint32_t id = ids_l[lane];
-    const float xs = scale_x ? a.inv_norm[id] : 1.0f;
-    return canon_dist_lane(metric01, qs, a.X + (size_t)id * a.ld, xs, scale_x, a.dims);
+    const float xs = SCALE ? a.inv_norm[id] : 1.0f;
+    return canon_dist_lane_t<METRIC01, SCALE>(qs, a.X + (size_t)id * a.ld, xs, a.dims);
   };
 
   // ---- entry point ----
@@ -149,23 +148,37 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     atomicOr(&vis[cur >> 5], 1u << (cur & 31));
   }
   __syncthreads();
+  // The adjacency row of the node most likely to be expanded NEXT (the second-closest unexpanded entry
+  // of R) is requested one expansion ahead, so its HBM round trip hides under this expansion's row
+  // fetches; it is only a hint: when the merge puts a closer fresh neighbour in front, the row is
+  // loaded on demand as before.  The traversal order is unchanged.
+  uint32_t pf_node = kNoNode, pf_nb = kNoNode;
   for (;;) {
-    // closest unexpanded entry
-    uint32_t idx = kNoNode;
-    for (uint32_t base = 0; base < nR && idx == kNoNode; base += 64) {
+    // closest unexpanded entry (and the one after it)
+    uint32_t idx = kNoNode, idx2 = kNoNode;
+    for (uint32_t base = 0; base < nR && idx2 == kNoNode; base += 64) {
       const uint32_t i = base + lane;
       const bool un = i < nR && !(R[i] & 1ull);
-      const uint64_t m = __ballot(un);
-      if (m) idx = base + (uint32_t)__builtin_ctzll(m);
+      uint64_t m = __ballot(un);
+      if (m && idx == kNoNode) {
+        idx = base + (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+      }
+      if (m && idx != kNoNode) idx2 = base + (uint32_t)__builtin_ctzll(m);
     }
     if (idx == kNoNode) break;
     const uint32_t c = (uint32_t)(R[idx] & 0xFFFFFFFFull) >> 1;
+    const uint32_t c2 = idx2 != kNoNode ? (uint32_t)(R[idx2] & 0xFFFFFFFFull) >> 1 : kNoNode;
     __syncthreads();
     if (lane == 0) R[idx] |= 1ull;
     n_hops0 += 1;
     // neighbours (stored order), visited test-and-set
     uint32_t nb = kNoNode;
-    if (lane < (int)a.M0) nb = a.adj0[(size_t)c * a.M0 + lane];
+    if (c == pf_node) nb = pf_nb;
+    else if (lane < (int)a.M0) nb = a.adj0[(size_t)c * a.M0 + lane];
+    pf_node = c2;
+    pf_nb = kNoNode;
+    if (c2 != kNoNode && lane < (int)a.M0) pf_nb = a.adj0[(size_t)c2 * a.M0 + lane];
     bool fresh = false;
     if (nb != kNoNode) {
       const uint32_t bit = 1u << (nb & 31);
@@ -222,12 +235,17 @@ hipError_t launch_graph_search(const GraphArgs& a, hipStream_t st) {
   const size_t lds = graph_lds_bytes(a.ld, a.ef_cap);
   static size_t attr_set = 0;
   if (lds > 64 * 1024 && lds > attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)graph_search_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    const void* fns[3] = {(const void*)graph_search_kernel<0, false>, (const void*)graph_search_kernel<1, true>,
+                          (const void*)graph_search_kernel<1, false>};
+    for (const void* f : fns) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
     attr_set = lds;
   }
-  hipLaunchKernelGGL(graph_search_kernel, dim3(a.nq), dim3(64), lds, st, a);
+  if (a.metric == 0) hipLaunchKernelGGL((graph_search_kernel<0, false>), dim3(a.nq), dim3(64), lds, st, a);
+  else if (a.metric == 2) hipLaunchKernelGGL((graph_search_kernel<1, true>), dim3(a.nq), dim3(64), lds, st, a);
+  else hipLaunchKernelGGL((graph_search_kernel<1, false>), dim3(a.nq), dim3(64), lds, st, a);
   return hipGetLastError();
 }
 
