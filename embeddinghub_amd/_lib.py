@@ -80,6 +80,7 @@ SYMBOLS = {
     "ehx_graph_export": (C.c_int, [_vp, _u32p, _i32p, _u32p, _u32p, C.c_uint64, _u64p, _u32p, _i32p]),
     "ehx_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "ehx_stats_reset": (C.c_int, [_vp]),
+    "ehx_graph_counters": (C.c_int, [_vp, _u64p, C.c_uint32]),
 }
 
 _LIB = None

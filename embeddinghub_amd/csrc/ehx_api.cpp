@@ -130,7 +130,7 @@ struct ehx_space {
   uint64_t g_stale_updates = 0;  // rows overwritten in place after their insertion (no graph repair)
   DevBuf<uint32_t> dInsIds, dInsSel, dInsVislog, dItemTgt, dItemKind, dItemOff, dItemIds;
   DevBuf<int32_t> dInsLevels, dItemLevel;
-  unsigned long long* dGraphCounters = nullptr;  // n_dist, n_hops0, n_hops_up
+  unsigned long long* dGraphCounters = nullptr;  // n_dist, n_hops0, n_hops_up, n_prefetch_hit, [4..11] profile builds
 
   // key map (explicit keys only)
   std::unordered_map<std::string, uint64_t> key_to_id;
@@ -692,8 +692,8 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
                      float* d_dist, uint32_t* d_count) {
   if (s->g_n != s->n)
     return fail(EHX_EUNSUPPORTED,
-                "graph mode: the graph covers %llu of %llu rows (import a graph with ehx_graph_import; "
-                "GPU-side insertion is not built yet)",
+                "graph mode: the graph covers %llu of %llu rows (rows were written while graph building was "
+                "switched off, build_batch = 0xFFFFFFFF: import the graph with ehx_graph_import)",
                 (unsigned long long)s->g_n, (unsigned long long)s->n);
   uint32_t ef = s->params.ef > k ? s->params.ef : k;  // searchKnn: max(ef_, k)
   if (ef > 4096) return fail(EHX_EUNSUPPORTED, "ef=%u exceeds 4096", ef);
@@ -703,8 +703,8 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   const uint32_t vis_words = (uint32_t)((s->n + 31) / 32);
   if ((rc = s->dVisited.ensure((size_t)nq * vis_words))) return rc;
   if (!s->dGraphCounters) {
-    HIP_TRY(hipMalloc((void**)&s->dGraphCounters, 3 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(s->dGraphCounters, 0, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&s->dGraphCounters, kGraphCounters * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(s->dGraphCounters, 0, kGraphCounters * sizeof(unsigned long long)));
   }
   if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
   HIP_TRY(hipEventRecord(s->ev[0], st));
@@ -1761,6 +1761,10 @@ int ehx_graph_import(ehx_space* s, uint64_t n, const uint32_t* level0, const int
     if (c > M0) return fail(EHX_EINVAL, "node %llu: level-0 degree %u > %u", (unsigned long long)i, c, M0);
     for (uint32_t j = 0; j < c; ++j) {
       if (row[1 + j] >= n) return fail(EHX_EINVAL, "node %llu: neighbour id out of range", (unsigned long long)i);
+      // a list holds distinct ids (hnswlib invariant); the search kernel's visited test relies on it
+      for (uint32_t t = 0; t < j; ++t)
+        if (row[1 + t] == row[1 + j])
+          return fail(EHX_EINVAL, "node %llu: neighbour %u listed twice at level 0", (unsigned long long)i, row[1 + j]);
       adj[i * M0 + j] = row[1 + j];
     }
   }
@@ -1901,6 +1905,19 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
   return EHX_OK;
 }
 
+int ehx_graph_counters(ehx_space* s, uint64_t* out, uint32_t n_out) {
+  if (!valid_space(s) || !out) return fail(EHX_EINVAL, "NULL argument");
+  if (n_out > kGraphCounters) return fail(EHX_EINVAL, "at most %u counters", kGraphCounters);
+  std::lock_guard<std::mutex> sl(s->scratch_mu);
+  unsigned long long g[kGraphCounters] = {};
+  if (s->dGraphCounters) {
+    HIP_TRY(hipSetDevice(engine().device));
+    HIP_TRY(hipMemcpy(g, s->dGraphCounters, sizeof(g), hipMemcpyDeviceToHost));
+  }
+  for (uint32_t i = 0; i < n_out; ++i) out[i] = g[i];
+  return EHX_OK;
+}
+
 int ehx_stats_reset(ehx_space* s) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   std::lock_guard<std::mutex> sl(s->scratch_mu);
@@ -1914,7 +1931,7 @@ int ehx_stats_reset(ehx_space* s) {
   s->n_uncertified_final = 0;
   s->ring_count = 0;
   if (s->dUncert) HIP_TRY(hipMemset(s->dUncert, 0, 2 * sizeof(unsigned long long)));
-  if (s->dGraphCounters) HIP_TRY(hipMemset(s->dGraphCounters, 0, 3 * sizeof(unsigned long long)));
+  if (s->dGraphCounters) HIP_TRY(hipMemset(s->dGraphCounters, 0, kGraphCounters * sizeof(unsigned long long)));
   return EHX_OK;
 }
 

@@ -108,12 +108,19 @@ __device__ __forceinline__ float canon_dist(int metric, const float* __restrict_
 // ld % 4 == 0).
 //
 // The walk is HBM-latency bound unless many loads are in flight per lane (a row is ld*4 contiguous
-// bytes = ld/32 cache lines that nobody else touches): the body is cut into blocks of kLaneBlk
-// 16-byte loads and a ring of three register blocks keeps two blocks (32 loads = 512 B per lane,
-// 16-32 KiB per wave) in flight ahead of the block being accumulated.  The graph kernels run one
-// wave per SIMD, so the 192 ring registers are free.  The accumulation order is unchanged (block
-// after block, 16 bytes after 16 bytes), so the result is bit-identical to the plain loop.
-constexpr int kLaneBlk = 16;  // 16-byte loads per ring block (256 B = 2 cache lines per lane)
+// bytes = ld/32 cache lines that nobody else touches; the plain loop compiles to ONE 16-byte load in
+// flight per lane): the body is cut into blocks of kLaneBlk 16-byte loads and a ring of three
+// register blocks keeps two blocks in flight ahead of the block being accumulated.  Measured on the
+// graph bench (profiles/r01_m_*): 16-24 loads in flight per lane are enough — kLaneBlk 8 and 16 are
+// within 3 % of each other, 4 is 6 % slower at d=768 — because past that point the random row gathers
+// are bound by what the memory system delivers for this pattern (scripts/ubench/gather_rows.hip:
+// 27 lanes x private rows, 4 waves per CU: 4.2-4.5 TB/s; deeper queues thrash the 32-KiB L1).
+// The accumulation order is unchanged (block after block, 16 bytes after 16 bytes), so the result is
+// bit-identical to the plain loop.
+#ifndef EHX_LANE_BLK
+#define EHX_LANE_BLK 8
+#endif
+constexpr int kLaneBlk = EHX_LANE_BLK;  // 16-byte loads per ring block (8: 128 B = one cache line per lane)
 
 template <int METRIC01, bool SCALE>
 __device__ __forceinline__ void canon_lane_step(float4 xv, const float4 qv, float xscale, float& p0, float& p1,
@@ -214,14 +221,17 @@ __device__ __forceinline__ float canon_dist_lane_t(const float* __restrict__ q, 
   return res;
 }
 
-// runtime-dispatch form (metric: 0 = L2^2, 1 = 1 - inner product; scale_x: cosine rows), without the
-// register ring: used by the insertion kernels, which keep several waves per SIMD resident
+// runtime-dispatch form (metric: 0 = L2^2, 1 = 1 - inner product; scale_x: cosine rows) used by the
+// insertion kernels (EHX_INSERT_RING: with or without the register ring — A/B switch)
+#ifndef EHX_INSERT_RING
+#define EHX_INSERT_RING 0
+#endif
 __device__ __forceinline__ float canon_dist_lane(int metric, const float* __restrict__ q,
                                                  const float* __restrict__ x, float xscale, bool scale_x,
                                                  uint32_t dims) {
-  if (metric == 0) return canon_dist_lane_t<0, false, false>(q, x, xscale, dims);
-  if (scale_x) return canon_dist_lane_t<1, true, false>(q, x, xscale, dims);
-  return canon_dist_lane_t<1, false, false>(q, x, xscale, dims);
+  if (metric == 0) return canon_dist_lane_t<0, false, EHX_INSERT_RING != 0>(q, x, xscale, dims);
+  if (scale_x) return canon_dist_lane_t<1, true, EHX_INSERT_RING != 0>(q, x, xscale, dims);
+  return canon_dist_lane_t<1, false, EHX_INSERT_RING != 0>(q, x, xscale, dims);
 }
 
 struct ScanArgs {
@@ -371,6 +381,7 @@ hipError_t launch_gen_rows(uint64_t seed, uint64_t row0, uint64_t n_rows, uint32
                            int normalize, float* out, hipStream_t st);
 
 // graph-mode search (k_graph.hip): one wave per query
+constexpr uint32_t kGraphCounters = 12;  // n_dist, n_hops0, n_hops_up, n_prefetch_hit, [4..11] profile builds
 struct GraphArgs {
   const float* Q;           // prepared queries [nq][ld]
   const float* X;           // rows [cap][ld]
@@ -382,7 +393,7 @@ struct GraphArgs {
   uint64_t* out_ids;        // [nq][k]
   float* out_dist;
   uint32_t* out_count;
-  unsigned long long* counters;  // n_dist, n_hops0, n_hops_up
+  unsigned long long* counters;  // [kGraphCounters]
   uint32_t nq, k, ef, ef_cap, n, dims, ld, M, M0, vis_words, entry_point;
   int max_level, metric;
 };

@@ -31,6 +31,27 @@ namespace {
 
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 
+// -DEHX_GRAPH_PROFILE (ablation builds, scripts/gpu_graph_profile.sh): per-phase wall-clock ticks (100 MHz)
+// of the level-0 loop, summed over all query waves into counters[4..11]: pick next node | adjacency +
+// visited | row fetch + distances | rank fresh keys | decide next + request | insertion points | move R | tail.
+// A/B switches of the level-0 loop (ablation builds only; the defaults are the shipped kernel)
+#ifndef EHX_G_NEXT_EARLY
+#define EHX_G_NEXT_EARLY 1  // decide the next node before the merge and request its adjacency / visited words there
+#endif
+
+#ifdef EHX_GRAPH_PROFILE
+#define EHX_PROF_DECL unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t_ = wall_clock64()
+#define EHX_PROF(i)                              \
+  {                                              \
+    const unsigned long long now_ = wall_clock64(); \
+    prof_[i] += now_ - prof_t_;                  \
+    prof_t_ = now_;                              \
+  }
+#else
+#define EHX_PROF_DECL
+#define EHX_PROF(i)
+#endif
+
 __device__ __forceinline__ uint64_t wave_sort64g(uint64_t key, int lane) {
 #pragma unroll
   for (int k = 2; k <= 64; k <<= 1) {
@@ -48,6 +69,14 @@ __device__ __forceinline__ uint64_t wave_sort64g(uint64_t key, int lane) {
 }
 
 // number of entries of the ascending array a[0..n) that are < key
+// Prefetch-style load: a relaxed atomic load (wavefront scope: no cache-policy bits) is an ordered
+// memory reference for the compiler, so it is ISSUED where it is written — a plain load whose first use
+// comes much later gets sunk down to that use by the machine-code sinking pass, and the HBM round trip
+// it was meant to overlap is exposed again.
+__device__ __forceinline__ uint32_t load_here(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
 __device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* a, uint32_t n, uint64_t key) {
   uint32_t lo = 0, hi = n;
   while (lo < hi) {
@@ -60,8 +89,8 @@ __device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* a, uint32_t 
 
 }  // namespace
 
-// LDS: q[ld] floats | R[ef_cap] u64 | R2[ef_cap] u64 | batch[64] u64 | ids[64] u32
-size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap) { return (size_t)ld * 4 + (size_t)ef_cap * 16 + 64 * 8 + 64 * 4; }
+// LDS: q[ld] floats | R[ef_cap] u64 | S[64] u64 (sorted fresh keys) | batch[64] u64 | ids[64] u32
+size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap) { return (size_t)ld * 4 + (size_t)ef_cap * 8 + 64 * 8 * 2 + 64 * 4; }
 
 template <int METRIC01, bool SCALE>
 __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
@@ -70,8 +99,8 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   const uint32_t qi = blockIdx.x;
   float* qs = (float*)smem;
   uint64_t* R = (uint64_t*)(smem + (size_t)a.ld * 4);
-  uint64_t* R2 = R + a.ef_cap;
-  uint64_t* batch = R2 + a.ef_cap;
+  uint64_t* S = R + a.ef_cap;
+  uint64_t* batch = S + 64;
   uint32_t* ids_l = (uint32_t*)(batch + 64);
   uint32_t* vis = a.visited + (size_t)qi * a.vis_words;
 
@@ -141,6 +170,21 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   }
 
   // ---- level 0: best-first, ef bounded ----
+  // Per expansion the dependent chain is: adjacency row -> visited words -> neighbour rows -> merge.
+  //  * The adjacency row of the node most likely to be expanded next (c2, the second-closest
+  //    unexpanded entry of R) is requested before this expansion's row fetches.  Right after the
+  //    distances — BEFORE the merge — the next node is known for certain (c2, or the closest fresh
+  //    neighbour if that is closer): c2's visited words, or the fresh node's adjacency row and then
+  //    its visited words, are requested there and fly while R is merged.  On a confirmed c2 only the
+  //    row fetch is left on the chain.  The traversal order is unchanged.
+  //  * visited: the test is an agent-scope atomic LOAD, the set a fire-and-forget atomicOr (an
+  //    adjacency list holds distinct ids — hnswlib invariant, checked on import — so the lanes of one
+  //    expansion never race on the same BIT, and the same wave's later loads of a word observe its
+  //    earlier atomics: per-location coherence).  The speculative words are loaded after this
+  //    expansion's atomicOrs in program order and nothing else touches the bitmap before they are used.
+  //  * merge: the fresh keys are ranked by counting (broadcast LDS reads, no shuffle network), their
+  //    insertion points found by binary search, and R is updated IN PLACE from the top down, touching
+  //    only [first insertion point, nR): nothing at all when no fresh key beats the current worst.
   const uint32_t ef = a.ef;
   uint32_t nR = 1;
   if (lane == 0) {
@@ -148,15 +192,14 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     atomicOr(&vis[cur >> 5], 1u << (cur & 31));
   }
   __syncthreads();
-  // The adjacency row of the node most likely to be expanded NEXT (the second-closest unexpanded entry
-  // of R) is requested one expansion ahead, so its HBM round trip hides under this expansion's row
-  // fetches; it is only a hint: when the merge puts a closer fresh neighbour in front, the row is
-  // loaded on demand as before.  The traversal order is unchanged.
-  uint32_t pf_node = kNoNode, pf_nb = kNoNode;
+  uint32_t scan_from = 0;  // every entry of R before this index is expanded
+  uint32_t pf_node = kNoNode, pf_nb = kNoNode, pf_word = 0;
+  unsigned long long n_pf_hit = 0;
+  EHX_PROF_DECL;
   for (;;) {
     // closest unexpanded entry (and the one after it)
     uint32_t idx = kNoNode, idx2 = kNoNode;
-    for (uint32_t base = 0; base < nR && idx2 == kNoNode; base += 64) {
+    for (uint32_t base = scan_from & ~63u; base < nR && idx2 == kNoNode; base += 64) {
       const uint32_t i = base + lane;
       const bool un = i < nR && !(R[i] & 1ull);
       uint64_t m = __ballot(un);
@@ -167,53 +210,128 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
       if (m && idx != kNoNode) idx2 = base + (uint32_t)__builtin_ctzll(m);
     }
     if (idx == kNoNode) break;
+    EHX_PROF(0)
     const uint32_t c = (uint32_t)(R[idx] & 0xFFFFFFFFull) >> 1;
     const uint32_t c2 = idx2 != kNoNode ? (uint32_t)(R[idx2] & 0xFFFFFFFFull) >> 1 : kNoNode;
     __syncthreads();
     if (lane == 0) R[idx] |= 1ull;
     n_hops0 += 1;
-    // neighbours (stored order), visited test-and-set
-    uint32_t nb = kNoNode;
-    if (c == pf_node) nb = pf_nb;
-    else if (lane < (int)a.M0) nb = a.adj0[(size_t)c * a.M0 + lane];
+    // neighbours (stored order) and their visited words
+    uint32_t nb = kNoNode, word = 0;
+    if (c == pf_node) {
+      nb = pf_nb;
+      word = pf_word;
+    } else {  // first expansion only
+      if (lane < (int)a.M0) nb = a.adj0[(size_t)c * a.M0 + lane];
+      if (nb != kNoNode) word = __hip_atomic_load(&vis[nb >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool fresh = nb != kNoNode && !(word & (1u << (nb & 31)));
+    if (fresh) (void)__hip_atomic_fetch_or(&vis[nb >> 5], 1u << (nb & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pf_node = c2;
     pf_nb = kNoNode;
-    if (c2 != kNoNode && lane < (int)a.M0) pf_nb = a.adj0[(size_t)c2 * a.M0 + lane];
-    bool fresh = false;
-    if (nb != kNoNode) {
-      const uint32_t bit = 1u << (nb & 31);
-      fresh = !(atomicOr(&vis[nb >> 5], bit) & bit);
-    }
+    if (c2 != kNoNode && lane < (int)a.M0) pf_nb = load_here(a.adj0 + (size_t)c2 * a.M0 + lane);
     const uint64_t fmask = __ballot(fresh);
     const uint32_t nfresh = __builtin_popcountll(fmask);
     if (fresh) ids_l[__builtin_popcountll(fmask & ((1ull << lane) - 1ull))] = nb;
     __syncthreads();
-    if (nfresh == 0) continue;
     n_dist += nfresh;
+    EHX_PROF(1)
     // distances: lane p (< nfresh) owns fresh neighbour p
     uint64_t mykey = kKeyInf;
-    {
+    if (nfresh) {
       const float d = lane_dist(nfresh);
       if ((uint32_t)lane < nfresh) mykey = ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)ids_l[lane] << 1);
     }
-    mykey = wave_sort64g(mykey, lane);  // ascending; INF padding at the end
-    batch[lane] = mykey;
-    __syncthreads();
-    // merge: R2 <- ef smallest of R u batch
-    if ((uint32_t)lane < nfresh) {
-      const uint32_t pos = lower_bound_lds(R, nR, mykey) + lane;
-      if (pos < ef) R2[pos] = mykey;
+    scan_from = idx + 1;
+#ifdef EHX_GRAPH_PROFILE
+    if (__any(mykey == 1ull)) prof_[7] += 1;  // keeps the distances live: the timer below waits for them
+#endif
+    EHX_PROF(2)
+    // Does any fresh key enter R?  If so rank the fresh keys among themselves by counting (keys are
+    // distinct: the id is part of the key); the key of rank 0 is the closest fresh neighbour.
+    const bool do_merge = nfresh != 0 && (nR < ef || __any(mykey < R[ef - 1]));
+    uint64_t minkey = kKeyInf;
+    uint32_t rank = 0;
+    if (do_merge) {
+      batch[lane] = mykey;
+      __syncthreads();
+      // eight keys per trip, all eight LDS reads issued before the first compare (a one-key-per-trip loop
+      // pays the LDS latency nfresh times); batch[nfresh..64) = +inf never counts
+      for (uint32_t j = 0; j < nfresh; j += 8) {
+        uint64_t kb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kb[u] = batch[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += kb[u] < mykey ? 1u : 0u;
+      }
+      const uint64_t first = __ballot((uint32_t)lane < nfresh && rank == 0);
+      minkey = __shfl(mykey, (int)__builtin_ctzll(first), 64);
     }
-    for (uint32_t j = lane; j < nR; j += 64) {
-      const uint64_t kj = R[j];
-      const uint32_t pos = j + lower_bound_lds(batch, nfresh, kj);
-      if (pos < ef) R2[pos] = kj;
+    EHX_PROF(3)
+    // The node expanded next is known NOW, before the merge: the closer of the closest fresh neighbour
+    // and the second unexpanded entry c2 (a fresh key below R[idx2] is always inserted; one above it
+    // leaves R[idx2] where it is).  Its adjacency row / visited words fly while R is merged.
+    const uint64_t k2 = idx2 != kNoNode ? R[idx2] : kKeyInf;
+    bool pf_have_word;
+#if EHX_G_NEXT_EARLY
+    if (minkey < k2) {
+      pf_node = (uint32_t)(minkey & 0xFFFFFFFFull) >> 1;
+      pf_nb = kNoNode;
+      if (lane < (int)a.M0) pf_nb = load_here(a.adj0 + (size_t)pf_node * a.M0 + lane);
+      pf_have_word = false;
+    } else
+#endif
+    {
+      // c2 it is (EHX_G_NEXT_EARLY=0: presumably), and its adjacency row has landed (requested before the
+      // row fetches): its visited words, loaded after this expansion's atomicOrs in program order
+      pf_word = 0;
+      if (pf_nb != kNoNode) pf_word = __hip_atomic_load(&vis[pf_nb >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pf_have_word = true;
+      if (!(minkey < k2)) n_pf_hit += 1;
     }
-    __syncthreads();
-    nR = nR + nfresh < ef ? nR + nfresh : ef;
-    uint64_t* t = R;
-    R = R2;
-    R2 = t;
+    EHX_PROF(4)
+    if (do_merge) {
+      S[lane] = kKeyInf;  // S[nfresh..64) = +inf: the counting searches below need no bound checks
+      __syncthreads();
+      if ((uint32_t)lane < nfresh) S[rank] = mykey;
+      __syncthreads();
+      const uint64_t skey = S[lane];
+      uint32_t ps = kNoNode;
+      if ((uint32_t)lane < nfresh) ps = lower_bound_lds(R, nR, skey);
+      const uint32_t p0 = __shfl(ps, 0, 64);  // insertion point of the smallest fresh key
+      EHX_PROF(5)
+      if (p0 < ef) {
+        // R[j], j >= p0, moves up by the number of fresh keys below it: top down, 64 entries at a time,
+        // in place — a chunk's new positions are >= its own start, so no unread entry is overwritten.
+        // (Moving 256 entries per trip with 4 interleaved searches per lane measured 9 % SLOWER: the
+        // range that moves is usually shorter than 64.)
+        for (uint32_t hi = nR; hi > p0;) {
+          const uint32_t lo = hi - p0 > 64 ? hi - 64 : p0;
+          const uint32_t j = lo + lane;
+          uint64_t kj = 0;
+          uint32_t pos = kNoNode;
+          if (j < hi) {
+            kj = R[j];
+            pos = j + lower_bound_lds(S, nfresh, kj);
+          }
+          __syncthreads();
+          if (pos < ef) R[pos] = kj;
+          __syncthreads();
+          hi = lo;
+        }
+        if ((uint32_t)lane < nfresh && ps + lane < ef) R[ps + lane] = skey;
+        __syncthreads();
+        nR = nR + nfresh < ef ? nR + nfresh : ef;
+        if (p0 < scan_from) scan_from = p0;
+      }
+      EHX_PROF(6)
+    }
+    if (!pf_have_word) {
+      // the adjacency row of the fresh node expanded next landed during the merge
+      pf_word = 0;
+      if (pf_nb != kNoNode) pf_word = __hip_atomic_load(&vis[pf_nb >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    EHX_PROF(7)
   }
 
   // ---- results: the k closest of R (already sorted by (dist, id)) ----
@@ -228,6 +346,10 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     atomicAdd(&a.counters[0], n_dist);
     atomicAdd(&a.counters[1], n_hops0);
     atomicAdd(&a.counters[2], n_hops_up);
+    atomicAdd(&a.counters[3], n_pf_hit);
+#ifdef EHX_GRAPH_PROFILE
+    for (int i = 0; i < 8; ++i) atomicAdd(&a.counters[4 + i], prof_[i]);
+#endif
   }
 }
 

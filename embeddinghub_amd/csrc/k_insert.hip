@@ -63,9 +63,7 @@ __device__ __forceinline__ float row_row_dist(int metric01, bool scale, const fl
   else if (dims > 4) body = dims & ~3u;
   else body = 0;
   float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
-  for (uint32_t m = 0; m < body; m += 4) {
-    float4 a = *(const float4*)(xa + m);
-    float4 b = *(const float4*)(xb + m);
+  auto step = [&](float4 a, float4 b) {
     if (scale) {
       a.x = ex_mul(a.x, sa); a.y = ex_mul(a.y, sa); a.z = ex_mul(a.z, sa); a.w = ex_mul(a.w, sa);
       b.x = ex_mul(b.x, sb); b.y = ex_mul(b.y, sb); b.z = ex_mul(b.z, sb); b.w = ex_mul(b.w, sb);
@@ -78,7 +76,25 @@ __device__ __forceinline__ float row_row_dist(int metric01, bool scale, const fl
       p0 = ex_add(p0, ex_mul(a.x, b.x)); p1 = ex_add(p1, ex_mul(a.y, b.y));
       p2 = ex_add(p2, ex_mul(a.z, b.z)); p3 = ex_add(p3, ex_mul(a.w, b.w));
     }
+  };
+  // eight 16-byte pieces of both rows requested before the first is used (a one-piece-per-trip loop keeps
+  // ONE load in flight and pays the cache latency dims/4 times); same accumulation order
+  constexpr int RB = 8;
+  const float4* a4 = (const float4*)xa;
+  const float4* b4 = (const float4*)xb;
+  const uint32_t n4 = body / 4u;
+  uint32_t m = 0;
+  for (; m + RB <= n4; m += RB) {
+    float4 ra[RB], rb[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      ra[i] = a4[m + i];
+      rb[i] = b4[m + i];
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) step(ra[i], rb[i]);
   }
+  for (; m < n4; ++m) step(a4[m], b4[m]);
   float res = ex_add(ex_add(ex_add(p0, p1), p2), p3);
   if (body != dims) {
     float tail = 0.0f;

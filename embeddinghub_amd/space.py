@@ -221,6 +221,12 @@ class Space:
     def stats_reset(self):
         check(self._L.ehx_stats_reset(self._h))
 
+    def graph_counters(self):
+        """(rows fetched, level-0 expansions, upper-level expansions, prefetch hits, ...) since the last reset"""
+        out = (C.c_uint64 * 12)()
+        check(self._L.ehx_graph_counters(self._h, out, 12))
+        return tuple(int(v) for v in out)  # [4:] phase timers of -DEHX_GRAPH_PROFILE builds, else zeros
+
 
 def nearest_neighbor_rpc(space, num, key="", embedding=None):
     """NearestNeighbor RPC semantics of embeddinghub/embeddingstore/server.cc:172-210 over a Space.

@@ -214,6 +214,12 @@ int ehx_graph_export(ehx_space* s, uint32_t* level0, int32_t* levels, uint32_t* 
 /* ---- stats ---- */
 int ehx_stats(ehx_space* s, ehx_stats_t* out);
 int ehx_stats_reset(ehx_space* s);
+/* Graph-search work counters since the last reset, the terms of SURVEY §8d's bytes-per-query formula plus a
+ * kernel diagnostic: out[0] = rows fetched (n_dist), out[1] = level-0 expansions, out[2] = upper-level
+ * expansions, out[3] = level-0 expansions whose adjacency row and visited words had been requested one
+ * expansion ahead (k_graph.hip); out[4..11] are phase timers that only -DEHX_GRAPH_PROFILE ablation builds
+ * fill.  n_out <= 12.  Zeros for a space that never ran a graph search. */
+int ehx_graph_counters(ehx_space* s, uint64_t* out, uint32_t n_out);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,7 @@ def main():
             ids, dist, cnt = g.knn(Q, k)
         wall = (time.perf_counter() - t0) / args.reps
         st = g.stats()
+        gc = g.graph_counters()
         recall = float(np.mean([len(set(ids[i]) & set(truth[i])) / k for i in range(B)]))
         best, same, orecall = 0.0, None, None
         if h is not None:
@@ -86,6 +87,11 @@ def main():
             "queries_identical_to_oracle": same,
             "n_dist_per_query": round(st["n_dist"] / (args.reps * B), 1),
             "n_hops_per_query": round(st["n_hops"] / (args.reps * B), 1),
+            "prefetch_hit_rate": round(gc[3] / max(gc[1], 1), 4),
+            # -DEHX_GRAPH_PROFILE builds only: mean microseconds per level-0 expansion spent in
+            # (pick next node, adjacency + visited, row fetch + distances, rank fresh keys, decide next + request,
+            #  insertion points, move R, tail)
+            "phase_us_per_hop": [round(v / 100.0 / max(gc[1], 1), 3) for v in gc[4:12]] if gc[4] else None,
             "bytes_per_query": round(bytes_q, 1),
             "roofline": {"bound": "hbm", "achieved": round(bytes_q * B / (kern_ms * 1e-3) / 1e9, 2), "peak": 8000.0,
                          "unit": "GB/s", "frac": round(bytes_q * B / (kern_ms * 1e-3) / 8e12, 5)},
