@@ -1424,6 +1424,12 @@ static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, con
     // in call order: a fresh key is an insertion, a known key hnswlib's update-in-place
     if (s->g_n == old_n && s->params.build_batch != 0xFFFFFFFFu) {
       if ((rc = graph_ensure_arrays(s))) return rc;
+      // Opt-in bulk write (ehx_params.build_batch > 1 given explicitly): a batch made only of fresh keys
+      // joins the graph in concurrent rounds of up to build_batch rows — hnswlib's multi-threaded
+      // add_items (offlinehub.py:89) — instead of one row per round.
+      bool all_fresh = s->params.build_batch > 1 && next - old_n == n;
+      for (size_t i = 0; i < n && all_fresh; ++i) all_fresh = ids[i] == old_n + i;
+      if (all_fresh) return graph_insert(s, old_n, n, s->params.build_batch);
       for (size_t i = 0; i < n; ++i) {
         if (ids[i] >= s->g_n) {
           if ((rc = graph_insert(s, ids[i], 1, 1))) return rc;

@@ -89,9 +89,12 @@ typedef struct ehx_params {
   uint32_t ef;              /* search ef; effective ef = max(ef, k)         */
   uint64_t seed;            /* level generator seed                         */
   uint64_t initial_capacity;/* rows; 0 -> 128 (index.h:21), doubles on fill */
-  uint32_t build_batch;     /* graph mode: rows inserted concurrently per round by bulk loads
-                               (ehx_fill_synthetic); 0 = auto, 1 = strictly sequential (hnswlib order).
-                               ehx_set / ehx_set_batch always insert sequentially.                     */
+  uint32_t build_batch;     /* graph mode: rows inserted concurrently per round by bulk loads; 0 = auto
+                               (ehx_fill_synthetic: up to 4096 per round; ehx_set / ehx_set_batch: strictly
+                               sequential = hnswlib's single-threaded addPoint order, graph bit-identical to
+                               the oracle's), 1 = strictly sequential everywhere, N > 1 = rounds of up to N
+                               rows, ALSO for an ehx_set_batch made only of fresh keys (hnswlib-python's
+                               multi-threaded add_items), 0xFFFFFFFF = no graph building (import one).    */
   uint32_t scan;            /* flat mode: EHX_SCAN_AUTO (0) = fp16 matrix-core filter scan in front of
                                the canonical fp32 re-rank, with an fp32 re-scan of every query the filter cannot
                                certify — results identical to EHX_SCAN_F32 (1) = fp32 matrix-core scan only.   */

@@ -27,6 +27,11 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--gpu-build", action="store_true", help="build the graph on the GPU (batched insertion); no oracle")
     ap.add_argument("--build-batch", type=int, default=0)
+    ap.add_argument("--data", default="gauss",
+                    help="gauss = EHX-GAUSS-1 (isotropic, the BASELINE workload: HNSW degenerates on it); "
+                         "manifold:R = rows on an R-dimensional linear manifold (z ~ N(0, I_R) times a fixed random "
+                         "R x dims matrix, plus 5 %% isotropic noise) — data with structure, where a graph index "
+                         "reaches recall >= 0.95; generated on the host and written through ehx_set_batch")
     args = ap.parse_args()
     import torch  # noqa: F401  (same HIP runtime instance as the engine)
     import embeddinghub_amd as ehx
@@ -37,7 +42,37 @@ def main():
     norm = args.metric == "cosine"
     Q = pyoracle.gen_rows(ehx.SEED_QUERY, 0, B, d, normalize=norm)
     h = None
-    if args.gpu_build:
+    manifold = None
+    if args.data.startswith("manifold:"):
+        R = int(args.data.split(":")[1])
+        A = np.random.default_rng(20250213).standard_normal((R, d)).astype(np.float32) / np.sqrt(R)
+
+        def manifold(seed, rows):
+            g = np.random.default_rng(seed)
+            x = g.standard_normal((rows, R)).astype(np.float32) @ A
+            x += 0.05 * g.standard_normal((rows, d)).astype(np.float32)
+            if norm:
+                x /= np.linalg.norm(x, axis=1, keepdims=True)
+            return np.ascontiguousarray(x, dtype=np.float32)
+        Q = manifold(ehx.SEED_QUERY, B)
+    if manifold is not None:
+        # host-generated rows through the public write path into a graph space (concurrent insertion rounds,
+        # build_batch given explicitly) and a flat space (ground truth)
+        g = ehx.Space.unique("gbench", d, metric=em, mode=ehx.MODE_GRAPH, initial_capacity=n,
+                             build_batch=args.build_batch or 4096)
+        flat = ehx.Space.unique("gbench-flat", d, metric=em, initial_capacity=n)
+        build_s, chunk = 0.0, 65536
+        for i0 in range(0, n, chunk):
+            m = min(chunk, n - i0)
+            X = manifold(ehx.SEED_CORPUS + 1 + i0 // chunk, m)
+            keys = [b"%d" % i for i in range(i0, i0 + m)]
+            t0 = time.perf_counter()
+            g.set_batch(keys, X)
+            build_s += time.perf_counter() - t0
+            flat.set_batch(keys, X)
+        builder = "GPU-built HNSW from ehx_set_batch (%s, rounds of <=%d rows, %.0f rows/s)" % (
+            args.data, args.build_batch or 4096, n / build_s)
+    elif args.gpu_build:
         g = ehx.Space.unique("gbench", d, metric=em, mode=ehx.MODE_GRAPH, initial_capacity=n, build_batch=args.build_batch)
         t0 = time.perf_counter()
         g.fill_synthetic(ehx.SEED_CORPUS, 0, n, norm)
@@ -52,9 +87,16 @@ def main():
         l0, lv, upper = h.export_graph()
         g.graph_import(l0, lv, upper, h.enterpoint, h.maxlevel)
         builder = "oracle-built HNSW"
-    flat = ehx.Space.unique("gbench-flat", d, metric=em, initial_capacity=n)
-    flat.fill_synthetic(ehx.SEED_CORPUS, 0, n, norm)
+    if manifold is None:
+        flat = ehx.Space.unique("gbench-flat", d, metric=em, initial_capacity=n)
+        flat.fill_synthetic(ehx.SEED_CORPUS, 0, n, norm)
     truth, _, _ = flat.knn(Q, k)
+    # the exact engine on the same data and queries, for the QPS-at-equal-recall comparison
+    flat.stats_reset()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        flat.knn(Q, k)
+    flat_qps = 3 * B / (time.perf_counter() - t0)
     cores = os.cpu_count() or 1
     for ef in [int(x) for x in args.efs.split(",")]:
         g.set_ef(ef)
@@ -96,6 +138,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(bytes_q * B / (kern_ms * 1e-3) / 1e9, 2), "peak": 8000.0,
                          "unit": "GB/s", "frac": round(bytes_q * B / (kern_ms * 1e-3) / 8e12, 5)},
             "cpu_oracle_qps": round(best, 1) if h is not None else None, "cpu_cores": cores,
+            "flat_exact_qps_host_pointers": round(flat_qps, 1),
         }), flush=True)
 
 

@@ -150,6 +150,46 @@ def test_batched_gpu_build_recall_parity_with_oracle():
     s.drop()
 
 
+def test_set_batch_bulk_rounds_opt_in():
+    """ehx_params.build_batch > 1: an ehx_set_batch of fresh keys joins the graph in concurrent rounds
+    (hnswlib-python's multi-threaded add_items, offlinehub.py:89); recall stays at the oracle's level, keys
+    and Get work, and a later batch that re-writes a key falls back to the sequential update path."""
+    n, d, nq, k = 12000, 48, 200, 10
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((12, d)).astype(np.float32)
+    X = (rng.standard_normal((n, 12)).astype(np.float32) @ A + 0.05 * rng.standard_normal((n, d))).astype(np.float32)
+    Q = (rng.standard_normal((nq, 12)).astype(np.float32) @ A + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
+    h = pyoracle.Hnsw(d, pyoracle.METRIC_L2, n)
+    h.add_rows(X)
+    s = ehx.Space.unique("gset", d, metric=ehx.METRIC_L2SQ, mode=ehx.MODE_GRAPH, initial_capacity=128, build_batch=512)
+    keys = ["row%d" % i for i in range(n)]
+    for i0 in range(0, n, 5000):  # three calls: growth past the initial capacity, rounds inside every call
+        s.set_batch(keys[i0:i0 + 5000], X[i0:i0 + 5000])
+    assert len(s) == n
+    truth, _, _ = pyoracle.exhaustive(X, Q, k, pyoracle.METRIC_L2)
+    h.set_ef(100)
+    s.set_ef(100)
+    labels, _, _, _, _ = h.search_batch(Q, k, threads=8)
+    ids, _, cnt = s.knn(Q, k)
+    assert (cnt == k).all()
+    r_o = np.mean([len(set(labels[i]) & set(truth[i])) / k for i in range(nq)])
+    r_g = np.mean([len(set(ids[i]) & set(truth[i])) / k for i in range(nq)])
+    assert r_o >= 0.95, r_o          # structured data: the graph index works
+    assert r_g >= r_o - 0.02, (r_g, r_o)
+    assert np.array_equal(s.get("row77"), X[77])
+    l0, lv, upper, ep, ml = s.graph_export()
+    assert (l0[:, 0] >= 1).all() and (l0[:, 0] <= 32).all()
+    for row in l0[:2000]:            # lists hold distinct ids (the search kernel's visited test relies on it)
+        c = int(row[0])
+        assert len(set(row[1:1 + c].tolist())) == c
+    # a batch that re-writes a known key goes row by row (update-in-place), the graph stays complete
+    s.set_batch(["row5", "fresh"], np.stack([X[9], X[10]]))
+    assert len(s) == n + 1 and np.array_equal(s.get("row5"), X[9])
+    ids2, _, _ = s.knn(X[10:11], 2)
+    assert set(ids2[0].tolist()) == {10, n}
+    s.drop()
+
+
 def test_update_in_place_repairs_the_graph_like_hnswlib():
     """index.cc:21-36: Set on an existing key keeps the label and takes hnswlib's updatePoint branch
     (re-selection of the one-hop neighbours' links among the two-hop set + repairConnectionsForUpdate)."""
