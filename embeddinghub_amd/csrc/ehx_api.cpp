@@ -104,6 +104,7 @@ struct ehx_space {
   const float* xf32() const { return (const float*)dX; }
   float2* dRowp = nullptr;   // [cap]
   float* dInv = nullptr;     // [cap] (cosine)
+  float* dXs = nullptr;      // [cap][ld] graph mode: the search copy (permuted blocks, cosine rows normalised)
   uint64_t cap = 0, n = 0;
   // fp16-MFMA filter scan (k_flat16.hip): unit-normalised binary16 scan copy of the rows
   bool use16 = false;          // this space scans with the fp16 filter (fp32 flat spaces, unless disabled)
@@ -184,6 +185,7 @@ struct ehx_space {
 
   ~ehx_space() {
     if (dX) (void)hipFree(dX);
+    if (dXs) (void)hipFree(dXs);
     if (dRowp) (void)hipFree(dRowp);
     if (dInv) (void)hipFree(dInv);
     if (dX16) (void)hipFree(dX16);
@@ -302,6 +304,21 @@ int grow(ehx_space* s, uint64_t rows) {
     if (s->dRowp16) (void)hipFree(s->dRowp16);
     s->dX16 = nx16;
     s->dRowp16 = nr16;
+  }
+  if (s->params.mode == EHX_MODE_GRAPH) {
+    float* nxs = nullptr;
+    if (hipMalloc((void**)&nxs, want * s->ld * sizeof(float)) != hipSuccess) {
+      (void)hipFree(nx);
+      (void)hipFree(nr);
+      (void)hipFree(ni);
+      return fail(EHX_ENOMEM, "hipMalloc failed growing the search copy of space '%s' to %llu rows", s->name.c_str(),
+                  (unsigned long long)want);
+    }
+    if (keep) HIP_TRY(hipMemcpyAsync(nxs, s->dXs, keep * s->ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemsetAsync(nxs + keep * s->ld, 0, (want - keep) * s->ld * sizeof(float), s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->dXs) (void)hipFree(s->dXs);
+    s->dXs = nxs;
   }
   if (s->dX) (void)hipFree(s->dX);
   if (s->dRowp) (void)hipFree(s->dRowp);
@@ -713,6 +730,7 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   GraphArgs a;
   a.Q = s->dQ.p;
   a.X = s->xf32();
+  a.Xs = s->dXs;
   a.inv_norm = s->dInv;
   a.adj0 = s->dAdj0;
   a.up_start = s->dUpStart;
@@ -1337,8 +1355,11 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
   return set_batch_locked(s, n, keys, klens, vecs);
 }
 
-// (re)build the fp16 scan copy of rows [row0, row0+n) after they were written; must follow row_stats
+// (re)build the derived copies of rows [row0, row0+n) after they were written; must follow row_stats:
+// graph mode: the search copy; flat fp32 spaces: the fp16 scan copy
 static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n) {
+  if (s->dXs && n)
+    HIP_TRY(launch_make_search_copy(s->xf32(), s->dInv, row0, n, s->ld, s->metric, s->dXs, s->stream));
   if (!s->use16 || n == 0) return EHX_OK;
   HIP_TRY(launch_make_scan16(s->dX, s->x_half, row0, n, s->dims, s->ld, s->ld16, s->metric, s->dX16, s->dRowp16,
                              s->dUnsafe, s->stream));

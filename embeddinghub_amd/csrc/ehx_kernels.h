@@ -221,6 +221,109 @@ __device__ __forceinline__ float canon_dist_lane_t(const float* __restrict__ q, 
   return res;
 }
 
+// The same canonical arithmetic executed by a 4-LANE GROUP over a row of the graph-mode SEARCH COPY
+// (launch_make_search_copy: inside every 16-float block the four inputs of SSE partial sum j are 16
+// contiguous bytes; cosine rows are stored normalised).  Lane `sub` of the group plays SSE lane `sub`:
+// per block it loads ONE float4 — the group reads the block as one coalesced 64-byte piece — and adds
+// its four products to its partial sum in order.  q is the query permuted the same way (LDS).  All four
+// lanes of the group must be active; every lane returns the full result.  Same register ring as above.
+template <int METRIC01>
+__device__ __forceinline__ void canon_group_step(const float4 xv, const float4 qv, float& p, int ncomp = 4) {
+  if (METRIC01 == 0) {
+    const float d0 = ex_sub(qv.x, xv.x), d1 = ex_sub(qv.y, xv.y), d2 = ex_sub(qv.z, xv.z), d3 = ex_sub(qv.w, xv.w);
+    p = ex_add(p, ex_mul(d0, d0));
+    if (ncomp > 1) p = ex_add(p, ex_mul(d1, d1));
+    if (ncomp > 2) p = ex_add(p, ex_mul(d2, d2));
+    if (ncomp > 3) p = ex_add(p, ex_mul(d3, d3));
+  } else {
+    p = ex_add(p, ex_mul(qv.x, xv.x));
+    if (ncomp > 1) p = ex_add(p, ex_mul(qv.y, xv.y));
+    if (ncomp > 2) p = ex_add(p, ex_mul(qv.z, xv.z));
+    if (ncomp > 3) p = ex_add(p, ex_mul(qv.w, xv.w));
+  }
+}
+
+// position of element m of a row inside the search copy / the permuted query
+__host__ __device__ inline uint32_t search_copy_pos(uint32_t m) { return (m & ~15u) + ((m & 3u) << 2) + ((m >> 2) & 3u); }
+
+template <int METRIC01>
+__device__ __forceinline__ float canon_dist_group_t(const float* __restrict__ qp, const float* __restrict__ xs, int sub,
+                                                    uint32_t dims) {
+  uint32_t body;
+  if ((dims & 15u) == 0 || (dims & 3u) == 0) body = dims;
+  else if (dims > 16) body = dims & ~15u;
+  else if (dims > 4) body = dims & ~3u;
+  else body = 0;
+  float p = 0.0f;
+  constexpr int BL = kLaneBlk;
+  const uint32_t n16 = body / 16u;       // full 16-float blocks: one float4 per lane each
+  const uint32_t nblk = n16 / BL;        // ring blocks
+  float4 r0[BL], r1[BL], r2[BL];
+  const float4* x4 = (const float4*)xs + sub;  // block t of this lane: x4[4 t]
+  const float4* q4 = (const float4*)qp + sub;
+#define EHX_GRP_LOAD(R, B)                                        \
+  _Pragma("unroll") for (int i_ = 0; i_ < BL; ++i_) R[i_] = x4[((size_t)(B) * BL + i_) * 4];
+#define EHX_GRP_ACC(R, B)                                         \
+  _Pragma("unroll") for (int i_ = 0; i_ < BL; ++i_) canon_group_step<METRIC01>(R[i_], q4[((size_t)(B) * BL + i_) * 4], p);
+  uint32_t b = 0;
+  if (nblk >= 2) {
+    EHX_GRP_LOAD(r0, 0)
+    EHX_GRP_LOAD(r1, 1)
+    for (; b + 5 <= nblk; b += 3) {
+      EHX_GRP_LOAD(r2, b + 2)
+      EHX_GRP_ACC(r0, b)
+      EHX_GRP_LOAD(r0, b + 3)
+      EHX_GRP_ACC(r1, b + 1)
+      EHX_GRP_LOAD(r1, b + 4)
+      EHX_GRP_ACC(r2, b + 2)
+    }
+    const uint32_t rem = nblk - b;  // 2, 3 or 4 ring blocks left; r0 / r1 hold blocks b / b+1
+    if (rem >= 3) { EHX_GRP_LOAD(r2, b + 2) }
+    EHX_GRP_ACC(r0, b)
+    if (rem == 4) { EHX_GRP_LOAD(r0, b + 3) }
+    EHX_GRP_ACC(r1, b + 1)
+    if (rem >= 3) { EHX_GRP_ACC(r2, b + 2) }
+    if (rem == 4) { EHX_GRP_ACC(r0, b + 3) }
+  } else if (nblk == 1) {
+    EHX_GRP_LOAD(r0, 0)
+    EHX_GRP_ACC(r0, 0)
+  }
+#undef EHX_GRP_LOAD
+#undef EHX_GRP_ACC
+  {
+    uint32_t t = nblk * BL;  // 16-float blocks after the last full ring block (fewer than kLaneBlk), four at a time
+    for (; t + 4 <= n16; t += 4) {
+      const float4 t0 = x4[t * 4], t1 = x4[(t + 1) * 4], t2 = x4[(t + 2) * 4], t3 = x4[(t + 3) * 4];
+      canon_group_step<METRIC01>(t0, q4[t * 4], p);
+      canon_group_step<METRIC01>(t1, q4[(t + 1) * 4], p);
+      canon_group_step<METRIC01>(t2, q4[(t + 2) * 4], p);
+      canon_group_step<METRIC01>(t3, q4[(t + 3) * 4], p);
+    }
+    for (; t < n16; ++t) canon_group_step<METRIC01>(x4[t * 4], q4[t * 4], p);
+    // the 4-float pieces of a last, partial block (body % 16 / 4 of them): components 0..rem4-1
+    const int rem4 = (int)((body & 15u) >> 2);
+    if (rem4) canon_group_step<METRIC01>(x4[n16 * 4], q4[n16 * 4], p, rem4);
+  }
+  // horizontal sum in SSE-lane order: ((p0 + p1) + p2) + p3, formed by every lane of the group
+  const float t0 = __shfl(p, 0, 4), t1 = __shfl(p, 1, 4), t2 = __shfl(p, 2, 4), t3 = __shfl(p, 3, 4);
+  float res = ex_add(ex_add(ex_add(t0, t1), t2), t3);
+  if (body != dims) {
+    float tail = 0.0f;
+    for (uint32_t m = body; m < dims; ++m) {
+      const uint32_t pos = search_copy_pos(m);
+      if (METRIC01 == 0) {
+        const float diff = ex_sub(qp[pos], xs[pos]);
+        tail = ex_add(tail, ex_mul(diff, diff));
+      } else {
+        tail = ex_add(tail, ex_mul(qp[pos], xs[pos]));
+      }
+    }
+    res = body ? ex_add(res, tail) : tail;
+  }
+  if (METRIC01 != 0) res = ex_sub(1.0f, res);
+  return res;
+}
+
 // runtime-dispatch form (metric: 0 = L2^2, 1 = 1 - inner product; scale_x: cosine rows) used by the
 // insertion kernels (EHX_INSERT_RING: with or without the register ring — A/B switch)
 #ifndef EHX_INSERT_RING
@@ -369,6 +472,10 @@ hipError_t launch_row_stats(const void* X, int x_half, uint64_t row0, uint64_t n
                             int metric, float* inv_norm, float2* rowp, hipStream_t st);
 // rowp for padding rows [row0, row0+n): (0, +inf)
 hipError_t launch_rowp_pad(float2* rowp, uint64_t row0, uint64_t n, hipStream_t st);
+// graph mode: rows [row0, row0+n) of the search copy (16-float blocks permuted for the four SSE partial
+// sums, cosine rows pre-normalised); must follow launch_row_stats (inv_norm)
+hipError_t launch_make_search_copy(const float* X, const float* inv_norm, uint64_t row0, uint64_t n, uint32_t ld,
+                                   int metric, float* Xs, hipStream_t st);
 
 // fp16 storage: rows of an fp32 matrix (stride src_ld) rounded to nearest-even into rows ids[i] (or
 // row0+i when ids == nullptr) of the fp16 matrix, and one fp16 row widened back for Get
@@ -385,6 +492,7 @@ constexpr uint32_t kGraphCounters = 12;  // n_dist, n_hops0, n_hops_up, n_prefet
 struct GraphArgs {
   const float* Q;           // prepared queries [nq][ld]
   const float* X;           // rows [cap][ld]
+  const float* Xs;          // search copy [cap][ld] (launch_make_search_copy)
   const float* inv_norm;    // cosine
   const uint32_t* adj0;     // [n][M0], pad 0xFFFFFFFF, stored order
   const uint32_t* up_start; // [n]: first upper list of the node (levels 1..L consecutive) or ~0

@@ -17,9 +17,11 @@
 // Layout re-designed for the GPU (SURVEY Appendix A.3 describes hnswlib's AoS element block):
 //   * adj0[n][2M] u32, padded with 0xFFFFFFFF, stored order preserved: one 128-B line per expansion;
 //   * upper levels: up_start[n] (index of the node's first upper list or ~0), up_lists[*][M];
-//   * vectors stay in the space's row-major X; distances use the canonical (oracle-order)
-//     arithmetic (canon_dist_lane: one lane per neighbour row, 16-byte loads), so on an imported
-//     graph the traversal, the returned ids and the distances are bit-identical to the oracle;
+//   * vectors: the space's row-major X plus a SEARCH COPY Xs (k_misc.hip: every 16-float block permuted
+//     so that the four inputs of SSE partial sum j are contiguous; cosine rows normalised): a 4-lane
+//     group reads a row in coalesced 64-byte pieces and lane j accumulates partial sum j — the canonical
+//     (oracle-order) arithmetic, so on an imported graph the traversal, the returned ids and the
+//     distances are bit-identical to the oracle;
 //   * visited set: one bit per row per in-flight query in HBM (n/8 bytes per query — 1.25 MB at 10 M
 //     rows, 1.3 GB for a 1024-query batch out of 288 GB), test-and-set with atomicOr;
 //   * work counters as SURVEY §8d: n_dist = rows actually fetched, n_hops0 / n_hops_up = expansions.
@@ -35,6 +37,9 @@ constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 // of the level-0 loop, summed over all query waves into counters[4..11]: pick next node | adjacency +
 // visited | row fetch + distances | rank fresh keys | decide next + request | insertion points | move R | tail.
 // A/B switches of the level-0 loop (ablation builds only; the defaults are the shipped kernel)
+#ifndef EHX_G_COOP
+#define EHX_G_COOP 1        // rows read by 4-lane groups from the search copy (coalesced 64-byte pieces) instead of
+#endif                      // one private row of X per lane
 #ifndef EHX_G_NEXT_EARLY
 #define EHX_G_NEXT_EARLY 1  // decide the next node before the merge and request its adjacency / visited words there
 #endif
@@ -104,19 +109,40 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   uint32_t* ids_l = (uint32_t*)(batch + 64);
   uint32_t* vis = a.visited + (size_t)qi * a.vis_words;
 
+#if EHX_G_COOP
+  for (uint32_t i = lane; i < a.ld; i += 64) qs[search_copy_pos(i)] = a.Q[(size_t)qi * a.ld + i];
+#else
   for (uint32_t i = lane; i < a.ld; i += 64) qs[i] = a.Q[(size_t)qi * a.ld + i];
+#endif
   __syncthreads();
 
   unsigned long long n_dist = 0, n_hops0 = 0, n_hops_up = 0;
 
   // canonical distance of row ids_l[lane] for lane < count: every lane owns one neighbour row and
   // keeps the 4 SSE partial sums itself (16-byte loads; the query is an LDS broadcast read)
+#if EHX_G_COOP
+  // canonical distances of rows ids_l[0..count): 16 rows per pass, one 4-lane group per row reading the
+  // search copy (canon_dist_group_t); lane p (< count) gets the distance of row p
+  auto lane_dist = [&](uint32_t count) -> float {
+    float mine = __builtin_inff();
+    for (uint32_t base = 0; base < count; base += 16) {
+      const uint32_t r = base + ((uint32_t)lane >> 2);
+      float res = __builtin_inff();
+      if (r < count)
+        res = canon_dist_group_t<METRIC01>(qs, a.Xs + (size_t)ids_l[r] * a.ld, lane & 3, a.dims);
+      const float got = __shfl(res, (lane & 15) << 2, 64);
+      if (((uint32_t)lane & ~15u) == base && (uint32_t)lane < count) mine = got;
+    }
+    return mine;
+  };
+#else
   auto lane_dist = [&](uint32_t count) -> float {
     if ((uint32_t)lane >= count) return __builtin_inff();
     const uint32_t id = ids_l[lane];
     const float xs = SCALE ? a.inv_norm[id] : 1.0f;
     return canon_dist_lane_t<METRIC01, SCALE>(qs, a.X + (size_t)id * a.ld, xs, a.dims);
   };
+#endif
 
   // ---- entry point ----
   uint32_t cur = a.entry_point;

@@ -90,6 +90,36 @@ hipError_t launch_row_stats(const void* X, int x_half, uint64_t row0, uint64_t n
   return hipGetLastError();
 }
 
+// ---- graph mode: the search copy of the rows (k_graph.hip) ------------------------------------------
+// Xs[row][16t + 4j + i] = X[row][16t + 4i + j] (* inv_norm[row] for cosine: hnswlib-python stores the
+// normalised row, one rounding per element — the same product the distance kernels otherwise form on
+// the fly).  Within every 16-float block the four inputs of SSE partial sum j become 16 contiguous
+// bytes, so a 4-lane group reads a block as ONE coalesced 64-byte piece and lane j gets exactly its
+// partial sum's inputs, in order.  Pad columns stay zero.
+namespace {
+__global__ __launch_bounds__(256) void make_search_copy_kernel(const float* __restrict__ X, const float* __restrict__ inv_norm,
+                                                               uint64_t row0, uint64_t n, uint32_t ld, int scale,
+                                                               float* __restrict__ Xs) {
+  const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // element index within the row range
+  if (e >= n * ld) return;
+  const uint64_t r = row0 + e / ld;
+  const uint32_t c = (uint32_t)(e % ld);                        // destination column
+  const uint32_t blk = c & ~15u, j = (c >> 2) & 3u, i = c & 3u;
+  float v = X[r * ld + blk + 4 * i + j];
+  if (scale) v = ex_mul(v, inv_norm[r]);
+  Xs[r * ld + c] = v;
+}
+}  // namespace
+
+hipError_t launch_make_search_copy(const float* X, const float* inv_norm, uint64_t row0, uint64_t n, uint32_t ld,
+                                   int metric, float* Xs, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const uint64_t elems = n * ld;
+  hipLaunchKernelGGL(make_search_copy_kernel, dim3((uint32_t)((elems + 255) / 256)), dim3(256), 0, st, X, inv_norm, row0,
+                     n, ld, metric == 2 ? 1 : 0, Xs);
+  return hipGetLastError();
+}
+
 // ---- fp16-MFMA filter scan: scan copy and query preparation (k_flat16.hip) ---------------------------
 // One wave per row.  The norm here is the filter's own (parallel fp32 sum; its rounding is inside the
 // eps of scan16_eps) — the canonical distances never see it.
