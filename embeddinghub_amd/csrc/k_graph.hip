@@ -94,8 +94,11 @@ __device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* a, uint32_t 
 
 }  // namespace
 
-// LDS: q[ld] floats | R[ef_cap] u64 | S[64] u64 (sorted fresh keys) | batch[64] u64 | ids[64] u32
-size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap) { return (size_t)ld * 4 + (size_t)ef_cap * 8 + 64 * 8 * 2 + 64 * 4; }
+// LDS: q[ld] floats | R[ef_cap] u64 | S[64] u64 (sorted fresh keys) | batch[64] u64 | ids[64] u32 |
+//      F[ef_cap] u8 (slots of R a fresh key lands on, during a merge)
+size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap) {
+  return (size_t)ld * 4 + (size_t)ef_cap * 8 + 64 * 8 * 2 + 64 * 4 + (((size_t)ef_cap + 15) & ~(size_t)15);
+}
 
 template <int METRIC01, bool SCALE>
 __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
@@ -107,7 +110,9 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   uint64_t* S = R + a.ef_cap;
   uint64_t* batch = S + 64;
   uint32_t* ids_l = (uint32_t*)(batch + 64);
+  uint8_t* F = (uint8_t*)(ids_l + 64);
   uint32_t* vis = a.visited + (size_t)qi * a.vis_words;
+  for (uint32_t i = lane; i < a.ef_cap; i += 64) F[i] = 0;
 
 #if EHX_G_COOP
   for (uint32_t i = lane; i < a.ld; i += 64) qs[search_copy_pos(i)] = a.Q[(size_t)qi * a.ld + i];
@@ -210,7 +215,8 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   //    expansion's atomicOrs in program order and nothing else touches the bitmap before they are used.
   //  * merge: the fresh keys are ranked by counting (broadcast LDS reads, no shuffle network), their
   //    insertion points found by binary search, and R is updated IN PLACE from the top down, touching
-  //    only [first insertion point, nR): nothing at all when no fresh key beats the current worst.
+  //    only [first insertion point, nR), one ballot + prefix popcount per 64 slots: nothing at all when
+  //    no fresh key beats the current worst.
   const uint32_t ef = a.ef;
   uint32_t nR = 1;
   if (lane == 0) {
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
       const float d = lane_dist(nfresh);
       if ((uint32_t)lane < nfresh) mykey = ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)ids_l[lane] << 1);
     }
-    scan_from = idx + 1;
+    scan_from = idx2 != kNoNode ? idx2 : nR;  // entries before idx2 are all expanded now (positions only grow)
 #ifdef EHX_GRAPH_PROFILE
     if (__any(mykey == 1ull)) prof_[7] += 1;  // keeps the distances live: the timer below waits for them
 #endif
@@ -317,37 +323,49 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     }
     EHX_PROF(4)
     if (do_merge) {
-      S[lane] = kKeyInf;  // S[nfresh..64) = +inf: the counting searches below need no bound checks
-      __syncthreads();
       if ((uint32_t)lane < nfresh) S[rank] = mykey;
       __syncthreads();
-      const uint64_t skey = S[lane];
+      uint64_t skey = kKeyInf;
       uint32_t ps = kNoNode;
-      if ((uint32_t)lane < nfresh) ps = lower_bound_lds(R, nR, skey);
+      if ((uint32_t)lane < nfresh) {
+        skey = S[lane];  // the lane-th smallest fresh key
+        ps = lower_bound_lds(R, nR, skey);
+      }
       const uint32_t p0 = __shfl(ps, 0, 64);  // insertion point of the smallest fresh key
       EHX_PROF(5)
       if (p0 < ef) {
-        // R[j], j >= p0, moves up by the number of fresh keys below it: top down, 64 entries at a time,
-        // in place — a chunk's new positions are >= its own start, so no unread entry is overwritten.
-        // (Moving 256 entries per trip with 4 interleaved searches per lane measured 9 % SLOWER: the
-        // range that moves is usually shorter than 64.)
-        for (uint32_t hi = nR; hi > p0;) {
-          const uint32_t lo = hi - p0 > 64 ? hi - 64 : p0;
-          const uint32_t j = lo + lane;
-          uint64_t kj = 0;
-          uint32_t pos = kNoNode;
-          if (j < hi) {
-            kj = R[j];
-            pos = j + lower_bound_lds(S, nfresh, kj);
-          }
-          __syncthreads();
-          if (pos < ef) R[pos] = kj;
-          __syncthreads();
-          hi = lo;
-        }
-        if ((uint32_t)lane < nfresh && ps + lane < ef) R[ps + lane] = skey;
+        // Merge in place, driven by the DESTINATION: fresh key i lands at fpos = ps_i + i (distinct,
+        // ascending); a destination slot no fresh key lands on receives the old entry whose index is the
+        // slot minus the number of fresh keys landing below it.  F flags the landing slots, so per 64 slots
+        // that number is one ballot + a lane-prefix popcount — no per-entry search.  Top down: a chunk
+        // reads only slots at or below its own, which are still untouched.
+        const uint32_t new_nR = nR + nfresh < ef ? nR + nfresh : ef;
+        const uint32_t fpos = ps + (uint32_t)lane;
+        const bool lands = (uint32_t)lane < nfresh && fpos < ef;
+        if (lands) F[fpos] = 1;
         __syncthreads();
-        nR = nR + nfresh < ef ? nR + nfresh : ef;
+        for (uint32_t dhi = new_nR; dhi > p0;) {
+          const uint32_t dlo = dhi - p0 > 64 ? dhi - 64 : p0;
+          const uint32_t dpos = dlo + (uint32_t)lane;
+          const bool in = dpos < dhi;
+          const bool taken = in && F[dpos] != 0;
+          const uint64_t occ = __ballot(taken);
+          const uint32_t below = (uint32_t)__builtin_popcountll(__ballot(lands && fpos < dlo));
+          const uint32_t cnt = below + (uint32_t)__builtin_popcountll(occ & ((1ull << lane) - 1ull));
+          const bool mv = in && !taken;
+          uint64_t kj = 0;
+          if (mv) kj = R[dpos - cnt];
+          __syncthreads();
+          if (mv) R[dpos] = kj;
+          __syncthreads();
+          dhi = dlo;
+        }
+        if (lands) {
+          R[fpos] = skey;
+          F[fpos] = 0;
+        }
+        __syncthreads();
+        nR = new_nR;
         if (p0 < scan_from) scan_from = p0;
       }
       EHX_PROF(6)
