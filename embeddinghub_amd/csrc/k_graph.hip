@@ -82,6 +82,13 @@ __device__ __forceinline__ uint32_t load_here(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+// value of a 64-bit register in lane l (wave-uniform l)
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* a, uint32_t n, uint64_t key) {
   uint32_t lo = 0, hi = n;
   while (lo < hi) {
@@ -229,22 +236,45 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   unsigned long long n_pf_hit = 0;
   EHX_PROF_DECL;
   for (;;) {
-    // closest unexpanded entry (and the one after it)
+    // closest unexpanded entry (and the one after it): 128 entries per trip (both LDS reads in flight
+    // together), the two keys taken out of the registers with readlane — one LDS latency per trip
     uint32_t idx = kNoNode, idx2 = kNoNode;
-    for (uint32_t base = scan_from & ~63u; base < nR && idx2 == kNoNode; base += 64) {
-      const uint32_t i = base + lane;
-      const bool un = i < nR && !(R[i] & 1ull);
-      uint64_t m = __ballot(un);
-      if (m && idx == kNoNode) {
-        idx = base + (uint32_t)__builtin_ctzll(m);
-        m &= m - 1;
+    uint64_t kidx = 0, kidx2 = kKeyInf;
+    for (uint32_t base = scan_from & ~63u; base < nR && idx2 == kNoNode; base += 128) {
+      const uint32_t i0 = base + lane, i1 = i0 + 64;
+      const uint64_t v0 = i0 < nR ? R[i0] : 1ull;  // beyond nR: "expanded"
+      const uint64_t v1 = i1 < nR ? R[i1] : 1ull;
+      uint64_t m0 = __ballot(!(v0 & 1ull)), m1 = __ballot(!(v1 & 1ull));
+#pragma unroll
+      for (int pick = 0; pick < 2; ++pick) {
+        if (pick == 0 ? idx != kNoNode : (idx == kNoNode || idx2 != kNoNode)) continue;
+        uint32_t at = kNoNode;
+        uint64_t key = 0;
+        if (m0) {
+          const int l = __builtin_ctzll(m0);
+          m0 &= m0 - 1;
+          at = base + (uint32_t)l;
+          key = readlane64(v0, l);
+        } else if (m1) {
+          const int l = __builtin_ctzll(m1);
+          m1 &= m1 - 1;
+          at = base + 64 + (uint32_t)l;
+          key = readlane64(v1, l);
+        }
+        if (at == kNoNode) continue;
+        if (pick == 0) {
+          idx = at;
+          kidx = key;
+        } else {
+          idx2 = at;
+          kidx2 = key;
+        }
       }
-      if (m && idx != kNoNode) idx2 = base + (uint32_t)__builtin_ctzll(m);
     }
     if (idx == kNoNode) break;
     EHX_PROF(0)
-    const uint32_t c = (uint32_t)(R[idx] & 0xFFFFFFFFull) >> 1;
-    const uint32_t c2 = idx2 != kNoNode ? (uint32_t)(R[idx2] & 0xFFFFFFFFull) >> 1 : kNoNode;
+    const uint32_t c = (uint32_t)(kidx & 0xFFFFFFFFull) >> 1;
+    const uint32_t c2 = idx2 != kNoNode ? (uint32_t)(kidx2 & 0xFFFFFFFFull) >> 1 : kNoNode;
     __syncthreads();
     if (lane == 0) R[idx] |= 1ull;
     n_hops0 += 1;
@@ -287,14 +317,14 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     if (do_merge) {
       batch[lane] = mykey;
       __syncthreads();
-      // eight keys per trip, all eight LDS reads issued before the first compare (a one-key-per-trip loop
+      // sixteen keys per trip, all LDS reads issued before the first compare (a one-key-per-trip loop
       // pays the LDS latency nfresh times); batch[nfresh..64) = +inf never counts
-      for (uint32_t j = 0; j < nfresh; j += 8) {
-        uint64_t kb[8];
+      for (uint32_t j = 0; j < nfresh; j += 16) {
+        uint64_t kb[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) kb[u] = batch[j + u];
+        for (int u = 0; u < 16; ++u) kb[u] = batch[j + u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) rank += kb[u] < mykey ? 1u : 0u;
+        for (int u = 0; u < 16; ++u) rank += kb[u] < mykey ? 1u : 0u;
       }
       const uint64_t first = __ballot((uint32_t)lane < nfresh && rank == 0);
       minkey = __shfl(mykey, (int)__builtin_ctzll(first), 64);
@@ -303,7 +333,7 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     // The node expanded next is known NOW, before the merge: the closer of the closest fresh neighbour
     // and the second unexpanded entry c2 (a fresh key below R[idx2] is always inserted; one above it
     // leaves R[idx2] where it is).  Its adjacency row / visited words fly while R is merged.
-    const uint64_t k2 = idx2 != kNoNode ? R[idx2] : kKeyInf;
+    const uint64_t k2 = kidx2;  // key of the second unexpanded entry (+inf if there is none)
     bool pf_have_word;
 #if EHX_G_NEXT_EARLY
     if (minkey < k2) {
