@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--dims", type=int, default=128)
     ap.add_argument("--metric", default="l2")
     ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--batches", default="",
+                    help="comma list of batch sizes measured on the same index (default: --batch only): more queries "
+                         "in flight = more waves per SIMD for the one-wave-per-query kernel")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--efs", default="10,50,200")
     ap.add_argument("--reps", type=int, default=5)
@@ -38,7 +41,8 @@ def main():
     from oracle import pyoracle
     em, om = {"l2": (ehx.METRIC_L2SQ, pyoracle.METRIC_L2), "cosine": (ehx.METRIC_COSINE, pyoracle.METRIC_COSINE),
               "ip": (ehx.METRIC_IP, pyoracle.METRIC_IP)}[args.metric]
-    n, d, B, k = args.rows, args.dims, args.batch, args.k
+    batches = [int(x) for x in args.batches.split(",")] if args.batches else [args.batch]
+    n, d, B, k = args.rows, args.dims, max(batches), args.k
     norm = args.metric == "cosine"
     Q = pyoracle.gen_rows(ehx.SEED_QUERY, 0, B, d, normalize=norm)
     h = None
@@ -98,49 +102,51 @@ def main():
         flat.knn(Q, k)
     flat_qps = 3 * B / (time.perf_counter() - t0)
     cores = os.cpu_count() or 1
-    for ef in [int(x) for x in args.efs.split(",")]:
-        g.set_ef(ef)
-        if h is not None:
-            h.set_ef(ef)
-        ids, dist, cnt = g.knn(Q, k)  # warm-up
-        g.stats_reset()
-        t0 = time.perf_counter()
-        for _ in range(args.reps):
-            ids, dist, cnt = g.knn(Q, k)
-        wall = (time.perf_counter() - t0) / args.reps
-        st = g.stats()
-        gc = g.graph_counters()
-        recall = float(np.mean([len(set(ids[i]) & set(truth[i])) / k for i in range(B)]))
-        best, same, orecall = 0.0, None, None
-        if h is not None:
-            labels, _, _, _, _ = h.search_batch(Q, k, threads=cores)
-            for _ in range(3):
-                _, _, _, sec, ost = h.search_batch(Q, k, threads=cores)
-                best = max(best, B / sec)
-            same = round(float(np.mean([np.array_equal(labels[i], ids[i]) for i in range(B)])), 4)
-            orecall = round(float(np.mean([len(set(labels[i]) & set(truth[i])) / k for i in range(B)])), 4)
-        bytes_q = st["bytes_algorithmic"] / (args.reps * B)
-        kern_ms = st["scan_ms_mean"]
-        print(json.dumps({
-            "workload": "%dx%d %s, graph (%s, M=16 efC=200, build %.1fs), batch=%d k=%d ef=%d" % (
-                n, d, args.metric, builder, build_s, B, k, ef),
-            "qps_host_pointers": round(B / wall, 1), "qps_kernel": round(B / (kern_ms * 1e-3), 1),
-            "kernel_ms": round(kern_ms, 4), "recall_at_k": round(recall, 4), "oracle_recall_at_k": orecall,
-            "queries_identical_to_oracle": same,
-            "n_dist_per_query": round(st["n_dist"] / (args.reps * B), 1),
-            "n_hops_per_query": round(st["n_hops"] / (args.reps * B), 1),
-            "prefetch_hit_rate": round(gc[3] / max(gc[1], 1), 4),
-            # -DEHX_GRAPH_PROFILE builds only: mean microseconds per level-0 expansion spent in
-            # (pick next node, adjacency + visited, row fetch + distances, rank fresh keys, decide next + request,
-            #  insertion points, move R, tail)
-            "phase_us_per_hop": [round(v / 100.0 / max(gc[1], 1), 3) for v in gc[4:12]] if gc[4] else None,
-            "bytes_per_query": round(bytes_q, 1),
-            "roofline": {"bound": "hbm", "achieved": round(bytes_q * B / (kern_ms * 1e-3) / 1e9, 2), "peak": 8000.0,
-                         "unit": "GB/s", "frac": round(bytes_q * B / (kern_ms * 1e-3) / 8e12, 5)},
-            "cpu_oracle_qps": round(best, 1) if h is not None else None, "cpu_cores": cores,
-            "flat_exact_qps_host_pointers": round(flat_qps, 1),
-        }), flush=True)
-
+    Q_all, truth_all = Q, truth
+    for B in batches:
+        Q, truth = Q_all[:B], truth_all[:B]
+        for ef in [int(x) for x in args.efs.split(",")]:
+            g.set_ef(ef)
+            if h is not None:
+                h.set_ef(ef)
+            ids, dist, cnt = g.knn(Q, k)  # warm-up
+            g.stats_reset()
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                ids, dist, cnt = g.knn(Q, k)
+            wall = (time.perf_counter() - t0) / args.reps
+            st = g.stats()
+            gc = g.graph_counters()
+            recall = float(np.mean([len(set(ids[i]) & set(truth[i])) / k for i in range(B)]))
+            best, same, orecall = 0.0, None, None
+            if h is not None:
+                labels, _, _, _, _ = h.search_batch(Q, k, threads=cores)
+                for _ in range(3):
+                    _, _, _, sec, ost = h.search_batch(Q, k, threads=cores)
+                    best = max(best, B / sec)
+                same = round(float(np.mean([np.array_equal(labels[i], ids[i]) for i in range(B)])), 4)
+                orecall = round(float(np.mean([len(set(labels[i]) & set(truth[i])) / k for i in range(B)])), 4)
+            bytes_q = st["bytes_algorithmic"] / (args.reps * B)
+            kern_ms = st["scan_ms_mean"]
+            print(json.dumps({
+                "workload": "%dx%d %s, graph (%s, M=16 efC=200, build %.1fs), batch=%d k=%d ef=%d" % (
+                    n, d, args.metric, builder, build_s, B, k, ef),
+                "qps_host_pointers": round(B / wall, 1), "qps_kernel": round(B / (kern_ms * 1e-3), 1),
+                "kernel_ms": round(kern_ms, 4), "recall_at_k": round(recall, 4), "oracle_recall_at_k": orecall,
+                "queries_identical_to_oracle": same,
+                "n_dist_per_query": round(st["n_dist"] / (args.reps * B), 1),
+                "n_hops_per_query": round(st["n_hops"] / (args.reps * B), 1),
+                "prefetch_hit_rate": round(gc[3] / max(gc[1], 1), 4),
+                # -DEHX_GRAPH_PROFILE builds only: mean microseconds per level-0 expansion spent in
+                # (pick next node, adjacency + visited, row fetch + distances, rank fresh keys, decide next + request,
+                #  insertion points, move R, tail)
+                "phase_us_per_hop": [round(v / 100.0 / max(gc[1], 1), 3) for v in gc[4:12]] if gc[4] else None,
+                "bytes_per_query": round(bytes_q, 1),
+                "roofline": {"bound": "hbm", "achieved": round(bytes_q * B / (kern_ms * 1e-3) / 1e9, 2), "peak": 8000.0,
+                             "unit": "GB/s", "frac": round(bytes_q * B / (kern_ms * 1e-3) / 8e12, 5)},
+                "cpu_oracle_qps": round(best, 1) if h is not None else None, "cpu_cores": cores,
+                "flat_exact_qps_host_pointers": round(flat_qps, 1),
+            }), flush=True)
 
 if __name__ == "__main__":
     main()
