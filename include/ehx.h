@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define EHX_ABI_VERSION 2
+#define EHX_ABI_VERSION 3
 
 /* ---- error codes (shim mapping: gRPC status for contract 1, fferr type for contract 2) ---- */
 enum {
