@@ -49,6 +49,11 @@ def parse():
     ap.add_argument("--set-stream", type=int, default=0, metavar="ROWS",
                     help="also time ehx_set_batch of ROWS fresh rows from host memory into a second space of the same "
                          "shape (BASELINE configs[4]: streamed Set); reported as set_stream")
+    ap.add_argument("--set-concurrent", type=int, default=0, metavar="ROWS",
+                    help="BASELINE configs[4] as written — streamed Set CONCURRENT with GetNeighbors: a writer thread "
+                         "streams ROWS fresh rows (ehx_set_batch, chunks of 8192) into a space of the bench shape (up to "
+                         "1 M rows, explicit keys) while the main thread keeps searching it; both rates reported as "
+                         "set_concurrent (rank 0)")
     ap.add_argument("--no-f32-engine", action="store_true", help="skip the short A/B leg on the fp32-only engine")
     ap.add_argument("--graph-rows", type=int, default=1_000_000,
                     help="N=1 only: also measure the graph path (GPU-built HNSW, M=16 efC=200) over the first ROWS corpus "
@@ -178,7 +183,8 @@ def main():
     B, d, k = args.batch, args.dims, args.k
     t_fill = time.time()
     metric = {"cosine": ehx.METRIC_COSINE, "l2": ehx.METRIC_L2SQ, "ip": ehx.METRIC_IP}[args.metric_kind]
-    space = ehx.Space("bench-r%d" % rank, d, metric=metric, initial_capacity=shard,
+    space = ehx.Space("bench-r%d" % rank, d, metric=metric,
+                      initial_capacity=shard,
                       dtype=ehx.DTYPE_F16 if args.rows_dtype == "f16" else ehx.DTYPE_F32)
     space.fill_synthetic(ehx.SEED_CORPUS, row0, shard, True)
     torch.cuda.synchronize()
@@ -304,6 +310,70 @@ def main():
         dt = time.perf_counter() - t0
         out["set_stream"] = {"rows": m, "rows_per_s": round(m / dt, 1), "GB_per_s_host": round(m * d * 4 / dt / 1e9, 3),
                              "chunk_rows": chunk}
+        w.drop()
+    if args.set_concurrent and rank == 0 and G == 1:
+        # streamed Set concurrent with search on the SAME space (explicit keys, so its own space: up to 1 M rows of
+        # the bench shape written through ehx_set_batch first — that load is the un-contended Set rate): writers
+        # take the space's write lock per chunk (row upload, per-row statistics, scan copy), searches take it
+        # shared per batch — every batch sees a consistent row count; both sides timed over the writer's lifetime
+        import threading
+        import numpy as np
+        m, chunk = args.set_concurrent, 8192
+        base = min(shard, 1_000_000)
+        rng = np.random.default_rng(2)
+
+        def gen(nrows):
+            x = rng.standard_normal((nrows, d), dtype=np.float32)
+            x /= np.linalg.norm(x, axis=1, keepdims=True)
+            return x
+        w = ehx.Space("bench-conc", d, metric=metric, initial_capacity=base + m,
+                      dtype=ehx.DTYPE_F16 if args.rows_dtype == "f16" else ehx.DTYPE_F32)
+        load_s = 0.0
+        for i0 in range(0, base, 65536):
+            x = gen(min(65536, base - i0))
+            ks = ["b%d" % i for i in range(i0, i0 + x.shape[0])]
+            t0 = time.perf_counter()
+            w.set_batch(ks, x)
+            load_s += time.perf_counter() - t0
+        rows = gen(m)
+        keys = ["c%d" % i for i in range(m)]
+        wsearch = ShardedSearcher(0, B, k, "cuda", space=w, stream=stream)
+        wsearch.knn(queries[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(5):
+            wsearch.knn(queries[i % n_batches])
+        torch.cuda.synchronize()
+        alone_qps = 5 * B / (time.perf_counter() - t0)
+        state = {"dt": None, "err": None}
+
+        def writer():
+            try:
+                t0 = time.perf_counter()
+                for i0 in range(0, m, chunk):
+                    w.set_batch(keys[i0:i0 + chunk], rows[i0:i0 + chunk])
+                state["dt"] = time.perf_counter() - t0
+            except Exception as e:  # noqa: BLE001 - reported in the JSON line
+                state["err"] = repr(e)
+
+        th = threading.Thread(target=writer)
+        t0 = time.perf_counter()
+        th.start()
+        batches = 0
+        while th.is_alive():
+            wsearch.knn(queries[batches % n_batches])
+            torch.cuda.synchronize()
+            batches += 1
+        th.join()
+        el = time.perf_counter() - t0
+        out["set_concurrent"] = {
+            "space": "%d x %d %s rows written through ehx_set_batch (%.0f rows/s un-contended), then %d more while "
+                     "searching" % (base, d, args.rows_dtype, base / load_s, m),
+            "rows_written_meanwhile": len(w) - base,
+            "set_rows_per_s_meanwhile": round(m / state["dt"], 1) if state["dt"] else None,
+            "search_queries_per_s_meanwhile": round(batches * B / el, 1), "search_batches_meanwhile": batches,
+            "search_queries_per_s_alone": round(alone_qps, 1), "chunk_rows": chunk, "error": state["err"],
+        }
         w.drop()
     if rank == 0 and G == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
