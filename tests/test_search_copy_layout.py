@@ -1,0 +1,95 @@
+"""Host-side check of the graph-mode SEARCH COPY layout (k_misc.hip::make_search_copy_kernel,
+ehx_kernels.h::search_copy_pos / canon_dist_group_t): restated in numpy float32 — every 16-float block
+permuted so that the four inputs of SSE partial sum j are contiguous, lane j of a 4-lane group adding its
+four products per block in order, ((p0+p1)+p2)+p3, scalar tail last — it must reproduce the oracle's
+(hnswlib SSE-order) distance bit for bit for every distance-function variant hnswlib dispatches on
+(d%16==0, d%4==0, residual-16, residual-4, scalar).  The GPU kernel itself is checked against the oracle by
+tests/test_graph_parity.py; this pins the layout the two sides agree on."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+
+f32 = np.float32
+
+
+def search_copy_pos(m):
+    return (m & ~15) + ((m & 3) << 2) + ((m >> 2) & 3)
+
+
+def make_search_copy(x, ld):
+    xs = np.zeros(ld, dtype=f32)
+    for m in range(len(x)):
+        xs[search_copy_pos(m)] = x[m]
+    return xs
+
+
+def group_distance(metric, qp, xs, dims):
+    if dims % 16 == 0 or dims % 4 == 0:
+        body = dims
+    elif dims > 16:
+        body = dims & ~15
+    elif dims > 4:
+        body = dims & ~3
+    else:
+        body = 0
+    p = [f32(0)] * 4
+    n16, rem4 = body // 16, (body % 16) // 4
+    for sub in range(4):
+        acc = f32(0)
+        for t in range(n16 + (1 if rem4 else 0)):
+            ncomp = 4 if t < n16 else rem4
+            for c in range(ncomp):
+                a, b = qp[16 * t + 4 * sub + c], xs[16 * t + 4 * sub + c]
+                if metric == pyoracle.METRIC_L2:
+                    dlt = f32(a - b)
+                    acc = f32(acc + f32(dlt * dlt))
+                else:
+                    acc = f32(acc + f32(a * b))
+        p[sub] = acc
+    res = f32(f32(f32(p[0] + p[1]) + p[2]) + p[3])
+    if body != dims:
+        tail = f32(0)
+        for m in range(body, dims):
+            a, b = qp[search_copy_pos(m)], xs[search_copy_pos(m)]
+            if metric == pyoracle.METRIC_L2:
+                dlt = f32(a - b)
+                tail = f32(tail + f32(dlt * dlt))
+            else:
+                tail = f32(tail + f32(a * b))
+        res = f32(res + tail) if body else tail
+    return f32(f32(1) - res) if metric != pyoracle.METRIC_L2 else res
+
+
+def test_permutation_is_a_bijection_on_every_block():
+    for blk in range(0, 64, 16):
+        assert sorted(search_copy_pos(m) for m in range(blk, blk + 16)) == list(range(blk, blk + 16))
+    # the four inputs of SSE partial sum j inside a block are contiguous and in order
+    for j in range(4):
+        assert [search_copy_pos(4 * i + j) for i in range(4)] == [4 * j + i for i in range(4)]
+
+
+@pytest.mark.parametrize("dims", [3, 4, 7, 16, 19, 20, 33, 100, 128, 131, 768])
+@pytest.mark.parametrize("metric", [pyoracle.METRIC_L2, pyoracle.METRIC_IP])
+def test_group_arithmetic_over_the_search_copy_equals_the_oracle(dims, metric):
+    rng = np.random.default_rng(dims * 7 + metric)
+    ld = (dims + 31) // 32 * 32
+    for _ in range(5):
+        q = rng.standard_normal(dims).astype(f32)
+        x = rng.standard_normal(dims).astype(f32)
+        want = f32(pyoracle.dist(metric, q, x))
+        got = group_distance(metric, make_search_copy(q, ld), make_search_copy(x, ld), dims)
+        assert got.tobytes() == want.tobytes(), (dims, metric, got, want)
+
+
+def test_cosine_rows_are_stored_normalised_like_hnswlib_python():
+    # cosine = inner product over rows normalised on add (one rounding per element): the search copy stores
+    # exactly that product, so the group arithmetic sees the same operands as the oracle's cosine distance
+    rng = np.random.default_rng(11)
+    dims, ld = 768, 768
+    q = pyoracle.normalize(rng.standard_normal(dims).astype(f32))
+    x = rng.standard_normal(dims).astype(f32)
+    xn = pyoracle.normalize(x)
+    want = f32(pyoracle.dist(pyoracle.METRIC_IP, q, xn))
+    got = group_distance(pyoracle.METRIC_IP, make_search_copy(q, ld), make_search_copy(xn, ld), dims)
+    assert got.tobytes() == want.tobytes()
