@@ -456,6 +456,7 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
     HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, P * vis_words * sizeof(uint32_t), st));
     InsertArgs a;
     a.X = s->xf32();
+    a.Xs = s->dXs;
     a.inv_norm = s->dInv;
     a.adj0 = s->dAdj0;
     a.up_start = s->dUpStart;
@@ -553,6 +554,7 @@ int graph_update(ehx_space* s, uint32_t id) {
   int rc;
   InsertArgs a;
   a.X = s->xf32();
+  a.Xs = s->dXs;
   a.inv_norm = s->dInv;
   a.adj0 = s->dAdj0;
   a.up_start = s->dUpStart;

@@ -511,6 +511,7 @@ hipError_t launch_graph_search(const GraphArgs& a, hipStream_t st);
 // graph-mode insertion (k_insert.hip)
 struct InsertArgs {
   const float* X;
+  const float* Xs;         // search copy (launch_make_search_copy)
   const float* inv_norm;
   uint32_t* adj0;          // [cap][M0]
   uint32_t* up_start;      // [cap]

@@ -22,6 +22,10 @@
 // the fly (x * inv_norm), i.e. exactly the vectors hnswlib would have stored.
 #include "ehx_kernels.h"
 
+#ifndef EHX_INSERT_COOP
+#define EHX_INSERT_COOP 1  // construction searches read neighbour rows through the search copy (4-lane groups)
+#endif
+
 namespace ehx {
 
 namespace {
@@ -174,17 +178,41 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
     const float s = scale_x ? a.inv_norm[me] : 1.0f;
     for (uint32_t i = lane; i < a.ld; i += 64) {
       const float v = a.X[(size_t)me * a.ld + i];
+#if EHX_INSERT_COOP
+      qs[search_copy_pos(i)] = scale_x ? ex_mul(v, s) : v;  // permuted like the search copy
+#else
       qs[i] = scale_x ? ex_mul(v, s) : v;
+#endif
     }
   }
   __syncthreads();
 
+#if EHX_INSERT_COOP
+  // canonical distances of rows ids_l[0..count) to the new row: 16 rows per pass, one 4-lane group per row
+  // reading the search copy in coalesced 64-byte pieces (canon_dist_group_t, as k_graph.hip); lane p gets row p
+  auto lane_dist = [&](uint32_t count) -> float {
+    float mine = __builtin_inff();
+    for (uint32_t base = 0; base < count; base += 16) {
+      const uint32_t r = base + ((uint32_t)lane >> 2);
+      float res = __builtin_inff();
+      if (r < count) {
+        const float* row = a.Xs + (size_t)ids_l[r] * a.ld;
+        res = metric01 == 0 ? canon_dist_group_t<0>(qs, row, lane & 3, a.dims)
+                            : canon_dist_group_t<1>(qs, row, lane & 3, a.dims);
+      }
+      const float got = __shfl(res, (lane & 15) << 2, 64);
+      if (((uint32_t)lane & ~15u) == base && (uint32_t)lane < count) mine = got;
+    }
+    return mine;
+  };
+#else
   auto lane_dist = [&](uint32_t count) -> float {
     if ((uint32_t)lane >= count) return __builtin_inff();
     const uint32_t id = ids_l[lane];
     const float xs = scale_x ? a.inv_norm[id] : 1.0f;
     return canon_dist_lane(metric01, qs, a.X + (size_t)id * a.ld, xs, scale_x, a.dims);
   };
+#endif
   auto list_of = [&](uint32_t node, int level, uint32_t* width) -> const uint32_t* {
     if (level == 0) {
       *width = a.M0;
