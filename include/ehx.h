@@ -84,7 +84,7 @@ typedef struct ehx_space ehx_space; /* opaque; owned by the process-global regis
  * (hnswlib defaults as used by index.cc:14-15: M=16, ef_construction=200, seed=100, ef=10). */
 typedef struct ehx_params {
   uint32_t mode;            /* EHX_MODE_*                                   */
-  uint32_t M;               /* graph degree (level 0 holds 2*M)             */
+  uint32_t M;               /* graph degree (level 0 holds 2*M); 2..32, GPU-side insertion needs M <= 31 */
   uint32_t ef_construction; /*                                              */
   uint32_t ef;              /* search ef; effective ef = max(ef, k)         */
   uint64_t seed;            /* level generator seed                         */

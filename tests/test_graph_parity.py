@@ -150,6 +150,41 @@ def test_batched_gpu_build_recall_parity_with_oracle():
     s.drop()
 
 
+@pytest.mark.parametrize("M", [8, 32])
+@pytest.mark.parametrize("em,om", [(ehx.METRIC_L2SQ, pyoracle.METRIC_L2), (ehx.METRIC_COSINE, pyoracle.METRIC_COSINE)])
+def test_other_degrees_M8_and_M32(M, em, om):
+    """M is a reference parameter (hnswlib default 16): M=8 -> level-0 lists of 16 (one distance pass of 16
+    rows), M=32 -> lists of 64 (four passes, every lane of the wave holds a neighbour).  Strict parity on the
+    oracle's graph, and the sequential GPU build reproduces the oracle's graph."""
+    n, d, nq, k = 2500, 48, 32, 10
+    X, h, s, rng = _build(n, d, em, om, seed=M, M=M)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    for ef in (10, 150):
+        h.set_ef(ef)
+        s.set_ef(ef)
+        s.stats_reset()
+        labels, dists, counts, _, st = h.search_batch(Q, k, threads=1)
+        ids, dist, cnt = s.knn(Q, k)
+        np.testing.assert_array_equal(cnt, counts)
+        np.testing.assert_array_equal(ids, labels)
+        assert dist.tobytes() == dists.tobytes()
+        g = s.stats()
+        assert g["n_dist"] == st["n_dist"] - nq
+        assert g["n_hops"] == st["n_hops0"] + st["n_hops_up"]
+    s.drop()
+    if M > 31:
+        with pytest.raises(ehx.EhxError, match="import the graph"):
+            ehx.Space.unique("gbuildM", d, metric=em, mode=ehx.MODE_GRAPH, M=M)
+        return
+    nb = 600
+    hb = pyoracle.Hnsw(d, om, nb, M=M)
+    hb.add_rows(X[:nb])
+    b = ehx.Space.unique("gbuildM", d, metric=em, mode=ehx.MODE_GRAPH, M=M, initial_capacity=nb)
+    b.set_batch(["k%d" % i for i in range(nb)], X[:nb])
+    _same_graph(b, hb)
+    b.drop()
+
+
 def test_set_batch_bulk_rounds_opt_in():
     """ehx_params.build_batch > 1: an ehx_set_batch of fresh keys joins the graph in concurrent rounds
     (hnswlib-python's multi-threaded add_items, offlinehub.py:89); recall stays at the oracle's level, keys
