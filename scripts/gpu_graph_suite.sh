@@ -1,5 +1,5 @@
 #!/bin/bash
-# graph-path measurement suite (profiles/r01_p_*): bench_graph on every dataset of DESIGN.md's table, the phase
+# graph-path measurement suite (profiles/r01_p_graph_*): bench_graph on every dataset of DESIGN.md's table, the phase
 # timers (ablation build), a rocprofv3 kernel trace of one bench_graph run, an FETCH_SIZE pass of the same.
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp

@@ -1,4 +1,6 @@
 #!/bin/bash
+# One GPU-box session: the GPU parity tests, smoke(), the default bench (one JSON line -> gpurun_out/bench_default.json).
+# usage: gpurun --timeout 1300 -- bash scripts/gpu_validate.sh
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 echo "== pytest -m gpu"; timeout 700 python -m pytest tests -m gpu -x -q --timeout=180 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_gpu.log
