@@ -36,6 +36,9 @@ type MI355XConfig struct {
 	Metric  string `json:"metric"`  // "cosine" (default, as redis.go:253 / pinecone.go:251), "l2", "ip"
 	Mode    string `json:"mode"`    // "flat" (exact, default) | "graph"
 	EF      uint32 `json:"ef"`
+	// graph mode: rows per concurrent insertion round of BatchSet (ehx_params.build_batch; 0 = strictly
+	// sequential, the graph single-threaded hnswlib would build; materialization wants e.g. 4096)
+	BuildBatch uint32 `json:"build_batch"`
 }
 
 type mi355xOnlineStore struct {
@@ -102,6 +105,7 @@ func (s *mi355xOnlineStore) create(feature, variant string, dims int32) (*mi355x
 		p.mode = C.EHX_MODE_GRAPH
 	}
 	p.ef = C.uint32_t(s.cfg.EF)
+	p.build_batch = C.uint32_t(s.cfg.BuildBatch)
 	var sp *C.ehx_space
 	rc := C.ehx_space_create(cname, C.size_t(len(name)), C.uint32_t(dims), s.metric(), C.EHX_DTYPE_F32, &p, &sp)
 	switch rc {
