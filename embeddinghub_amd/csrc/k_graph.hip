@@ -74,10 +74,10 @@ __device__ __forceinline__ uint64_t wave_sort64g(uint64_t key, int lane) {
 }
 
 // number of entries of the ascending array a[0..n) that are < key
-// Prefetch-style load: a relaxed atomic load (wavefront scope: no cache-policy bits) is an ordered
-// memory reference for the compiler, so it is ISSUED where it is written — a plain load whose first use
-// comes much later gets sunk down to that use by the machine-code sinking pass, and the HBM round trip
-// it was meant to overlap is exposed again.
+// Prefetch-style load: a relaxed atomic load (wavefront scope: no cache-policy bits) is an ordered memory
+// reference for the compiler, so it is issued where it is written — a plain load whose first use comes an
+// LDS-heavy phase later is a candidate for the compiler's code sinking, which would expose the HBM round
+// trip the early issue is meant to overlap.
 __device__ __forceinline__ uint32_t load_here(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
