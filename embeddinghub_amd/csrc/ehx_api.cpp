@@ -56,6 +56,7 @@ struct Engine {
   int device = 0;
   int n_cus = 256;
   std::unordered_map<std::string, std::unique_ptr<ehx_space>> spaces;
+  std::vector<std::unique_ptr<ehx_space>> graveyard;  // dropped spaces (tombstones), freed by ehx_shutdown
 };
 Engine& engine() {
   static Engine e;
@@ -93,6 +94,9 @@ struct ehx_space {
   int metric = EHX_METRIC_L2SQ;
   ehx_params params{};
   bool frozen = false;
+  bool dropped = false;        // ehx_space_drop ran: HBM released, the host object stays (tombstone) so that a
+                               // thread still holding the handle fails with EHX_ENOTFOUND instead of touching
+                               // freed memory; reclaimed by ehx_shutdown
   bool implicit_keys = false;  // rows appended by ehx_fill_synthetic: key == decimal row id
   std::shared_mutex mu;        // writers: set/drop/reserve ; readers: knn/get
 
@@ -104,10 +108,12 @@ struct ehx_space {
   const float* xf32() const { return (const float*)dX; }
   float2* dRowp = nullptr;   // [cap]
   float* dInv = nullptr;     // [cap] (cosine)
+  float* dMaxSumsq = nullptr;  // device scalar: largest |x|^2 ever written (certification margin, cert_margin)
   float* dXs = nullptr;      // [cap][ld] graph mode: the search copy (permuted blocks, cosine rows normalised)
   uint64_t cap = 0, n = 0;
   // fp16-MFMA filter scan (k_flat16.hip): unit-normalised binary16 scan copy of the rows
-  bool use16 = false;          // this space scans with the fp16 filter (fp32 flat spaces, unless disabled)
+  bool has16 = false;          // the space keeps the fp16 scan copy (maintained on every write, whatever use16 says)
+  bool use16 = false;          // ... and scans with the fp16 filter right now (ehx_space_set_scan switches it)
   __half* dX16 = nullptr;      // [cap][ld16] in the stage-blocked scan16_index layout
   float2* dRowp16 = nullptr;   // [cap]
   uint32_t ld16 = 0;
@@ -183,15 +189,26 @@ struct ehx_space {
   // stats
   std::atomic<uint64_t> n_queries{0}, n_dist{0}, n_rerank{0}, bytes_algo{0};
 
-  ~ehx_space() {
-    if (dX) (void)hipFree(dX);
-    if (dXs) (void)hipFree(dXs);
-    if (dRowp) (void)hipFree(dRowp);
-    if (dInv) (void)hipFree(dInv);
-    if (dX16) (void)hipFree(dX16);
-    if (dRowp16) (void)hipFree(dRowp16);
-    if (dUnsafe) (void)hipFree(dUnsafe);
-    if (dUncert16) (void)hipFree(dUncert16);
+  // frees every device / pinned resource (idempotent); the host-side object stays usable as a tombstone
+  void release_device() {
+    auto fr = [](auto*& p) {
+      if (p) (void)hipFree(p);
+      p = nullptr;
+    };
+    fr(dX);
+    fr(dXs);
+    fr(dRowp);
+    fr(dInv);
+    fr(dMaxSumsq);
+    fr(dX16);
+    fr(dRowp16);
+    fr(dUnsafe);
+    fr(dUncert16);
+    fr(dAdj0);
+    fr(dUpStart);
+    fr(dUpLists);
+    fr(dGraphCounters);
+    fr(dUncert);
     dQ16.release();
     dQgamma.release();
     dSample.release();
@@ -201,10 +218,6 @@ struct ehx_space {
     dUflags.release();
     dFbCnt.release();
     dFbIds.release();
-    if (dAdj0) (void)hipFree(dAdj0);
-    if (dUpStart) (void)hipFree(dUpStart);
-    if (dUpLists) (void)hipFree(dUpLists);
-    if (dGraphCounters) (void)hipFree(dGraphCounters);
     dVisited.release();
     dInsIds.release();
     dInsSel.release();
@@ -224,15 +237,26 @@ struct ehx_space {
     dOutIds.release();
     dOutDist.release();
     dOutCount.release();
-    if (dUncert) (void)hipFree(dUncert);
     if (hStage) (void)hipHostFree(hStage);
-    for (auto& e : ev)
+    hStage = nullptr;
+    hStageBytes = 0;
+    for (auto& e : ev) {
       if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+    ev_valid = false;
     for (auto& pr : ring)
-      for (auto& e : pr)
+      for (auto& e : pr) {
         if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+      }
     if (stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
+    cap = 0;
+    n = 0;
+    g_n = 0;
   }
+  ~ehx_space() { release_device(); }
 };
 
 namespace {
@@ -275,7 +299,7 @@ int grow(ehx_space* s, uint64_t rows) {
   HIP_TRY(hipMemsetAsync(ni + keep, 0, (want - keep) * sizeof(float), s->stream));
   HIP_TRY(launch_rowp_pad(nr, keep, want - keep, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  if (s->use16) {
+  if (s->has16) {
     __half* nx16 = nullptr;
     float2* nr16 = nullptr;
     // (+ tail padding: the scan's DMA reads three stage blocks / two tiles of row parameters ahead)
@@ -823,6 +847,15 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
     const uint32_t kp = k + 22 > 56 ? (k + 8 > 56 ? k + 8 : 56) : k + 22;
     for (auto& ps : passes) ps.plan.kprime = kp;
     p.kprime = kp;
+  } else if (s->dims > 1024) {
+    // fp32 scan at large d: the certification margin grows like d * 2^-24 (cert_margin) while the gap between the
+    // k-th and the k'-th best of isotropic data shrinks like ln(k'/k) / sqrt(d): widen k' (up to the 56 a
+    // 64-slot list allows) so that typical data still certifies instead of falling to the exhaustive pass
+    const double grow = std::exp(std::min(4.0, 5.3e-7 * std::pow((double)s->dims, 1.5)));
+    uint32_t kp = (uint32_t)std::ceil((double)k * grow);
+    kp = std::min<uint32_t>(56, std::max<uint32_t>(k + 8, kp));
+    for (auto& ps : passes) ps.plan.kprime = kp;
+    p.kprime = kp;
   }
   uint32_t lists_total = 0, grid_max = 0;  // every pass reuses the same list slots
   for (auto& ps : passes) {
@@ -955,6 +988,7 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
   r.ld = s->ld;
   r.metric = s->metric;
   if (f16) r.quv = s->dQuv.p;
+  r.max_sumsq = s->dMaxSumsq;
   r.uncert_flags = s->dUflags.p;
   HIP_TRY(launch_rerank(r, st));
   HIP_TRY(hipEventRecord(s->ev[3], st));
@@ -1034,8 +1068,8 @@ int exhaustive_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_quer
 //   1. fp16 matrix-core filter scan + certified re-rank      (all queries; spaces with the scan copy)
 //   2. fp32 matrix-core scan + certified re-rank              (what stage 1 could not certify / fp32-only spaces)
 //   3. canonical distance of every row                        (what stage 2 could not certify: near-ties finer
-//                                                              than fp32 rounding; at most kMaxExhaustive queries
-//                                                              per call, the rest is reported in n_uncertified)
+//                                                              than the certification margin; kMaxExhaustive
+//                                                              queries per launch group, as many groups as needed)
 // One host round trip (8 bytes) per stage to read its verdict.
 int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k,
                       uint64_t* d_ids, float* d_dist, uint32_t* d_count) {
@@ -1129,13 +1163,18 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   if ((rc = stage(kF32, all ? nullptr : &todo, !counted, &next))) return rc;
   if (next.empty()) return EHX_OK;
   todo.swap(next);
-  if (todo.size() > kMaxExhaustive) {
-    s->n_uncertified_final += todo.size();
-    return EHX_OK;
+  // Whatever the matrix-core scans could not certify is answered by the exhaustive canonical pass, kMaxExhaustive
+  // queries at a time (bounded scratch): an EHX_OK result is always the certified exhaustive top-k.
+  std::vector<uint32_t> chunk;
+  for (size_t i0 = 0; i0 < todo.size(); i0 += kMaxExhaustive) {
+    chunk.assign(todo.begin() + i0, todo.begin() + std::min(todo.size(), i0 + kMaxExhaustive));
+    if ((rc = stage(kExhaustive, &chunk, false, &next))) return rc;
+    s->n_exhaustive += chunk.size();
+    if (!next.empty()) {  // cannot happen: exact keys are never flagged
+      s->n_uncertified_final += next.size();
+      return fail(EHX_EINTERNAL, "%zu queries left uncertified by the exhaustive canonical pass", next.size());
+    }
   }
-  if ((rc = stage(kExhaustive, &todo, false, &next))) return rc;
-  s->n_exhaustive += todo.size();
-  s->n_uncertified_final += next.size();  // (always 0: exact keys are not certified)
   return EHX_OK;
 }
 
@@ -1206,6 +1245,7 @@ int ehx_shutdown(void) {
   std::lock_guard<std::mutex> lk(E.mu);
   if (E.inited) (void)hipDeviceSynchronize();
   E.spaces.clear();
+  E.graveyard.clear();  // (handles of dropped spaces die here: no call may be in flight during shutdown)
   return EHX_OK;
 }
 
@@ -1253,12 +1293,15 @@ int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metri
     const char* env = getenv("EHX_SCAN");  // "f32": every space scans in fp32 (A/B runs, profiling)
     const bool env_f32 = env && strcmp(env, "f32") == 0;
     s->use16 = s->params.mode == EHX_MODE_FLAT && s->params.scan != EHX_SCAN_F32 && !env_f32;
+    s->has16 = s->use16;
     s->ld16 = (uint32_t)round_up(dims, 128);
-    if (s->use16) {
+    if (s->has16) {
       HIP_TRY(hipMalloc((void**)&s->dUnsafe, sizeof(unsigned long long)));
       HIP_TRY(hipMemset(s->dUnsafe, 0, sizeof(unsigned long long)));
     }
   }
+  HIP_TRY(hipMalloc((void**)&s->dMaxSumsq, sizeof(float)));
+  HIP_TRY(hipMemset(s->dMaxSumsq, 0, sizeof(float)));
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
   for (auto& pr : s->ring)
@@ -1283,20 +1326,39 @@ int ehx_space_open(const char* name, size_t name_len, ehx_space** out) {
 int ehx_space_drop(ehx_space* s) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   Engine& E = engine();
-  std::lock_guard<std::mutex> lk(E.mu);
-  auto it = E.spaces.find(s->name);
-  if (it == E.spaces.end() || it->second.get() != s) return fail(EHX_ENOTFOUND, "Not found");
+  std::unique_ptr<ehx_space> owned;
   {
-    std::unique_lock<std::shared_mutex> wl(s->mu);
-    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(E.mu);
+    auto it = E.spaces.find(s->name);
+    if (it == E.spaces.end() || it->second.get() != s) return fail(EHX_ENOTFOUND, "Not found");
+    owned = std::move(it->second);
+    E.spaces.erase(it);  // the name is free again; late users of the handle see the tombstone below
   }
-  E.spaces.erase(it);
+  {
+    // Wait for every in-flight user (readers hold mu shared, writers exclusive), then release the HBM.  The host
+    // object is NOT freed: threads that fetched the handle before the drop, or are parked on its mutexes /
+    // condition variable, find `dropped` set and return EHX_ENOTFOUND.
+    std::unique_lock<std::shared_mutex> wl(s->mu);
+    std::lock_guard<std::mutex> sl(s->scratch_mu);
+    (void)hipSetDevice(E.device);
+    (void)hipDeviceSynchronize();
+    s->dropped = true;
+    s->release_device();
+    s->key_to_id.clear();
+    s->id_to_key.clear();
+    s->id_to_key.shrink_to_fit();
+    s->h_levels.clear();
+    s->h_levels.shrink_to_fit();
+  }
+  std::lock_guard<std::mutex> lk(E.mu);
+  E.graveyard.push_back(std::move(owned));
   return EHX_OK;
 }
 
 int ehx_space_freeze(ehx_space* s) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   std::unique_lock<std::shared_mutex> wl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   s->frozen = true;
   return EHX_OK;
 }
@@ -1304,6 +1366,7 @@ int ehx_space_freeze(ehx_space* s) {
 int ehx_space_size(ehx_space* s, uint64_t* n) {
   if (!valid_space(s) || !n) return fail(EHX_EINVAL, "NULL argument");
   std::shared_lock<std::shared_mutex> rl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   *n = s->n;
   return EHX_OK;
 }
@@ -1317,6 +1380,7 @@ int ehx_space_dims(ehx_space* s, uint32_t* dims) {
 int ehx_space_reserve(ehx_space* s, uint64_t rows) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   std::unique_lock<std::shared_mutex> wl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   HIP_TRY(hipSetDevice(engine().device));
   return grow(s, rows);
 }
@@ -1324,6 +1388,7 @@ int ehx_space_reserve(ehx_space* s, uint64_t rows) {
 int ehx_space_set_ef(ehx_space* s, uint32_t ef) {
   if (!valid_space(s) || ef == 0) return fail(EHX_EINVAL, "bad argument");
   std::unique_lock<std::shared_mutex> wl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   s->params.ef = ef;
   return EHX_OK;
 }
@@ -1331,7 +1396,8 @@ int ehx_space_set_ef(ehx_space* s, uint32_t ef) {
 int ehx_space_set_scan(ehx_space* s, uint32_t scan) {
   if (!valid_space(s) || scan > EHX_SCAN_F32) return fail(EHX_EINVAL, "bad argument");
   std::unique_lock<std::shared_mutex> wl(s->mu);
-  if (scan == EHX_SCAN_AUTO && !s->dX16)
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+  if (scan == EHX_SCAN_AUTO && !s->has16)
     return fail(EHX_EUNSUPPORTED, "space '%s' was created without the fp16 scan copy", s->name.c_str());
   s->params.scan = scan;
   s->use16 = scan == EHX_SCAN_AUTO;
@@ -1345,6 +1411,7 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
   if (n == 0) return EHX_OK;
   if (!keys || !klens || !vecs) return fail(EHX_EINVAL, "NULL argument");
   std::unique_lock<std::shared_mutex> wl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   if (s->params.mode == EHX_MODE_GRAPH && n > 1 && s->params.build_batch != 0xFFFFFFFFu) {
     // graph mode replays a batch in call order; when it re-writes keys (known ones, or the same key
     // twice) every row must be in HBM exactly when its turn comes, so such batches go row by row
@@ -1372,7 +1439,7 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
 static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n) {
   if (s->dXs && n)
     HIP_TRY(launch_make_search_copy(s->xf32(), s->dInv, row0, n, s->ld, s->metric, s->dXs, s->stream));
-  if (!s->use16 || n == 0) return EHX_OK;
+  if (!s->has16 || n == 0) return EHX_OK;  // (kept current even while EHX_SCAN_F32 is selected)
   HIP_TRY(launch_make_scan16(s->dX, s->x_half, row0, n, s->dims, s->ld, s->ld16, s->metric, s->dX16, s->dRowp16,
                              s->dUnsafe, s->stream));
   unsigned long long u = 0;
@@ -1392,25 +1459,29 @@ static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, con
   std::vector<uint64_t> ids(n);
   const uint64_t old_n = s->n;
   uint64_t next = s->n;
+  // fresh keys are resolved against a batch-local map and committed to key_to_id / id_to_key only after their
+  // rows are in HBM with statistics: a failing upload leaves the key maps and the row count untouched
   std::vector<std::string> new_keys;
+  std::unordered_map<std::string, uint64_t> fresh;
   for (size_t i = 0; i < n; ++i) {
     std::string k(keys[i], klens[i]);
     auto it = s->key_to_id.find(k);
-    if (it == s->key_to_id.end()) {
-      ids[i] = next;
-      s->key_to_id.emplace(k, next);
-      new_keys.push_back(std::move(k));
-      ++next;
-    } else {
+    if (it != s->key_to_id.end()) {
       ids[i] = it->second;
+      continue;
     }
+    auto f = fresh.find(k);
+    if (f != fresh.end()) {
+      ids[i] = f->second;
+      continue;
+    }
+    ids[i] = next;
+    fresh.emplace(k, next);
+    new_keys.push_back(std::move(k));
+    ++next;
   }
   int rc = ensure_rows(s, next);
-  if (rc) {
-    for (auto& k : new_keys) s->key_to_id.erase(k);
-    return rc;
-  }
-  for (auto& k : new_keys) s->id_to_key.push_back(std::move(k));
+  if (rc) return rc;
   // upload through pinned staging in slabs; rows may be non-contiguous (updates) so copy per row
   // (fp16 spaces: rows are rounded to binary16, round-to-nearest-even, while they are staged)
   const size_t row_bytes = (size_t)s->dims * s->esz;
@@ -1445,12 +1516,15 @@ static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, con
       max_id = std::max(max_id, ids[i0 + i]);
     }
   }
-  s->n = next;
   // per-row statistics over the touched id range (idempotent for untouched rows in between)
   HIP_TRY(launch_row_stats(s->dX, s->x_half, min_id, max_id - min_id + 1, s->dims, s->ld, s->metric, s->dInv,
-                           s->dRowp, s->stream));
+                           s->dRowp, s->dMaxSumsq, s->stream));
   if ((rc = refresh_scan16(s, min_id, max_id - min_id + 1))) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
+  // commit: the rows are resident and described — publish the keys and the new row count
+  for (size_t i = 0; i < new_keys.size(); ++i) s->key_to_id.emplace(new_keys[i], old_n + i);
+  for (auto& k : new_keys) s->id_to_key.push_back(std::move(k));
+  s->n = next;
   if (s->params.mode == EHX_MODE_GRAPH) {
     // new rows join the graph one at a time, in id order (ANNIndex::set -> addPoint, index.cc:36);
     // rows overwritten in place keep their links (hnswlib's updatePoint repair is not built yet)
@@ -1487,6 +1561,7 @@ int ehx_set(ehx_space* s, const char* key, size_t klen, const float* vec) {
 int ehx_get_by_id(ehx_space* s, uint64_t id, float* out_vec) {
   if (!valid_space(s) || !out_vec) return fail(EHX_EINVAL, "NULL argument");
   std::shared_lock<std::shared_mutex> rl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   if (id >= s->n) return fail(EHX_ENOTFOUND, "Not found");
   HIP_TRY(hipSetDevice(engine().device));
   if (s->x_half) {
@@ -1504,7 +1579,7 @@ int ehx_get(ehx_space* s, const char* key, size_t klen, float* out_vec) {
   uint64_t id;
   {
     std::shared_lock<std::shared_mutex> rl(s->mu);
-    if (lookup_key(s, key, klen, &id)) return fail(EHX_ENOTFOUND, "Not found");
+    if (s->dropped || lookup_key(s, key, klen, &id)) return fail(EHX_ENOTFOUND, "Not found");
   }
   return ehx_get_by_id(s, id, out_vec);
 }
@@ -1512,6 +1587,7 @@ int ehx_get(ehx_space* s, const char* key, size_t klen, float* out_vec) {
 int ehx_key_of(ehx_space* s, uint64_t id, char* out_key, size_t cap, size_t* klen) {
   if (!valid_space(s) || !klen) return fail(EHX_EINVAL, "NULL argument");
   std::shared_lock<std::shared_mutex> rl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   std::string k;
   if (key_for_id(s, id, &k)) return fail(EHX_ENOTFOUND, "Not found");
   *klen = k.size();
@@ -1526,6 +1602,7 @@ int ehx_knn_device(ehx_space* s, void* stream, size_t n_queries, const float* d_
     return fail(EHX_EINVAL, "NULL device pointer");
   std::shared_lock<std::shared_mutex> rl(s->mu);
   std::lock_guard<std::mutex> sl(s->scratch_mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   HIP_TRY(hipSetDevice(engine().device));
   return knn_device_locked(s, (hipStream_t)stream, n_queries, d_queries, k, d_out_ids, d_out_dist, d_out_count);
 }
@@ -1542,6 +1619,7 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
   if (!queries || !out_ids || !out_dist) return fail(EHX_EINVAL, "NULL argument");
   std::shared_lock<std::shared_mutex> rl(s->mu);
   std::lock_guard<std::mutex> sl(s->scratch_mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   HIP_TRY(hipSetDevice(engine().device));
   int rc;
   const size_t qbytes = n_queries * s->dims * sizeof(float);
@@ -1582,68 +1660,72 @@ int ehx_knn(ehx_space* s, size_t n_queries, const float* queries, uint32_t k, ui
   me.cnt = out_count;
   std::unique_lock<std::mutex> lk(s->bq_mu);
   s->bq.push_back(&me);
-  if (s->bq_leader) {
-    s->bq_cv.wait(lk, [&] { return me.done; });
-    if (me.rc) snprintf(g_err, sizeof(g_err), "%s", me.err);
-    return me.rc;
-  }
-  s->bq_leader = true;
   std::vector<ehx_space::KnnReq*> group;
   std::vector<float> q;
   std::vector<uint64_t> ids;
   std::vector<float> dist;
   std::vector<uint32_t> cnt;
-  while (!s->bq.empty()) {
-    // one group = the oldest request's k, in arrival order, up to kCoalesceMaxBatch queries
-    group.clear();
-    const uint32_t gk = s->bq.front()->k;
-    size_t total = 0;
-    for (auto it = s->bq.begin(); it != s->bq.end();) {
-      if ((*it)->k == gk && total + (*it)->nq <= kCoalesceMaxBatch) {
-        total += (*it)->nq;
-        group.push_back(*it);
-        it = s->bq.erase(it);
-      } else {
-        ++it;
-      }
+  while (!me.done) {
+    if (s->bq_leader) {  // somebody else is serving: wait for my result, or for the leadership to come free
+      s->bq_cv.wait(lk, [&] { return me.done || !s->bq_leader; });
+      continue;
     }
-    lk.unlock();
-    int rc;
-    if (group.size() == 1) {
-      ehx_space::KnnReq* r = group[0];
-      rc = knn_host_direct(s, r->nq, r->q, gk, r->ids, r->dist, r->cnt);
-    } else {
-      q.resize(total * s->dims);
-      ids.resize(total * gk);
-      dist.resize(total * gk);
-      cnt.resize(total);
-      size_t off = 0;
-      for (auto* r : group) {
-        memcpy(q.data() + off * s->dims, r->q, r->nq * s->dims * sizeof(float));
-        off += r->nq;
-      }
-      rc = knn_host_direct(s, total, q.data(), gk, ids.data(), dist.data(), cnt.data());
-      off = 0;
-      for (auto* r : group) {
-        if (rc == EHX_OK) {
-          memcpy(r->ids, ids.data() + off * gk, r->nq * gk * sizeof(uint64_t));
-          memcpy(r->dist, dist.data() + off * gk, r->nq * gk * sizeof(float));
-          memcpy(r->cnt, cnt.data() + off, r->nq * sizeof(uint32_t));
+    // Leader: serve groups until my own request has been answered, then hand the role to a waiter (a leader
+    // that kept serving while the queue refills would delay its own, already answered, caller without bound).
+    s->bq_leader = true;
+    while (!me.done && !s->bq.empty()) {
+      // one group = the oldest request's k, in arrival order, up to kCoalesceMaxBatch queries
+      group.clear();
+      const uint32_t gk = s->bq.front()->k;
+      size_t total = 0;
+      for (auto it = s->bq.begin(); it != s->bq.end();) {
+        if ((*it)->k == gk && total + (*it)->nq <= kCoalesceMaxBatch) {
+          total += (*it)->nq;
+          group.push_back(*it);
+          it = s->bq.erase(it);
+        } else {
+          ++it;
         }
-        off += r->nq;
       }
-      s->n_coalesced_batches += 1;
-      s->n_coalesced_queries += total;
+      lk.unlock();
+      int rc;
+      if (group.size() == 1) {
+        ehx_space::KnnReq* r = group[0];
+        rc = knn_host_direct(s, r->nq, r->q, gk, r->ids, r->dist, r->cnt);
+      } else {
+        q.resize(total * s->dims);
+        ids.resize(total * gk);
+        dist.resize(total * gk);
+        cnt.resize(total);
+        size_t off = 0;
+        for (auto* r : group) {
+          memcpy(q.data() + off * s->dims, r->q, r->nq * s->dims * sizeof(float));
+          off += r->nq;
+        }
+        rc = knn_host_direct(s, total, q.data(), gk, ids.data(), dist.data(), cnt.data());
+        off = 0;
+        for (auto* r : group) {
+          if (rc == EHX_OK) {
+            memcpy(r->ids, ids.data() + off * gk, r->nq * gk * sizeof(uint64_t));
+            memcpy(r->dist, dist.data() + off * gk, r->nq * gk * sizeof(float));
+            memcpy(r->cnt, cnt.data() + off, r->nq * sizeof(uint32_t));
+          }
+          off += r->nq;
+        }
+        s->n_coalesced_batches += 1;
+        s->n_coalesced_queries += total;
+      }
+      lk.lock();
+      for (auto* r : group) {
+        r->rc = rc;
+        if (rc) snprintf(r->err, sizeof(r->err), "%s", g_err);
+        r->done = true;
+      }
+      s->bq_cv.notify_all();
     }
-    lk.lock();
-    for (auto* r : group) {
-      r->rc = rc;
-      if (rc) snprintf(r->err, sizeof(r->err), "%s", g_err);
-      r->done = true;
-    }
-    s->bq_cv.notify_all();
+    s->bq_leader = false;
+    s->bq_cv.notify_all();  // a waiter whose request is still queued takes over
   }
-  s->bq_leader = false;
   lk.unlock();
   if (me.rc) snprintf(g_err, sizeof(g_err), "%s", me.err);
   return me.rc;
@@ -1655,6 +1737,7 @@ int ehx_knn_keys(ehx_space* s, size_t n_queries, const float* queries, uint32_t 
   int rc = ehx_knn(s, n_queries, queries, k, out_ids, out_dist, out_count);
   if (rc) return rc;
   std::shared_lock<std::shared_mutex> rl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   uint64_t off = 0;
   std::string key;
   for (size_t i = 0; i < n_queries; ++i) {
@@ -1678,7 +1761,7 @@ int ehx_knn_by_key(ehx_space* s, const char* key, size_t klen, uint32_t k, uint6
   std::vector<float> v(s->dims);
   {
     std::shared_lock<std::shared_mutex> rl(s->mu);
-    if (lookup_key(s, key, klen, &id)) return fail(EHX_ENOTFOUND, "Not found");
+    if (s->dropped || lookup_key(s, key, klen, &id)) return fail(EHX_ENOTFOUND, "Not found");
   }
   int rc = ehx_get_by_id(s, id, v.data());  // Version::get(key), server.cc:195
   if (rc) return rc;
@@ -1743,6 +1826,7 @@ int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_ro
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   if (n_rows == 0) return EHX_OK;
   std::unique_lock<std::shared_mutex> wl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   if (s->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
   if (!s->implicit_keys && s->n != 0)
     return fail(EHX_EINVAL, "space '%s' already holds keyed rows", s->name.c_str());
@@ -1766,7 +1850,8 @@ int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_ro
   } else {
     HIP_TRY(launch_gen_rows(seed, row0, n_rows, s->dims, s->ld, normalize, (float*)s->xrow(s->n), s->stream));
   }
-  HIP_TRY(launch_row_stats(s->dX, s->x_half, s->n, n_rows, s->dims, s->ld, s->metric, s->dInv, s->dRowp, s->stream));
+  HIP_TRY(launch_row_stats(s->dX, s->x_half, s->n, n_rows, s->dims, s->ld, s->metric, s->dInv, s->dRowp, s->dMaxSumsq,
+                           s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   if ((rc = refresh_scan16(s, s->n, n_rows))) return rc;
   const uint64_t old_n = s->n;
@@ -1782,6 +1867,7 @@ int ehx_graph_import(ehx_space* s, uint64_t n, const uint32_t* level0, const int
                      const uint32_t* upper_ids, uint32_t entry_point, int32_t max_level) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   std::unique_lock<std::shared_mutex> wl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   if (s->params.mode != EHX_MODE_GRAPH) return fail(EHX_EINVAL, "space '%s' is not in graph mode", s->name.c_str());
   if (n != s->n) return fail(EHX_EINVAL, "graph has %llu nodes but the space holds %llu rows", (unsigned long long)n,
                              (unsigned long long)s->n);
@@ -1862,6 +1948,7 @@ int ehx_graph_export(ehx_space* s, uint32_t* level0, int32_t* levels, uint32_t* 
                      uint64_t up_lists_cap, uint64_t* n_lists, uint32_t* entry_point, int32_t* max_level) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   std::shared_lock<std::shared_mutex> rl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   if (s->params.mode != EHX_MODE_GRAPH) return fail(EHX_EINVAL, "space '%s' is not in graph mode", s->name.c_str());
   const uint64_t n = s->g_n;
   const uint32_t M = s->params.M, M0 = 2 * M;
@@ -1898,6 +1985,7 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
   if (!valid_space(s) || !out) return fail(EHX_EINVAL, "NULL argument");
   std::shared_lock<std::shared_mutex> rl(s->mu);
   std::lock_guard<std::mutex> sl(s->scratch_mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   memset(out, 0, sizeof(*out));
   out->n_rows = s->n;
   out->capacity = s->cap;
@@ -1948,6 +2036,7 @@ int ehx_graph_counters(ehx_space* s, uint64_t* out, uint32_t n_out) {
   if (!valid_space(s) || !out) return fail(EHX_EINVAL, "NULL argument");
   if (n_out > kGraphCounters) return fail(EHX_EINVAL, "at most %u counters", kGraphCounters);
   std::lock_guard<std::mutex> sl(s->scratch_mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   unsigned long long g[kGraphCounters] = {};
   if (s->dGraphCounters) {
     HIP_TRY(hipSetDevice(engine().device));
@@ -1960,6 +2049,7 @@ int ehx_graph_counters(ehx_space* s, uint64_t* out, uint32_t n_out) {
 int ehx_stats_reset(ehx_space* s) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   std::lock_guard<std::mutex> sl(s->scratch_mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   s->n_queries = 0;
   s->n_dist = 0;
   s->n_rerank = 0;

@@ -46,6 +46,35 @@ __device__ __forceinline__ float ex_mul(float a, float b) { return a * b; }
 __device__ __forceinline__ float ex_div(float a, float b) { return a / b; }
 __device__ __forceinline__ float ex_sqrt(float a) { return __builtin_sqrtf(a); }
 
+// Certification margin of the re-rank (rerank_kernel*): an upper bound of
+//     | scan score of a row  -  that row's canonical (oracle-order) distance |
+// for EVERY row of the space, so that  "worst kept score - margin > exact k-th distance"  proves that no
+// row outside the candidate list can enter the top-k.  Both numbers are fp32 evaluations of the same real
+// quantity T over the same fp32 inputs; with u = 2^-24 and Higham's gamma_n ~ n*u:
+//   * matrix-core scan: one fma chain over d products                      -> |err| <= gamma_d     * W
+//   * canonical order : products rounded, 4 chains of d/4 adds, 3 joining adds, cosine also rounds
+//     x_i * inv_norm                                                        -> |err| <= gamma_(d/4+5) * W
+//   with W = sum|q_i x_i| <= |q| |x| (Cauchy-Schwarz): cosine W <= 1.01 (both operands normalised by their
+//   fp32 norms), inner product W <= |q| * max|x|, L2^2: every term is bounded by (|q| + max|x|)^2 (the row and
+//   query norms enter the scan score through their own d-term sums).
+//   eps_d = 1.3 * (d + 16) * u  >=  gamma_d + gamma_(d/4+5)  for every d <= 65536.
+//   * the last affine operations (score = dot*a + b, D = u*S + v, 1 - sum) round relative to the result:
+//     2e-6 * scale  (>= 32 u).
+// Filter scans (fp16 / int8 lower bounds) need only the canonical-order term; the same formula covers them.
+// max_sumsq = the largest |x|^2 ever written to the space (launch_row_stats); Inf or NaN there makes the
+// margin infinite, i.e. nothing is certified and the exhaustive canonical pass answers.
+__device__ __forceinline__ float cert_margin(int metric, uint32_t dims, float qn, float max_sumsq, float scale) {
+  const float eps_d = 1.3f * ((float)dims + 16.0f) * 5.9604645e-8f;
+  float base;
+  if (metric == 2) {
+    base = eps_d * 1.01f;
+  } else {
+    const float qb = __builtin_sqrtf(qn), mx = __builtin_sqrtf(max_sumsq);
+    base = metric == 1 ? eps_d * 1.01f * qb * mx : eps_d * 1.01f * (qb + mx) * (qb + mx);
+  }
+  return base + 2e-6f * fmaxf(scale, fmaxf(qn, 1.0f));
+}
+
 // Canonical distance between a prepared query and a stored row, in exactly the order of hnswlib's SSE
 // kernels (space_l2.h / space_ip.h; oracle/hnsw_oracle.hpp restates them): 4 strided partial sums
 // over the multiple-of-4 body (multiply and add NOT fused), horizontal sum t0+t1+t2+t3 left to
@@ -453,6 +482,7 @@ struct RerankArgs {
   const float2* quv = nullptr;
   uint32_t* uncert_flags = nullptr;  // [nq] 1 = not certified (optional)
   uint32_t exact_keys = 0;           // keys come from launch_exhaustive (exact distances): skip the certification
+  const float* max_sumsq = nullptr;  // largest |x|^2 in the space (device scalar, launch_row_stats): margin of the certificate
   uint32_t out_stride = 0, out_offset = 0;  // paged output: row stride (0 = k) and first column of this page
 };
 hipError_t launch_rerank(const RerankArgs& a, hipStream_t st);
@@ -467,9 +497,10 @@ hipError_t launch_set_floor(const uint64_t* merged, uint32_t nq, uint64_t* floor
 hipError_t launch_prep_queries(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld,
                                uint32_t q_rows, int metric, float* q_out, hipStream_t st);
 
-// per-row statistics for rows [row0, row0+n): inv_norm (cosine), rowp (a,b) for the scan epilogue
+// per-row statistics for rows [row0, row0+n): inv_norm (cosine), rowp (a,b) for the scan epilogue;
+// *max_sumsq (optional) is raised to the largest |x|^2 seen (the certification margin's norm bound)
 hipError_t launch_row_stats(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
-                            int metric, float* inv_norm, float2* rowp, hipStream_t st);
+                            int metric, float* inv_norm, float2* rowp, float* max_sumsq, hipStream_t st);
 // rowp for padding rows [row0, row0+n): (0, +inf)
 hipError_t launch_rowp_pad(float2* rowp, uint64_t row0, uint64_t n, hipStream_t st);
 // graph mode: rows [row0, row0+n) of the search copy (16-float blocks permuted for the four SSE partial

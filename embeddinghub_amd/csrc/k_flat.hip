@@ -572,7 +572,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
     d = canon_dist(a.metric == 0 ? 0 : 1, qv, xv, xs, scale_x, a.dims, sub);
   }
   if (sub == 0) {
-    keys[g] = valid ? (((uint64_t)f32_to_ordered(d) << 32) | id) : kKeyInf;
+    // (a NaN distance — a row or query holding NaN — is never a neighbour: the key is dropped)
+    keys[g] = (valid && d == d) ? (((uint64_t)f32_to_ordered(d) << 32) | id) : kKeyInf;
     approx[g] = valid ? ordered_to_f32((uint32_t)(mk >> 32)) : __builtin_inff();
   }
   __syncthreads();
@@ -593,8 +594,9 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
     // certification: every row that is NOT a candidate has approx score >= the worst candidate's
     // approx score A_last (for L2 the scan's score omits |q|^2, added back here).  If
     // A_last - margin > exact k-th distance, no outsider can beat the k-th result, so the top-k is
-    // provably the exhaustive top-k.  margin bounds the fp32 rounding gap between the MFMA-order
-    // score and the canonical-order distance.  (Skipped when every row is a candidate.)
+    // provably the exhaustive top-k.  margin (cert_margin, ehx_kernels.h) is a worst-case bound of the gap
+    // between an outsider's scan score and its canonical-order distance.  (Skipped when every row is a
+    // candidate.)
     bool uncert = false;
     if (a.exact_keys) {
       // the keys are canonical distances of every row (exhaustive pass): nothing to certify
@@ -602,22 +604,23 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
       float worst = -__builtin_inff();
       for (int j = 0; j < 64; ++j)
         if (approx[j] != __builtin_inff() && approx[j] > worst) worst = approx[j];
-      float qn = 0.0f;
+      float qn = 1.0f;  // |q|^2 of the query the distances are taken from (cosine: the normalised query)
       if (a.quv) {
-        // fp16-filter keys: `worst` is a lower bound S of every outsider's score; map it to a distance
+        // filter keys: `worst` is a lower bound S of every outsider's score; map it to a distance
         // (NaN u marks a query the filter could not bound: the comparison below fails)
         const float2 uv = a.quv[q];
         worst = __builtin_fmaf(uv.x, worst, uv.y);
-        qn = a.metric == 0 ? uv.y : 0.0f;
-      } else if (a.metric == 0) {
+        qn = a.metric == 0 ? uv.y : (a.metric == 1 ? uv.x * uv.x : 1.0f);
+      } else {
         const float* qv = a.Q + (size_t)q * a.ld;
+        qn = 0.0f;
         for (uint32_t m = tid; m < a.dims; m += 64) qn += qv[m] * qv[m];
         for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o, 64);
-        worst += qn;
+        if (a.metric == 0) worst += qn;
       }
       const float kth = ordered_to_f32((uint32_t)(__shfl(key, (int)a.k - 1, 64) >> 32));
-      const float scale = fmaxf(fmaxf(fabsf(kth), fabsf(worst)), fmaxf(qn, 1.0f));
-      const float margin = 1e-5f * scale;
+      const float margin = cert_margin(a.metric, a.dims, qn, a.max_sumsq ? *a.max_sumsq : __builtin_inff(),
+                                       fmaxf(fabsf(kth), fabsf(worst)));
       uncert = !(worst - margin > kth);
     } else if (a.quv && a.n > a.kprime && cnt < a.k) {
       uncert = true;  // the filter lost candidates (overflowing gamma etc.): let the fp32 scan decide
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(256) void exhaustive_kernel(const float* __restrict
       d = canon_dist(metric == 0 ? 0 : 1, qv, X + (size_t)id * ld, xs, scale_x, dims, sub);
     }
     if (sub == 0) {
-      uint64_t key = id < r1 ? (((uint64_t)f32_to_ordered(d) << 32) | id) : kKeyInf;
+      uint64_t key = (id < r1 && d == d) ? (((uint64_t)f32_to_ordered(d) << 32) | id) : kKeyInf;  // NaN: not a neighbour
       if (paged && key <= fl) key = kKeyInf;
       keys[g] = key;
     }

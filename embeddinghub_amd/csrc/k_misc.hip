@@ -61,11 +61,15 @@ template <typename XT>
 __global__ __launch_bounds__(256) void row_stats_kernel(const XT* __restrict__ X, uint64_t row0,
                                                         uint64_t n, uint32_t dims, uint32_t ld, int metric,
                                                         float* __restrict__ inv_norm,
-                                                        float2* __restrict__ rowp) {
+                                                        float2* __restrict__ rowp,
+                                                        unsigned int* __restrict__ max_sumsq) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t r = row0 + i;
   const float s = seq_sumsq(X + r * ld, dims);
+  // largest |x|^2 ever written to the space (bit pattern of a non-negative float orders like the float;
+  // NaN / Inf rows park it at +Inf): the re-rank's certification margin needs a bound of every row's norm
+  if (max_sumsq) atomicMax(max_sumsq, (s == s) ? __float_as_uint(s) : 0x7F800000u);
   if (metric == 2) {
     const float inv = inv_norm_of(s);
     inv_norm[r] = inv;
@@ -78,15 +82,15 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const XT* __restrict__ X
 }
 
 hipError_t launch_row_stats(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
-                            int metric, float* inv_norm, float2* rowp, hipStream_t st) {
+                            int metric, float* inv_norm, float2* rowp, float* max_sumsq, hipStream_t st) {
   if (n == 0) return hipSuccess;
   const uint32_t grid = (uint32_t)((n + 255) / 256);
   if (x_half)
     hipLaunchKernelGGL(row_stats_kernel<__half>, dim3(grid), dim3(256), 0, st, (const __half*)X, row0, n, dims, ld,
-                       metric, inv_norm, rowp);
+                       metric, inv_norm, rowp, (unsigned int*)max_sumsq);
   else
     hipLaunchKernelGGL(row_stats_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)X, row0, n, dims, ld,
-                       metric, inv_norm, rowp);
+                       metric, inv_norm, rowp, (unsigned int*)max_sumsq);
   return hipGetLastError();
 }
 
