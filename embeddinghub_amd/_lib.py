@@ -14,7 +14,8 @@ OK, EINVAL, ENOTFOUND, EEXISTS, EIMMUTABLE, ENODEVICE, ENOMEM, ERANGE, EUNSUPPOR
 METRIC_L2SQ, METRIC_IP, METRIC_COSINE = 0, 1, 2
 MODE_FLAT, MODE_GRAPH = 0, 1
 DTYPE_F32, DTYPE_F16 = 0, 1
-SCAN_AUTO, SCAN_F32 = 0, 1
+SCAN_AUTO, SCAN_F32, SCAN_F16 = 0, 1, 2
+ENGINE_F32, ENGINE_F16, ENGINE_I8 = 0, 1, 2
 MAX_K = 48
 SEED_CORPUS, SEED_QUERY = 20250211, 20250212
 
@@ -38,7 +39,7 @@ class Stats(C.Structure):
                 ("last_scan_ms", C.c_double), ("last_total_ms", C.c_double),
                 ("scan_ms_mean", C.c_double), ("scan_launches", C.c_uint64),
                 ("n_filter_queries", C.c_uint64), ("n_filter_fallback", C.c_uint64),
-                ("n_exhaustive", C.c_uint64)]
+                ("n_exhaustive", C.c_uint64), ("n_i8_queries", C.c_uint64), ("n_i8_fallback", C.c_uint64)]
 
 
 # every symbol include/ehx.h declares: name -> (restype, argtypes)
@@ -60,6 +61,7 @@ SYMBOLS = {
     "ehx_space_reserve": (C.c_int, [_vp, C.c_uint64]),
     "ehx_space_set_ef": (C.c_int, [_vp, C.c_uint32]),
     "ehx_space_set_scan": (C.c_int, [_vp, C.c_uint32]),
+    "ehx_space_scan_engine": (C.c_int, [_vp, _u32p]),
     "ehx_set": (C.c_int, [_vp, C.c_char_p, C.c_size_t, _f32p]),
     "ehx_set_batch": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), _f32p]),
     "ehx_get": (C.c_int, [_vp, C.c_char_p, C.c_size_t, _f32p]),

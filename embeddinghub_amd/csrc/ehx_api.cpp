@@ -119,6 +119,16 @@ struct ehx_space {
   uint32_t ld16 = 0;
   unsigned long long* dUnsafe = nullptr;  // rows the filter cannot bound (then every scan is the fp32 scan)
   uint64_t h_unsafe = 0;
+  // int8-MFMA filter scan (k_flati8.hip): per-row-scaled int8 scan copy of the unit-normalised rows
+  bool has8 = false;           // the space keeps the int8 scan copy (flat spaces whose row length makes it pay)
+  int8_t* dX8 = nullptr;       // [cap][ld8] in the stage-blocked scan8_index layout
+  float4* dRowp8 = nullptr;    // [cap + 512] (A, B, C, D)
+  float4* dTilep8 = nullptr;   // [cap/256 + 2]
+  uint32_t ld8 = 0;
+  unsigned long long* dUnsafe8 = nullptr;
+  uint64_t h_unsafe8 = 0;
+  uint64_t i8_min_rows = 16384;  // below this the fp16 filter serves (sample pass + cascade need a few thousand rows)
+  uint32_t scan_sel = EHX_SCAN_AUTO;  // EHX_SCAN_*: what ehx_space_set_scan selected
 
   // graph (graph mode): imported adjacency, re-laid-out for the GPU (k_graph.hip)
   uint32_t* dAdj0 = nullptr;     // [g_n][2M]
@@ -158,7 +168,14 @@ struct ehx_space {
   DevBuf<uint32_t> dUflags, dFbCnt;
   DevBuf<uint64_t> dFbIds;
   unsigned long long* dUncert16 = nullptr;  // queries the filter pass could not certify
+  // int8 filter scratch: query tiles + parameters, per-pass thresholds, sample scores, pools, running best 256
+  DevBuf<int8_t> dQ8;
+  DevBuf<float4> dQp8;
+  DevBuf<float> dThr8, dSample8;
+  DevBuf<uint64_t> dPool, dMerged8;
+  DevBuf<uint32_t> dI8Ctl;  // [q_rows] pool counts | [q_rows] overflow flags | [256] lock-step counters
   std::atomic<uint64_t> n_filter_queries{0}, n_filter_fallback{0}, n_exhaustive{0}, n_uncertified_final{0};
+  std::atomic<uint64_t> n_i8_queries{0}, n_i8_fallback{0};
   float* hStage = nullptr;  // pinned staging (Set / Get / query upload)
   size_t hStageBytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -203,6 +220,17 @@ struct ehx_space {
     fr(dX16);
     fr(dRowp16);
     fr(dUnsafe);
+    fr(dX8);
+    fr(dRowp8);
+    fr(dTilep8);
+    fr(dUnsafe8);
+    dQ8.release();
+    dQp8.release();
+    dThr8.release();
+    dSample8.release();
+    dPool.release();
+    dMerged8.release();
+    dI8Ctl.release();
     fr(dUncert16);
     fr(dAdj0);
     fr(dUpStart);
@@ -328,6 +356,41 @@ int grow(ehx_space* s, uint64_t rows) {
     if (s->dRowp16) (void)hipFree(s->dRowp16);
     s->dX16 = nx16;
     s->dRowp16 = nr16;
+  }
+  if (s->has8) {
+    int8_t* nx8 = nullptr;
+    float4* nr8 = nullptr;
+    float4* nt8 = nullptr;
+    const uint64_t tiles = want / kTileRows16;
+    hipError_t e5 = hipMalloc((void**)&nx8, want * s->ld8 + kScan8TailPadBytes);
+    hipError_t e6 = hipMalloc((void**)&nr8, (want + 2 * kTileRows16) * sizeof(float4));
+    hipError_t e7 = hipMalloc((void**)&nt8, (tiles + 2) * sizeof(float4));
+    if (e5 != hipSuccess || e6 != hipSuccess || e7 != hipSuccess) {
+      if (nx8) (void)hipFree(nx8);
+      if (nr8) (void)hipFree(nr8);
+      if (nt8) (void)hipFree(nt8);
+      (void)hipFree(nx);
+      (void)hipFree(nr);
+      (void)hipFree(ni);
+      return fail(EHX_ENOMEM, "hipMalloc failed growing the int8 scan copy of space '%s' to %llu rows", s->name.c_str(),
+                  (unsigned long long)want);
+    }
+    const uint64_t keep8 = round_up(keep, kTileRows16), keep_tiles = keep8 / kTileRows16;
+    if (keep) {
+      HIP_TRY(hipMemcpyAsync(nx8, s->dX8, keep8 * s->ld8, hipMemcpyDeviceToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(nr8, s->dRowp8, keep8 * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(nt8, s->dTilep8, keep_tiles * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+    }
+    HIP_TRY(hipMemsetAsync(nx8 + keep8 * s->ld8, 0, (want - keep8) * s->ld8 + kScan8TailPadBytes, s->stream));
+    HIP_TRY(launch_rowp8_pad(nr8, keep8, want + 2 * kTileRows16 - keep8, s->stream));
+    HIP_TRY(launch_tilep8_pad(nt8, keep_tiles, tiles + 2 - keep_tiles, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->dX8) (void)hipFree(s->dX8);
+    if (s->dRowp8) (void)hipFree(s->dRowp8);
+    if (s->dTilep8) (void)hipFree(s->dTilep8);
+    s->dX8 = nx8;
+    s->dRowp8 = nr8;
+    s->dTilep8 = nt8;
   }
   if (s->params.mode == EHX_MODE_GRAPH) {
     float* nxs = nullptr;
@@ -1004,6 +1067,166 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
   return EHX_OK;
 }
 
+// which scan engine answers first on this space right now: EHX_ENGINE_* (include/ehx.h)
+int resolve_engine(const ehx_space* s) {
+  if (s->params.mode != EHX_MODE_FLAT || s->scan_sel == EHX_SCAN_F32 || s->n == 0) return EHX_ENGINE_F32;
+  if (s->scan_sel == EHX_SCAN_AUTO && s->has8 && s->h_unsafe8 == 0 && s->n >= s->i8_min_rows) return EHX_ENGINE_I8;
+  if (s->has16 && s->h_unsafe == 0) return EHX_ENGINE_F16;
+  return EHX_ENGINE_F32;
+}
+
+// The int8 filter pipeline (k_flati8.hip, k_select.hip): prepared queries -> sample pass (first thresholds) ->
+// cascade of collect passes, x4 in rows, each followed by select256 (running best 256 + the next threshold) ->
+// rerank256 (canonical distances of the k' = 128 best lower bounds, top-k, certificate).  Per-query verdicts land in
+// s->dUflags / s->dUncert16 like those of flat_pass.
+int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k, uint64_t* d_ids,
+               float* d_dist, uint32_t* d_count, bool count_stats) {
+  Engine& E = engine();
+  static const uint32_t growth = [] {
+    const char* g = getenv("EHX_I8_GROWTH");
+    const long v = g ? atol(g) : 4;
+    return (uint32_t)(v < 2 ? 2 : (v > 64 ? 64 : v));
+  }();
+  static const bool use_sync = [] {
+    const char* g = getenv("EHX_I8_SYNC");
+    return g ? atoi(g) != 0 : true;
+  }();
+  constexpr uint32_t kSampleTiles = 8;
+  // the int8 bound leaves ~60-75 rows per query it cannot exclude from the top-10 (scripts/studies/int8_filter_bound.py);
+  // more for a larger k (the k-th best sits where rows are denser)
+  const uint32_t kprime = k <= 16 ? 128u : std::min<uint32_t>(192u, 96u + 2u * k);
+  const uint32_t n_tiles = (uint32_t)((s->n + kTileRows16 - 1) / kTileRows16);
+  struct Pass {
+    uint32_t tile0;
+    ScanPlan plan;
+  };
+  std::vector<Pass> passes;
+  {
+    uint32_t done = 0, cum = 4 * kSampleTiles;
+    while ((uint64_t)cum * 2 < n_tiles) {
+      passes.push_back({done, plan_scan((uint32_t)nq, cum - done, k, E.n_cus)});
+      done = cum;
+      cum *= growth;
+    }
+    passes.push_back({done, plan_scan((uint32_t)nq, n_tiles - done, k, E.n_cus)});
+  }
+  const ScanPlan p = passes.back().plan;  // (q_tiles, q_rows are the same for every pass)
+  uint32_t grid_max = 0, chunks_max = 0;
+  for (auto& ps : passes) {
+    grid_max = std::max(grid_max, ps.plan.grid);
+    chunks_max = std::max(chunks_max, ps.plan.n_chunks);
+  }
+  if (chunks_max > 256) return fail(EHX_EINTERNAL, "scan plan with %u chunks", chunks_max);
+  int rc;
+  if ((rc = s->dQ.ensure((size_t)p.q_rows * s->ld))) return rc;
+  if ((rc = s->dQ8.ensure(scanq8_bytes(p.q_rows, s->ld8)))) return rc;
+  if ((rc = s->dQp8.ensure(p.q_rows))) return rc;
+  if ((rc = s->dQuv.ensure(p.q_rows))) return rc;
+  if ((rc = s->dThr8.ensure(p.q_rows))) return rc;
+  if ((rc = s->dSample8.ensure((size_t)kSampleTiles * kTileRows16 * p.q_rows))) return rc;
+  if ((rc = s->dCand.ensure((size_t)grid_max * 512 * kCandSlots))) return rc;
+  if ((rc = s->dPool.ensure((size_t)p.q_rows * kPoolCap))) return rc;
+  if ((rc = s->dMerged8.ensure((size_t)p.q_rows * kMerged8))) return rc;
+  if ((rc = s->dI8Ctl.ensure((size_t)p.q_rows * 2 + 256))) return rc;
+  if ((rc = s->dUflags.ensure(p.q_rows))) return rc;
+  if (!s->dUncert16) {
+    HIP_TRY(hipMalloc((void**)&s->dUncert16, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(s->dUncert16, 0, sizeof(unsigned long long)));
+  }
+  uint32_t* pool_cnt = s->dI8Ctl.p;
+  uint32_t* ovf = s->dI8Ctl.p + p.q_rows;
+  uint32_t* sync = s->dI8Ctl.p + 2 * (size_t)p.q_rows;
+  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
+  HIP_TRY(hipEventRecord(s->ev[0], st));
+  HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, p.q_rows, s->metric, s->dQ.p, st));
+  HIP_TRY(launch_prep_queries8(d_queries, (uint32_t)nq, s->dims, s->ld8, p.q_rows, s->metric, s->dQ8.p, s->dQp8.p,
+                               s->dQuv.p, s->dThr8.p, st));
+  HIP_TRY(hipMemsetAsync(s->dI8Ctl.p, 0, ((size_t)p.q_rows * 2 + 256) * sizeof(uint32_t), st));
+  ScanArgsI8 a;
+  a.Q = s->dQ8.p;
+  a.X = s->dX8;
+  a.rowp = s->dRowp8;
+  a.tilep = s->dTilep8;
+  a.qparams = s->dQp8.p;
+  a.thr = s->dThr8.p;
+  a.cand = s->dCand.p;
+  a.pool = s->dPool.p;
+  a.pool_cnt = pool_cnt;
+  a.ovf = ovf;
+  a.pool_cap = kPoolCap;
+  a.n = (uint32_t)s->n;
+  a.ld = s->ld8;
+  a.q_tiles = p.q_tiles;
+  auto scan = [&](const ScanPlan& pl, uint32_t tile0) -> hipError_t {
+    a.tile0 = tile0;
+    a.n_tiles = pl.n_tiles;
+    a.n_chunks = pl.n_chunks;
+    a.tiles_per_chunk = pl.tiles_per_chunk;
+    a.xcd_map = pl.xcd_map;
+    return launch_flat_scan_i8(a, st);
+  };
+  hipEvent_t* pr = s->ring[s->ring_count % ehx_space::kRing];
+  HIP_TRY(hipEventRecord(s->ev[1], st));
+  HIP_TRY(hipEventRecord(pr[0], st));
+  {  // sample pass: lower bounds of the first 2048 rows -> thr[q] = the k'-th best of them
+    ScanPlan sp = plan_scan((uint32_t)nq, kSampleTiles, k, E.n_cus);
+    a.dump = s->dSample8.p;
+    a.sync = nullptr;
+    HIP_TRY(scan(sp, 0));
+    a.dump = nullptr;
+    HIP_TRY(launch_sample_select256(s->dSample8.p, kSampleTiles * kTileRows16, p.q_rows, (uint32_t)nq, kprime,
+                                    s->dThr8.p, st));
+  }
+  for (size_t i = 0; i < passes.size(); ++i) {
+    const bool last = i + 1 == passes.size();
+    a.sync = nullptr;
+    if (use_sync && passes[i].plan.xcd_map && p.q_tiles > 1 && passes[i].plan.tiles_per_chunk >= 4) {
+      a.sync = sync;
+      if (i > 0) HIP_TRY(hipMemsetAsync(sync, 0, 256 * sizeof(uint32_t), st));
+    }
+    HIP_TRY(scan(passes[i].plan, passes[i].tile0));
+    if (last) {  // (the last select and the re-rank are outside the timed scan phase, like flat_pass's final merge)
+      HIP_TRY(hipEventRecord(pr[1], st));
+      HIP_TRY(hipEventRecord(s->ev[2], st));
+      s->ring_count++;
+    }
+    HIP_TRY(launch_select256(s->dPool.p, pool_cnt, kPoolCap, (uint32_t)nq, kprime, s->dMerged8.p, i > 0, s->dThr8.p,
+                             st));
+  }
+  Rerank256Args r;
+  r.Q = s->dQ.p;
+  r.X = s->dX;
+  r.x_half = (uint32_t)s->x_half;
+  r.inv_norm = s->dInv;
+  r.merged = s->dMerged8.p;
+  r.ovf = ovf;
+  r.quv = s->dQuv.p;
+  r.max_sumsq = s->dMaxSumsq;
+  r.out_ids = d_ids;
+  r.out_dist = d_dist;
+  r.out_count = d_count;
+  r.n_uncertified = s->dUncert16;
+  r.uncert_flags = s->dUflags.p;
+  r.nq = (uint32_t)nq;
+  r.k = k;
+  r.kprime = kprime;
+  r.n = (uint32_t)s->n;
+  r.dims = s->dims;
+  r.ld = s->ld;
+  r.metric = s->metric;
+  HIP_TRY(launch_rerank256(r, st));
+  HIP_TRY(hipEventRecord(s->ev[3], st));
+  s->ev_valid = true;
+  if (count_stats) {
+    s->n_queries += nq;
+    s->n_dist += (uint64_t)nq * s->n;
+    // SURVEY §8d brute force bytes per batch: N*d*s + B*d*4 + B*k*12 (s = 1: the int8 scan copy)
+    s->bytes_algo += s->n * (uint64_t)s->dims + (uint64_t)nq * s->dims * 4ull + (uint64_t)nq * k * 12ull;
+  }
+  s->n_rerank += (uint64_t)nq * kprime;
+  return EHX_OK;
+}
+
 // Exhaustive canonical pass: the canonical distance of every row for `nq` queries (k_flat.hip:
 // exhaustive_kernel), merged and emitted through the re-rank with the certification switched off (the keys
 // are exact).  Serves (a) queries no matrix-core scan can certify and (b) requests with k > EHX_MAX_K, which
@@ -1065,7 +1288,8 @@ int exhaustive_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_quer
 
 // Device pipeline of a flat space: up to three stages, each run only for the queries the previous one
 // could not certify, so the answer is always the exhaustive fp32 answer in the oracle's arithmetic:
-//   1. fp16 matrix-core filter scan + certified re-rank      (all queries; spaces with the scan copy)
+//   0. int8 matrix-core filter scan + certified re-rank      (all queries; spaces with the int8 scan copy, >= i8_min_rows)
+//   1. fp16 matrix-core filter scan + certified re-rank      (what stage 0 could not certify / spaces without it)
 //   2. fp32 matrix-core scan + certified re-rank              (what stage 1 could not certify / fp32-only spaces)
 //   3. canonical distance of every row                        (what stage 2 could not certify: near-ties finer
 //                                                              than the certification margin; kMaxExhaustive
@@ -1096,7 +1320,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     return EHX_OK;
   }
   constexpr size_t kMaxExhaustive = 32;
-  enum { kFilter, kF32, kExhaustive };
+  enum { kI8, kFilter, kF32, kExhaustive };
   int rc;
   // run one stage on `subset` (nullptr = every query); *unc = global indices it could not certify
   auto stage = [&](int kind, const std::vector<uint32_t>* subset, bool count_stats, std::vector<uint32_t>* unc) -> int {
@@ -1119,6 +1343,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
       oc = s->dFbCnt.p;
     }
     if (kind == kExhaustive) rc = exhaustive_pass(s, st, m, q, k, oi, od, oc);
+    else if (kind == kI8) rc = flat_pass8(s, st, m, q, k, oi, od, oc, count_stats);
     else rc = flat_pass(s, st, m, q, k, oi, od, oc, kind == kFilter, count_stats);
     if (rc) return rc;
     if (subset) {
@@ -1151,10 +1376,21 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   std::vector<uint32_t> todo, next;
   bool all = true;  // `todo` = every query
   bool counted = false;
-  if (s->use16 && s->h_unsafe == 0 && s->n > 0) {
-    if ((rc = stage(kFilter, nullptr, true, &next))) return rc;
+  const int eng = resolve_engine(s);
+  if (eng == EHX_ENGINE_I8) {
+    if ((rc = stage(kI8, nullptr, true, &next))) return rc;
     counted = true;
-    s->n_filter_queries += nq;
+    s->n_i8_queries += nq;
+    s->n_i8_fallback += next.size();
+    if (next.empty()) return EHX_OK;
+    todo.swap(next);
+    all = todo.size() * 2 > nq;
+  }
+  if ((eng == EHX_ENGINE_I8 || eng == EHX_ENGINE_F16) && s->has16 && s->h_unsafe == 0) {
+    const size_t m = all ? nq : todo.size();
+    if ((rc = stage(kFilter, all ? nullptr : &todo, !counted, &next))) return rc;
+    counted = true;
+    s->n_filter_queries += m;
     s->n_filter_fallback += next.size();
     if (next.empty()) return EHX_OK;
     todo.swap(next);
@@ -1288,16 +1524,27 @@ int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metri
                   "graph mode: M=32 spaces cannot build their graph on the GPU (2M+1 candidates exceed one wave); "
                   "create the space with build_batch = 0xFFFFFFFF and import the graph (ehx_graph_import)");
   }
-  if (s->params.scan > EHX_SCAN_F32) return fail(EHX_EINVAL, "unknown scan engine %u", s->params.scan);
+  if (s->params.scan > EHX_SCAN_F16) return fail(EHX_EINVAL, "unknown scan engine %u", s->params.scan);
   {
     const char* env = getenv("EHX_SCAN");  // "f32": every space scans in fp32 (A/B runs, profiling)
     const bool env_f32 = env && strcmp(env, "f32") == 0;
+    const bool env_f16 = env && strcmp(env, "f16") == 0;  // "f16": no int8 scan copy (A/B runs)
     s->use16 = s->params.mode == EHX_MODE_FLAT && s->params.scan != EHX_SCAN_F32 && !env_f32;
     s->has16 = s->use16;
+    s->scan_sel = s->use16 ? s->params.scan : (uint32_t)EHX_SCAN_F32;
     s->ld16 = (uint32_t)round_up(dims, 128);
+    s->ld8 = (uint32_t)round_up(dims, 256);
+    // the int8 scan copy pays when its rows are clearly shorter than the fp16 copy's (both are padded to a whole
+    // number of LDS ring revolutions: 256 bytes here, 128 halves there)
+    s->has8 = s->has16 && s->params.scan == EHX_SCAN_AUTO && !env_f16 && (uint64_t)s->ld8 * 10 < (uint64_t)s->ld16 * 2 * 8;
+    if (const char* mr = getenv("EHX_I8_MIN_ROWS")) s->i8_min_rows = std::max<uint64_t>(4096, strtoull(mr, nullptr, 10));
     if (s->has16) {
       HIP_TRY(hipMalloc((void**)&s->dUnsafe, sizeof(unsigned long long)));
       HIP_TRY(hipMemset(s->dUnsafe, 0, sizeof(unsigned long long)));
+    }
+    if (s->has8) {
+      HIP_TRY(hipMalloc((void**)&s->dUnsafe8, sizeof(unsigned long long)));
+      HIP_TRY(hipMemset(s->dUnsafe8, 0, sizeof(unsigned long long)));
     }
   }
   HIP_TRY(hipMalloc((void**)&s->dMaxSumsq, sizeof(float)));
@@ -1394,13 +1641,22 @@ int ehx_space_set_ef(ehx_space* s, uint32_t ef) {
 }
 
 int ehx_space_set_scan(ehx_space* s, uint32_t scan) {
-  if (!valid_space(s) || scan > EHX_SCAN_F32) return fail(EHX_EINVAL, "bad argument");
+  if (!valid_space(s) || scan > EHX_SCAN_F16) return fail(EHX_EINVAL, "bad argument");
   std::unique_lock<std::shared_mutex> wl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
-  if (scan == EHX_SCAN_AUTO && !s->has16)
-    return fail(EHX_EUNSUPPORTED, "space '%s' was created without the fp16 scan copy", s->name.c_str());
+  if (scan != EHX_SCAN_F32 && !s->has16)
+    return fail(EHX_EUNSUPPORTED, "space '%s' was created without the filter scan copies", s->name.c_str());
   s->params.scan = scan;
-  s->use16 = scan == EHX_SCAN_AUTO;
+  s->scan_sel = scan;
+  s->use16 = scan != EHX_SCAN_F32;
+  return EHX_OK;
+}
+
+int ehx_space_scan_engine(ehx_space* s, uint32_t* engine) {
+  if (!valid_space(s) || !engine) return fail(EHX_EINVAL, "NULL argument");
+  std::shared_lock<std::shared_mutex> rl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+  *engine = (uint32_t)resolve_engine(s);
   return EHX_OK;
 }
 
@@ -1439,13 +1695,21 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
 static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n) {
   if (s->dXs && n)
     HIP_TRY(launch_make_search_copy(s->xf32(), s->dInv, row0, n, s->ld, s->metric, s->dXs, s->stream));
-  if (!s->has16 || n == 0) return EHX_OK;  // (kept current even while EHX_SCAN_F32 is selected)
-  HIP_TRY(launch_make_scan16(s->dX, s->x_half, row0, n, s->dims, s->ld, s->ld16, s->metric, s->dX16, s->dRowp16,
-                             s->dUnsafe, s->stream));
-  unsigned long long u = 0;
-  HIP_TRY(hipMemcpyAsync(&u, s->dUnsafe, sizeof(u), hipMemcpyDeviceToHost, s->stream));
+  if ((!s->has16 && !s->has8) || n == 0) return EHX_OK;  // (kept current whatever engine is selected right now)
+  unsigned long long u = 0, u8 = 0;
+  if (s->has16) {
+    HIP_TRY(launch_make_scan16(s->dX, s->x_half, row0, n, s->dims, s->ld, s->ld16, s->metric, s->dX16, s->dRowp16,
+                               s->dUnsafe, s->stream));
+    HIP_TRY(hipMemcpyAsync(&u, s->dUnsafe, sizeof(u), hipMemcpyDeviceToHost, s->stream));
+  }
+  if (s->has8) {
+    HIP_TRY(launch_make_scan8(s->dX, s->x_half, row0, n, s->dims, s->ld, s->ld8, s->metric, s->dX8, s->dRowp8,
+                              s->dTilep8, s->dUnsafe8, s->stream));
+    HIP_TRY(hipMemcpyAsync(&u8, s->dUnsafe8, sizeof(u8), hipMemcpyDeviceToHost, s->stream));
+  }
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->h_unsafe = u;
+  s->h_unsafe8 = u8;
   return EHX_OK;
 }
 
@@ -1997,6 +2261,8 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
   out->n_filter_fallback = s->n_filter_fallback;
   out->n_exhaustive = s->n_exhaustive;
   out->n_uncertified = s->n_uncertified_final;
+  out->n_i8_queries = s->n_i8_queries;
+  out->n_i8_fallback = s->n_i8_fallback;
   if (s->dGraphCounters) {
     unsigned long long g[3] = {0, 0, 0};
     HIP_TRY(hipMemcpy(g, s->dGraphCounters, sizeof(g), hipMemcpyDeviceToHost));
@@ -2058,6 +2324,8 @@ int ehx_stats_reset(ehx_space* s) {
   s->n_filter_fallback = 0;
   s->n_exhaustive = 0;
   s->n_uncertified_final = 0;
+  s->n_i8_queries = 0;
+  s->n_i8_fallback = 0;
   s->ring_count = 0;
   if (s->dUncert) HIP_TRY(hipMemset(s->dUncert, 0, 2 * sizeof(unsigned long long)));
   if (s->dGraphCounters) HIP_TRY(hipMemset(s->dGraphCounters, 0, kGraphCounters * sizeof(unsigned long long)));

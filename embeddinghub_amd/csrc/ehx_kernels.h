@@ -439,6 +439,85 @@ hipError_t launch_flat_scan16(const ScanArgs16& a, hipStream_t st);
 // bound of |<fp16(q^), fp16(x^)> accumulated in fp32 - <q^, x^>| for unit vectors of `dims` elements
 inline float scan16_eps(uint32_t dims) { return 1.0e-3f + 2.0e-7f * (float)dims; }
 
+// ---- int8-MFMA filter scan (k_flati8.hip) ----
+constexpr uint32_t kPoolCap = 4096;    // candidate keys one query can collect in one pass (overflow: query flagged)
+constexpr uint32_t kMerged8 = 256;     // width of the running best list of the int8 pipeline (k' <= 192)
+struct ScanArgsI8 {
+  const int8_t* Q;        // [q_tiles][ld/64 + 3][256][64] int8 query tiles, scan8 stage-blocked layout
+  const int8_t* X;        // scan copy, scan8_index layout; cap % 256 == 0
+  const float4* rowp;     // [cap + 512] (A, B, C, D) per row; padding rows (0, +inf, 0, 0)
+  const float4* tilep;    // [cap/256 + 2] (max|A|, max|C|, max|D|, min B) per 256-row tile
+  const float4* qparams;  // [q_tiles*256] (s_q, e_q, gamma_q, -)
+  const float* thr;       // [q_tiles*256] score threshold of this pass per query (-inf: padding query)
+  float* dump = nullptr;  // sample pass: every lower bound -> dump[row - tile0*256][q_tiles*256]
+  uint64_t* cand;         // [grid][512][64] staging slots
+  uint64_t* pool;         // [q_tiles*256][pool_cap] collected (score, id) keys of this pass, unsorted
+  uint32_t* pool_cnt;     // [q_tiles*256]
+  uint32_t* ovf;          // [q_tiles*256] 1 = the pool overflowed: the query must be answered by another engine
+  uint32_t pool_cap;
+  uint32_t n;
+  uint32_t ld;            // bytes (= k-values) per row of the scan copy, % 256 == 0
+  uint32_t tile0, n_tiles, q_tiles, n_chunks, tiles_per_chunk;
+  uint32_t xcd_map;
+  uint32_t* sync = nullptr;  // [n_chunks] lock-step counters, zero before the launch (nullptr: off)
+};
+// Stage-blocked layout of the int8 scan copy / query tiles: tiles of 256 rows, stages of 64 columns (bytes); one
+// (tile, stage) block is 256 rows x 64 B = 16 KiB in exactly the LDS image of the kernel (16-byte chunk c of row r
+// at physical chunk c ^ ((r>>2)&3)); blocks ordered [tile][stage].  Byte index of element (row, col):
+__host__ __device__ inline size_t scan8_index(uint64_t row, uint32_t col, uint32_t ld8) {
+  const uint64_t tile = row >> 8;
+  const uint32_t rr = (uint32_t)(row & 255u), kt = col >> 6, cc = col & 63u;
+  const uint32_t chunk = (cc >> 4) ^ ((rr >> 2) & 3u);
+  return ((size_t)(tile * (ld8 >> 6) + kt) * 256u + rr) * 64u + chunk * 16u + (cc & 15u);
+}
+// query tiles: the same blocks, [q_tile][stage], stages 0..2 stored once more after the last (DMA read-ahead)
+__host__ __device__ inline size_t scanq8_index(uint64_t row, uint32_t stage, uint32_t cc, uint32_t ld8) {
+  const uint64_t tile = row >> 8;
+  const uint32_t rr = (uint32_t)(row & 255u);
+  const uint32_t chunk = (cc >> 4) ^ ((rr >> 2) & 3u);
+  return ((size_t)(tile * ((ld8 >> 6) + 3u) + stage) * 256u + rr) * 64u + chunk * 16u + (cc & 15u);
+}
+inline size_t scanq8_bytes(uint32_t q_rows, uint32_t ld8) { return (size_t)(q_rows >> 8) * ((ld8 >> 6) + 3u) * 256u * 64u; }
+constexpr size_t kScan8TailPadBytes = 3u * 256u * 64u;  // X8 tail padding: three stage blocks (DMA read-ahead)
+size_t scan_i8_lds_bytes();
+hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st);
+// scan copy of rows [row0, row0+n): X8 = int8(x/|x| / s_r), rowp8 = (A, B, C, D); then the tile parameters of
+// every tile touching the range.  Rows the filter cannot bound are counted in *n_unsafe.
+hipError_t launch_make_scan8(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
+                             uint32_t ld8, int metric, int8_t* X8, float4* rowp8, float4* tilep8,
+                             unsigned long long* n_unsafe, hipStream_t st);
+// rowp8 for padding rows [row0, row0+n): (0, +inf, 0, 0); tilep8 for padding tiles [t0, t0+n): never alarm
+hipError_t launch_rowp8_pad(float4* rowp8, uint64_t row0, uint64_t n, hipStream_t st);
+hipError_t launch_tilep8_pad(float4* tilep8, uint64_t t0, uint64_t n, hipStream_t st);
+// int8 query tiles + (s_q, e_q, gamma_q) + (u, v) with D = u*S + v; thr[q] = +inf for q < nq, -inf for padding
+hipError_t launch_prep_queries8(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld8, uint32_t q_rows,
+                                int metric, int8_t* Q8, float4* qparams, float2* quv, float* thr, hipStream_t st);
+// sample pass -> first thresholds: thr[q] = the kprime-th smallest of scores[0..n_rows)[q] (+inf if fewer)
+hipError_t launch_sample_select256(const float* scores, uint32_t n_rows, uint32_t q_rows, uint32_t nq,
+                                   uint32_t kprime, float* thr, hipStream_t st);
+// merge one pass's pool into the query's running best kMerged8 keys (seed: keep what `merged` holds); publishes
+// thr[q] = score of the kprime-th best (+inf while fewer are known) and empties the pool (pool_cnt = 0)
+hipError_t launch_select256(const uint64_t* pool, uint32_t* pool_cnt, uint32_t pool_cap, uint32_t nq, uint32_t kprime,
+                            uint64_t* merged, bool seed, float* thr, hipStream_t st);
+struct Rerank256Args {
+  const float* Q;          // prepared (canonical) queries [*][ld]
+  const void* X;
+  uint32_t x_half;
+  const float* inv_norm;
+  const uint64_t* merged;  // [nq][kMerged8] keys (S_lower, id), ascending
+  const uint32_t* ovf;     // [nq] pool overflow flags
+  const float2* quv;       // [nq] D = u*S + v
+  const float* max_sumsq;
+  uint64_t* out_ids;
+  float* out_dist;
+  uint32_t* out_count;
+  unsigned long long* n_uncertified;
+  uint32_t* uncert_flags;
+  uint32_t nq, k, kprime, n, dims, ld;
+  int metric;
+};
+hipError_t launch_rerank256(const Rerank256Args& a, hipStream_t st);
+
 // sample pass -> starting thresholds: gthr[q] = key of the kprime-th smallest of scores[0..n_rows)[q] (id part
 // 0xFFFFFFFF, so a row that ties the threshold still passes); one wave per query
 hipError_t launch_sample_select(const float* scores, uint32_t n_rows, uint32_t q_rows, uint32_t nq, uint32_t kprime,

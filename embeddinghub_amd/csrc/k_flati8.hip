@@ -1,0 +1,484 @@
+// flat_scan_i8_kernel — the exhaustive scan as an INT8 matrix-core FILTER (v_mfma_i32_32x32x32_i8: twice the
+// fp16 matrix rate on half the bytes, EXACT int32 accumulation) in front of the canonical fp32 re-rank.  Like the
+// fp16 filter (k_flat16.hip) it only decides which rows become candidates, with a certified LOWER BOUND of every
+// row's score, so the answer stays the exact fp32 answer (rerank256_kernel certifies each query; what it cannot
+// certify falls to the fp16 filter, the fp32 scan and finally the exhaustive canonical pass).
+//
+// The scan copy (k_misc.hip: make_scan8): every row normalised to unit length (x^ = x / n_r) and quantised with
+// its own scale,  x^ = s_r * xi + dx,  xi int8,  s_r = max|x^| / 127,  e_r >= |dx|;  queries likewise
+// (s_q, qi, e_q).  The integer dot product I = <qi, xi> is exact, so with dot^ = <q^, x^>
+//     dot^  <=  U = s_q s_r I + e_q (1.0001 + e_r) + 1.0001 e_r          (Cauchy-Schwarz on the two residuals)
+// and every metric of the engine is affine in dot^ with a non-positive slope (table in k_flat16.hip):
+//     S(r,q) = b_r*gamma_q + a_r*dot^  >=  S_lower = B_r*gamma_q + D_r + C_r*e_q + A_r*(s_q*I)
+// with the row parameters (A, B, C, D) = (a_r s_r, b_r(1-1e-6), a_r(1.0001 + e_r), a_r(1.0001 e_r + slack)) computed
+// when the row is written (slack: the fp32 evaluation of this expression, the filter's own norms — make_scan8).
+//
+// Kernel shape: that of the fp16 filter, byte for byte — workgroup = 8 waves (two per SIMD), tile 256 rows x 256
+// queries, wave tile 128 x 64 = 4x2 MFMA blocks; a stage row is 64 bytes = 64 k-values (two k-steps of 32), X stage
+// 16 KiB + Q stage 16 KiB, ring of 4 stages filled three stages ahead by global->LDS DMA from the stage-blocked
+// scan copy; one counted s_waitcnt + one raw s_barrier per stage.  Half the stages of the fp16 scan per tile.
+//
+// Epilogue.  The lists of the fp16 kernel (sorted, compacted, thresholds tightened in flight) do not pay here: the
+// int8 bound (~1.5e-2 in dot units, vs 1.2e-3) needs k' = 128 candidates per query, so hits are ~4x as frequent
+// while a tile takes half the time.  Instead the threshold of a (query, pass) is FIXED — the k'-th best lower bound
+// of the rows scanned by the earlier passes (select256_kernel) — and a pass simply collects every (row, query) whose
+// lower bound is not above it:
+//   phase 1  per 32x32 block one integer max per lane (v_max3_i32 tree) against an integer alarm level derived from
+//            the tile's parameter extremes (tile_params8) — no row parameters, no float conversion;
+//   phase 2  (blocks with an alarm) a 16-bit mask per lane of the accumulators at or above the alarm level; each
+//            trip of a short loop takes one set bit per lane, evaluates S_lower with that row's parameters and
+//            appends (score, id, query) to the wave's own staging buffer in LDS (128 entries);
+//   a staging buffer that runs full is flushed to the queries' POOLS in HBM (one global atomicAdd per entry); what is
+//   left is flushed when the workgroup is done.  The hot path touches LDS only: a global store or atomic per hit would
+//   put foreign entries into the vmcnt queue the stage loop counts on (loads and stores may retire out of order with
+//   respect to each other), so the flush — rare — drains the queue instead.  A pool that overflows (adversarial row
+//   order: every row beats a stale threshold) only flags its query — the next engine of the chain answers it.
+// A cascade of passes x4 in rows keeps the hits at ~3 k' per query and pass.
+//
+// Lock-step (optional, ScanArgsI8::sync): the q_tiles workgroups that stream the same row chunk sit on one XCD and
+// share its L2, but nothing keeps them together, and once they drift apart by more than the L2 holds every one of
+// them fetches the rows from HBM again (the fp16 scan measured 3.1x the algorithmic traffic).  Each workgroup
+// announces every finished ring revolution on a per-chunk counter and does not run more than ~2 revolutions ahead
+// of its slowest sibling; the poll is an asynchronous 4-byte global->LDS load issued a revolution before its value
+// is looked at, so the steady state costs one atomic and one LDS read per revolution.  The wait is bounded (a
+// sibling that is not resident must not hang the launch): after the bound the workgroup stops synchronising.
+#include "ehx_kernels.h"
+#include "k_scan_common.h"
+
+namespace ehx {
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kThreadsI8 = 512;
+constexpr uint32_t kRingI8 = 4;
+constexpr uint32_t kRowBI8 = 64;                                   // bytes (= k-values) per stage row
+constexpr uint32_t kStageI8 = kTileRows16 * kRowBI8;               // 16 KiB (X and Q alike: 256 rows / queries)
+constexpr uint32_t kXOffI8 = 0;
+constexpr uint32_t kQOffI8 = kRingI8 * kStageI8;                   // 64 KiB
+constexpr uint32_t kStgCap = 128;                                  // staging entries per wave
+constexpr uint32_t kRowpOffI8 = 2 * kRingI8 * kStageI8;            // float4 rowp_lds[3][256]
+constexpr uint32_t kQpOffI8 = kRowpOffI8 + 3 * kTileRows16 * 16;   // float4 qp_lds[256] = (s_q, e_q, gamma_q, thr_q)
+constexpr uint32_t kSyncOffI8 = kQpOffI8 + kTileQ * 16;            // u32 snapshot[64] of the lock-step counter
+constexpr uint32_t kCtxOffI8 = kSyncOffI8 + 256;                   // I8Ctx: what the (rare) flush path needs
+constexpr uint32_t kStgKeyOffI8 = kCtxOffI8 + 64;                  // u64 stg_key[8][128]
+constexpr uint32_t kStgQlOffI8 = kStgKeyOffI8 + 8 * kStgCap * 8;   // u32 stg_ql[8][128]
+constexpr uint32_t kStgCntOffI8 = kStgQlOffI8 + 8 * kStgCap * 4;   // u32 stg_cnt[8]
+constexpr uint32_t kLdsBytesI8 = kStgCntOffI8 + 64;
+static_assert(kLdsBytesI8 <= 160 * 1024, "LDS budget");
+static_assert(kTileRows16 == 256 && kTileQ == 256, "kernel geometry is hard-wired");
+
+#define EHX_MFMA_I8(A, B, C) __builtin_amdgcn_mfma_i32_32x32x32_i8((A), (B), (C), 0, 0, 0)
+
+__device__ __forceinline__ void lds_barrier_i8() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // vmcnt 63, expcnt 7, lgkmcnt 0
+  __builtin_amdgcn_s_barrier();
+}
+
+// S_lower of one (row, query) from the row parameters P = (A, B, C, D), the query parameters
+// qq = (s_q, e_q, gamma_q, -) and the exact integer dot product v
+__device__ __forceinline__ float i8_score(const float4 P, const float4 qq, int v) {
+  const float t = qq.x * (float)v;
+  const float K = __builtin_fmaf(P.y, qq.z, __builtin_fmaf(P.z, qq.y, P.w));
+  return __builtin_fmaf(P.x, t, K);
+}
+
+// Integer alarm level of a tile for one query: a lane's accumulator I can only belong to a row with
+// S_lower <= thr if  I >= level.  tp = (max|A|, max|C|, max|D|, min B) over the tile's rows (tile_params8):
+//   S_lower(r) >= Bmin*gamma - Dmax - Cmax*e_q - Amax*s_q*max(I, 0)
+// The level errs towards alarms (relative slack, one integer unit); INT_MIN = always alarm, INT_MAX = never.
+__device__ __forceinline__ int i8_alarm_level(const float4 tp, const float4 qq) {
+  const float bg = tp.w * qq.z, ce = tp.y * qq.y;
+  float num = bg - tp.z - ce - qq.w;
+  num -= 1e-5f * (fabsf(bg) + tp.z + ce + fabsf(qq.w));
+  if (!(num > 0.0f)) return (int)0x80000000;                 // thr = +inf, NaN, or the bound is already below thr
+  const float den = tp.x * qq.x;
+  if (!(den > 0.0f)) return 0x7FFFFFFF;                      // no row of the tile depends on I: S_lower >= lo > thr
+  const float lev = num / den * (1.0f - 1e-5f) - 1.0f;
+  if (!(lev < 2.0e9f)) return 0x7FFFFFFF;
+  if (lev < -2.0e9f) return (int)0x80000000;
+  return (int)floorf(lev);
+}
+
+// What the flush path needs lives in LDS (written once per workgroup): the out-of-line flush takes no arguments.
+struct I8Ctx {
+  uint64_t* pool;        // [q_rows][pool_cap]
+  uint32_t* pool_cnt;    // [q_rows]
+  uint32_t* ovf;         // [q_rows]
+  uint32_t pool_cap;
+  uint32_t n;            // valid rows
+  uint32_t q_tile0;      // global index of this workgroup's query 0 (q_tile * 256)
+  uint32_t pad;
+};
+static_assert(sizeof(I8Ctx) <= 64, "I8Ctx slot");
+
+// Empty this wave's staging buffer into the pools of its queries (wave-uniform call).  Every entry takes one slot
+// of its query's pool with a global atomicAdd; the vmcnt queue is drained before returning, so the caller's counted
+// waits see DMA pieces only.
+__device__ __attribute__((noinline)) void i8_flush_staging() {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const I8Ctx* ctx = (const I8Ctx*)(smem + kCtxOffI8);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint64_t* keys = (const uint64_t*)(smem + kStgKeyOffI8) + (size_t)w * kStgCap;
+  const uint32_t* qls = (const uint32_t*)(smem + kStgQlOffI8) + (size_t)w * kStgCap;
+  uint32_t* cnt = (uint32_t*)(smem + kStgCntOffI8) + w;
+  uint32_t n = *cnt;
+  if (n > kStgCap) n = kStgCap;
+  const uint32_t cap = ctx->pool_cap;
+  for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
+    const uint64_t key = keys[i];
+    const uint32_t q = ctx->q_tile0 + (uint32_t)(w & 3) * 64u + qls[i];
+    const uint32_t pos = atomicAdd(&ctx->pool_cnt[q], 1u);
+    if (pos < cap) ctx->pool[(size_t)q * cap + pos] = key;
+    else ctx->ovf[q] = 1u;  // the pool is full: the query is answered by the next engine
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (lane == 0) *cnt = 0u;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// phase 2 of the epilogue for one accumulator value per lane: lanes with `hi` evaluate their row's exact lower
+// bound and stage it when it does not exceed the query's threshold (qq.w).  LDS traffic only (see the header).
+__device__ __forceinline__ void i8_hit(int v, bool hi, uint32_t r_local, uint32_t tile_row0, uint32_t rp_off,
+                                       const float4 qq, int ql, int w, uint32_t n_rows) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const float4 P = *(const float4*)(smem + rp_off + r_local * 16u);
+  const float S = i8_score(P, qq, v);
+  const uint32_t grow = tile_row0 + r_local;
+  bool ok = hi && (S <= qq.w) && grow < n_rows;
+  if (!__any(ok)) return;
+  const uint64_t key = ((uint64_t)f32_to_ordered(S) << 32) | grow;
+  uint64_t* keys = (uint64_t*)(smem + kStgKeyOffI8) + (size_t)w * kStgCap;
+  uint32_t* qls = (uint32_t*)(smem + kStgQlOffI8) + (size_t)w * kStgCap;
+  uint32_t* cnt = (uint32_t*)(smem + kStgCntOffI8) + w;
+  for (int round = 0; round < 8 && __any(ok); ++round) {  // (64 lanes, 128 entries: a flushed buffer takes them all)
+    bool full = false;
+    if (ok) {
+      const uint32_t pos = atomicAdd(cnt, 1u);
+      if (pos < kStgCap) {
+        keys[pos] = key;
+        qls[pos] = (uint32_t)ql;
+        ok = false;
+      } else {
+        full = true;
+      }
+    }
+    if (__any(full)) i8_flush_staging();
+  }
+}
+
+}  // namespace
+
+size_t scan_i8_lds_bytes() { return kLdsBytesI8; }
+
+// DUMP: the sample pass — every lower bound of the scanned tiles is written to a.dump[row - tile0*256][q] and
+// sample_select256_kernel turns them into the first thresholds.
+template <bool DUMP>
+__global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanArgsI8 a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const int h = lane >> 5, i31 = lane & 31;
+
+  uint32_t qt, chunk;
+  {
+    const uint32_t b = blockIdx.x;
+    if (a.xcd_map) {
+      const uint32_t xcd = b & 7u, slot = b >> 3;
+      qt = slot % a.q_tiles;
+      chunk = xcd * (a.n_chunks >> 3) + slot / a.q_tiles;
+    } else {
+      qt = b % a.q_tiles;
+      chunk = b / a.q_tiles;
+    }
+  }
+  float4* qp_lds = (float4*)(smem + kQpOffI8);
+  const volatile uint32_t* sync_lds = (const volatile uint32_t*)(smem + kSyncOffI8);
+
+  if (tid < (int)kTileQ) {  // query parameters and this pass's threshold, once per workgroup
+    const size_t qg = (size_t)qt * kTileQ + tid;
+    float4 qp = a.qparams[qg];
+    qp.w = a.thr ? a.thr[qg] : __builtin_inff();
+    qp_lds[tid] = qp;
+  }
+  if (tid < 64) ((uint32_t*)(smem + kSyncOffI8))[tid] = 0u;
+  if (tid < 8) ((uint32_t*)(smem + kStgCntOffI8))[tid] = 0u;
+  if (tid == 0) {
+    I8Ctx* ctx = (I8Ctx*)(smem + kCtxOffI8);
+    ctx->pool = a.pool;
+    ctx->pool_cnt = a.pool_cnt;
+    ctx->ovf = a.ovf;
+    ctx->pool_cap = a.pool_cap;
+    ctx->n = a.n;
+    ctx->q_tile0 = qt * kTileQ;
+    ctx->pad = 0u;
+  }
+
+  const uint32_t tile_begin = a.tile0 + chunk * a.tiles_per_chunk;
+  uint32_t tile_end = tile_begin + a.tiles_per_chunk;
+  if (tile_end > a.tile0 + a.n_tiles) tile_end = a.tile0 + a.n_tiles;
+  const uint32_t my_tiles = tile_end > tile_begin ? tile_end - tile_begin : 0u;
+  const uint32_t ktiles = a.ld / kRowBI8;  // stages per tile, a multiple of 4
+
+  // ---- DMA duty of this wave: 1-KiB pieces w and w+8 of the X stage block and of the Q stage block (linear
+  // copies: the blocks are stored in HBM in the LDS image, scan8_index); waves 0..3 also one piece each of the
+  // tile's row parameters (256 x 16 B), once per tile.  Sources are uniform pointers advanced one block per stage.
+  const uint32_t voff = (uint32_t)lane * 16u;
+  const uint32_t voff8 = voff + 8u * 1024u;
+  const size_t tile_bytes = (size_t)ktiles * kStageI8;
+  const char* xsrc = (const char*)a.X + (size_t)tile_begin * tile_bytes + (size_t)w * 1024;
+  const char* qbase = (const char*)a.Q + (size_t)qt * ((size_t)(ktiles + 3) * kStageI8) + (size_t)w * 1024;
+  const char* qsrc = qbase;
+  const char* rsrc = (const char*)(a.rowp + (size_t)tile_begin * kTileRows16) + (size_t)(w & 3) * 1024;
+  const uint32_t xdst = kXOffI8 + (uint32_t)w * 1024u;  // + slot*16384 (+8192 for the second piece)
+  const uint32_t qdst = kQOffI8 + (uint32_t)w * 1024u;
+  const uint32_t rdst = kRowpOffI8 + (uint32_t)(w & 3) * 1024u;  // + (tile % 3)*4096
+
+#define EHX_DMA(DST_BASE, DST_IMM, VOFF, SRC)                                                              \
+  do {                                                                                                     \
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"                       \
+                 :                                                                                         \
+                 : "s"(DST_BASE), "n"(DST_IMM), "v"(VOFF), "s"(SRC)                                        \
+                 : "memory", "scc");                                                                       \
+  } while (0)
+#define EHX_DMA_X0(SLOT) EHX_DMA(xdst, (SLOT) * 16384, voff, xsrc)
+#define EHX_DMA_Q0(SLOT) EHX_DMA(qdst, (SLOT) * 16384, voff, qsrc)
+#define EHX_DMA_X1(SLOT) EHX_DMA(xdst, (SLOT) * 16384 + 8192, voff8, xsrc)
+#define EHX_DMA_Q1(SLOT)                               \
+  do {                                                 \
+    EHX_DMA(qdst, (SLOT) * 16384 + 8192, voff8, qsrc); \
+    xsrc += kStageI8;                                  \
+    qsrc += kStageI8;                                  \
+  } while (0)
+
+  // ---- fragment read offsets: k-step j (0/1) of a stage row is its logical 16-byte chunks 2j (lanes 0-31) and
+  // 2j+1 (lanes 32-63); any fixed permutation of k is fine as long as rows and queries use the same one
+  const uint32_t sw = ((uint32_t)i31 >> 2) & 3u;
+  const uint32_t a_off0 = kXOffI8 + (uint32_t)(wr * 128 + i31) * kRowBI8 + (((uint32_t)h) ^ sw) * 16u;       // + rb*2048
+  const uint32_t a_off1 = kXOffI8 + (uint32_t)(wr * 128 + i31) * kRowBI8 + ((2u + (uint32_t)h) ^ sw) * 16u;
+  const uint32_t b_off0 = kQOffI8 + (uint32_t)(wc * 64 + i31) * kRowBI8 + (((uint32_t)h) ^ sw) * 16u;        // + cb*2048
+  const uint32_t b_off1 = kQOffI8 + (uint32_t)(wc * 64 + i31) * kRowBI8 + ((2u + (uint32_t)h) ^ sw) * 16u;
+
+  i32x16 acc[4][2];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0;
+
+  uint32_t rp_slot = 0u;  // LDS slot (tile % 3) of the current tile's row parameters
+  // =============================== tile epilogue ===============================
+  auto epilogue = [&](uint32_t t) {
+    const uint32_t tile = tile_begin + t;
+    const uint32_t tile_row0 = tile * kTileRows16;
+    const uint32_t rp_off = kRowpOffI8 + rp_slot * 4096u;  // this tile's row parameters in LDS
+    const float4* rp = (const float4*)(smem + rp_off);
+    const int col = wc * 64 + i31;
+    const float4 qq0 = qp_lds[col], qq1 = qp_lds[col + 32];
+    if (DUMP) {
+      const size_t qcol = (size_t)qt * kTileQ + col;
+      const size_t q_rows = (size_t)a.q_tiles * kTileQ;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const uint32_t r = (uint32_t)(wr * 128 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
+          const float4 P = rp[r];
+          float* o = a.dump + (size_t)(tile_row0 - a.tile0 * kTileRows16 + r) * q_rows + qcol;
+          o[0] = i8_score(P, qq0, acc[rb][0][reg]);
+          o[32] = i8_score(P, qq1, acc[rb][1][reg]);
+        }
+      }
+      return;
+    }
+    const float4 tp = a.tilep[tile];  // uniform: (max|A|, max|C|, max|D|, min B) of the tile's rows
+    const int lev0 = i8_alarm_level(tp, qq0), lev1 = i8_alarm_level(tp, qq1);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        // ---- phase 1: the block's integer maximum per lane against the alarm level ----
+        const i32x16 c = acc[rb][cb];
+        const int m0 = max(max(c[0], c[1]), c[2]), m1 = max(max(c[3], c[4]), c[5]);
+        const int m2 = max(max(c[6], c[7]), c[8]), m3 = max(max(c[9], c[10]), c[11]);
+        const int m4 = max(max(c[12], c[13]), c[14]);
+        const int m = max(max(max(m0, m1), m2), max(max(m3, m4), c[15]));
+        const int lev = cb ? lev1 : lev0;
+        if (!__any(m >= lev)) continue;
+        // ---- phase 2: the accumulators at or above the alarm level, one per lane and trip ----
+        const float4 qq = cb ? qq1 : qq0;
+        const int ql = cb * 32 + i31;
+        const uint32_t rbase = (uint32_t)(wr * 128 + rb * 32) + 4u * h;
+        uint32_t pend = 0u;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) pend |= (c[reg] >= lev) ? (1u << reg) : 0u;
+        while (__any(pend != 0u)) {
+          const bool hi = pend != 0u;
+          int v = 0;
+          uint32_t r_local = rbase;
+          if (hi) {
+            const int b = __builtin_ctz(pend);
+            pend &= pend - 1u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v = (b == i) ? c[i] : v;
+            r_local = rbase + (uint32_t)((b & 3) + 8 * (b >> 2));
+          }
+          i8_hit(v, hi, r_local, tile_row0, rp_off, qq, ql, w, a.n);
+        }
+      }
+    }
+  };
+
+  // ---- lock-step with the sibling workgroups of this chunk (see the header) ----
+  uint32_t* const sync_ctr = (a.sync && a.xcd_map && a.q_tiles > 1) ? a.sync + chunk : nullptr;
+  bool sync_on = sync_ctr != nullptr && !DUMP;
+  uint32_t sync_m0 = kSyncOffI8;
+  uint32_t sync_voff = 0u;
+
+  __syncthreads();  // state init visible
+  if (my_tiles > 0) {  // (a chunk past the end of the pass has nothing to scan and must not touch memory)
+  // ---- prologue: row parameters of tile 0, stages 0..2 into ring slots 0..2 ----
+  if (w < 4) EHX_DMA(rdst, 0, voff, rsrc);
+  EHX_DMA_X0(0); EHX_DMA_Q0(0); EHX_DMA_X1(0); EHX_DMA_Q1(0);
+  EHX_DMA_X0(1); EHX_DMA_Q0(1); EHX_DMA_X1(1); EHX_DMA_Q1(1);
+  EHX_DMA_X0(2); EHX_DMA_Q0(2); EHX_DMA_X1(2); EHX_DMA_Q1(2);
+  wait_vmcnt<8>();  // stage 0 (and the row parameters, older) landed <=> at most stages 1, 2 in flight
+  lds_barrier_i8();  // B_0
+
+  // Fragments are double-buffered: set 0 feeds k-step 0, set 1 feeds k-step 1; the six fragment reads of
+  // the next k-step are issued ahead of the current k-step's 8 MFMAs and land in their shadow.
+  i32x4 fa0[4], fb0[2], fa1[4], fb1[2];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) fa0[rb] = *(const i32x4*)(smem + a_off0 + rb * 2048);
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) fb0[cb] = *(const i32x4*)(smem + b_off0 + cb * 2048);
+
+#define EHX_FR(P) (*(const i32x4*)(P))
+#define EHX_MF(A, B, RB, CB) acc[RB][CB] = EHX_MFMA_I8(A[RB], B[CB], acc[RB][CB])
+#define EHX_SB() __builtin_amdgcn_sched_barrier(0)
+  // One stage, ring slot S (compile-time): no branches, no address arithmetic; every gap between two MFMAs carries
+  // exactly one other instruction of this wave (a fragment read or a DMA piece).
+#define EHX_STAGE_I8(S)                                                                                  \
+  do {                                                                                                   \
+    constexpr uint32_t so = (uint32_t)(S) * kStageI8, sn = (uint32_t)(((S) + 1) & 3) * kStageI8;         \
+    constexpr int sd = ((S) + 3) & 3;                                                                    \
+    EHX_MF(fa0, fb0, 0, 0); fb1[0] = EHX_FR(smem + b_off1 + so);            EHX_SB();                    \
+    EHX_MF(fa0, fb0, 0, 1); fb1[1] = EHX_FR(smem + b_off1 + so + 2048);     EHX_SB();                    \
+    EHX_MF(fa0, fb0, 1, 0); fa1[0] = EHX_FR(smem + a_off1 + so);            EHX_SB();                    \
+    EHX_MF(fa0, fb0, 1, 1); fa1[1] = EHX_FR(smem + a_off1 + so + 2048);     EHX_SB();                    \
+    EHX_MF(fa0, fb0, 2, 0); fa1[2] = EHX_FR(smem + a_off1 + so + 4096);     EHX_SB();                    \
+    EHX_MF(fa0, fb0, 2, 1); fa1[3] = EHX_FR(smem + a_off1 + so + 6144);     EHX_SB();                    \
+    EHX_MF(fa0, fb0, 3, 0); EHX_DMA_X0(sd);                                 EHX_SB();                    \
+    EHX_MF(fa0, fb0, 3, 1); EHX_DMA_Q0(sd);                                 EHX_SB();                    \
+    /* stage barrier: the next stage landed (own pieces counted: the younger stage and the two pieces    \
+       just issued may still be in flight) and is visible; every wave is done reading this stage */      \
+    wait_vmcnt<6>();                                                                                     \
+    lds_barrier_i8();                                                                                    \
+    EHX_SB();                                                                                            \
+    EHX_MF(fa1, fb1, 0, 0); fb0[0] = EHX_FR(smem + b_off0 + sn);            EHX_SB();                    \
+    EHX_MF(fa1, fb1, 0, 1); fb0[1] = EHX_FR(smem + b_off0 + sn + 2048);     EHX_SB();                    \
+    EHX_MF(fa1, fb1, 1, 0); fa0[0] = EHX_FR(smem + a_off0 + sn);            EHX_SB();                    \
+    EHX_MF(fa1, fb1, 1, 1); fa0[1] = EHX_FR(smem + a_off0 + sn + 2048);     EHX_SB();                    \
+    EHX_MF(fa1, fb1, 2, 0); fa0[2] = EHX_FR(smem + a_off0 + sn + 4096);     EHX_SB();                    \
+    EHX_MF(fa1, fb1, 2, 1); fa0[3] = EHX_FR(smem + a_off0 + sn + 6144);     EHX_SB();                    \
+    EHX_MF(fa1, fb1, 3, 0); EHX_DMA_X1(sd);                                 EHX_SB();                    \
+    EHX_MF(fa1, fb1, 3, 1); EHX_DMA_Q1(sd);                                 EHX_SB();                    \
+  } while (0)
+
+  // One flat loop over groups of four stages (= one revolution of the ring; ld % 256 == 0 makes a tile a whole
+  // number of them); the tile boundary work hangs off a counter inside it.
+  const uint32_t kquads = ktiles >> 2;
+  const uint32_t total_quads = my_tiles * kquads;
+  // row parameters of tile 1 (consumed by its epilogue, a whole tile from now)
+  rsrc += kTileRows16 * 16;
+  if (w < 4) EHX_DMA(rdst, 4096, voff, rsrc);
+  uint32_t kq = 0, t = 0;
+  for (uint32_t q = 0; q < total_quads; ++q) {
+    EHX_STAGE_I8(0);
+    EHX_STAGE_I8(1);
+    EHX_STAGE_I8(2);
+    EHX_STAGE_I8(3);
+    if (sync_on && w == 0) {
+      // revolution q is done.  The snapshot taken after revolution q-1 (landed long ago: four stage waits have
+      // passed) must show every sibling through revolution q-2; then announce q and take the next snapshot.
+      const uint32_t seen = __builtin_amdgcn_readfirstlane(sync_lds[0]);
+      const uint32_t need = q >= 2 ? a.q_tiles * (q - 1) : 0u;
+      if (seen < need) {
+        uint32_t spins = 0;
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <
+               need) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > 4000u) {  // a sibling is not resident (or died): never hang, just stop synchronising
+            sync_on = false;
+            break;
+          }
+        }
+      }
+      if (lane == 0) __hip_atomic_fetch_add(sync_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1"
+                   :
+                   : "s"(sync_m0), "v"(sync_voff), "s"(sync_ctr)
+                   : "memory");
+    }
+    if (++kq == kquads) {
+      kq = 0;
+      epilogue(t);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0;
+      ++t;
+      // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
+      // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
+      qsrc = qbase + 3 * kStageI8;
+      rsrc += kTileRows16 * 16;
+      // tile t+1 (counting the new t) goes to the slot tile t-2 used: every wave left that epilogue long ago
+      const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 1) % 3 == (t - 2) % 3
+      rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
+      if (w < 4) {
+        const uint32_t rd = rdst + rp_next * 4096u;
+        EHX_DMA(rd, 0, voff, rsrc);
+      }
+    }
+  }
+  }  // my_tiles > 0
+#undef EHX_STAGE_I8
+#undef EHX_MF
+#undef EHX_SB
+#undef EHX_FR
+#undef EHX_DMA_X0
+#undef EHX_DMA_Q0
+#undef EHX_DMA_X1
+#undef EHX_DMA_Q1
+#undef EHX_DMA
+
+  // ---- final: what is left in this wave's staging buffer goes to the pools ----
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (DUMP) return;
+  i8_flush_staging();
+}
+
+hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* fns[2] = {(const void*)flat_scan_i8_kernel<false>, (const void*)flat_scan_i8_kernel<true>};
+    for (const void* f : fns) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesI8);
+      if (e != hipSuccess) return e;
+    }
+    attr_set = true;
+  }
+  const uint32_t grid = a.q_tiles * a.n_chunks;
+  if (a.dump) hipLaunchKernelGGL((flat_scan_i8_kernel<true>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
+  else hipLaunchKernelGGL((flat_scan_i8_kernel<false>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace ehx

@@ -236,6 +236,202 @@ hipError_t launch_prep_queries16(const float* q_in, uint32_t nq, uint32_t dims, 
   return hipGetLastError();
 }
 
+// ---- int8-MFMA filter scan: scan copy, tile parameters, query preparation (k_flati8.hip) -------------------
+// One wave per row.  x^ = x * (1/|x|) in fp32 (the filter's own parallel-sum norm), s = max|x^| / 127,
+// xi = clamp(rint(x^ / s), -127, 127), e >= |x^ - s xi| (fp32, rounded up by a relative and an absolute margin).
+// Row parameters (A, B, C, D) of the lower bound  S_lower = B*gamma_q + D + C*e_q + A*(s_q*I)  (k_flati8.hip):
+//     A = a_r s      B = b_r (1 - 1e-6)      C = a_r (1.0001 + e)      D = a_r (1.0001 e + slack)
+// with (a_r, b_r) = cosine (-1, 1), IP (-n_r, 1), L2^2 (-n_r, n_r^2 rounded down), and
+//     slack = 4e-6 (fp32 evaluation of S_lower and of x * inv) + 1.5e-7 * d (2.5 d u: the gap between this
+//     kernel's norms and the canonical sequential-sum norms the re-rank's cosine distances use).
+namespace {
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float i8_slack(uint32_t dims) { return 4e-6f + 1.5e-7f * (float)dims; }
+__device__ __forceinline__ float i8_err_up(float e2) { return __builtin_sqrtf(e2) * (1.0f + 1e-4f) + 3e-7f; }
+}  // namespace
+
+template <typename XT>
+__global__ __launch_bounds__(256) void make_scan8_kernel(const XT* __restrict__ X, uint64_t row0, uint64_t n,
+                                                         uint32_t dims, uint32_t ld, uint32_t ld8, int metric,
+                                                         int8_t* __restrict__ X8, float4* __restrict__ rowp8,
+                                                         unsigned long long* __restrict__ n_unsafe) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const uint64_t r = row0 + i;
+  const XT* x = X + r * ld;
+  float ss = 0.0f;
+  for (uint32_t c = lane; c < dims; c += 64) ss += ld_row(x, c) * ld_row(x, c);
+  ss = wave_sum(ss);
+  const bool ok = norm_ok(ss);
+  const float nr = ok ? __builtin_sqrtf(ss) : 0.0f;
+  const float inv = nr > 0.0f ? 1.0f / nr : 0.0f;
+  float amax = 0.0f;
+  for (uint32_t c = lane; c < dims; c += 64) amax = fmaxf(amax, fabsf(ld_row(x, c) * inv));
+  amax = wave_max(amax);
+  const float s = amax / 127.0f;
+  const float rs = amax > 0.0f ? 127.0f / amax : 0.0f;
+  float e2 = 0.0f;
+  for (uint32_t c = lane; c < ld8; c += 64) {
+    const float v = c < dims ? ld_row(x, c) * inv : 0.0f;
+    float qf = rintf(v * rs);
+    qf = fminf(fmaxf(qf, -127.0f), 127.0f);
+    X8[scan8_index(r, c, ld8)] = (int8_t)(int)qf;
+    const float res = v - s * qf;
+    e2 += res * res;
+  }
+  e2 = wave_sum(e2);
+  if (lane == 0) {
+    float4 p;
+    if (!ok) {
+      p = make_float4(0.0f, __builtin_inff(), 0.0f, 0.0f);
+      atomicAdd(n_unsafe, 1ull);
+    } else {
+      const float e = i8_err_up(e2);
+      float a_r = -1.0f, b_r = 1.0f;
+      if (metric == 1) {
+        a_r = -nr;
+      } else if (metric == 0) {
+        a_r = -nr;
+        b_r = ss * (1.0f - 1e-6f - 7e-8f * ((float)(dims >> 6) + 8.0f));  // the parallel sum, rounded down
+      }
+      p = make_float4(a_r * s, b_r * (1.0f - 1e-6f), a_r * (1.0001f + e), a_r * (1.0001f * e + i8_slack(dims)));
+    }
+    rowp8[r] = p;
+  }
+}
+
+// (max|A|, max|C|, max|D|, min B) over the 256 rows of each tile: one wave per tile, 4 rows per lane
+__global__ __launch_bounds__(64) void tile_params8_kernel(const float4* __restrict__ rowp8, uint64_t tile0,
+                                                          float4* __restrict__ tilep8) {
+  const int lane = threadIdx.x;
+  const uint64_t tile = tile0 + blockIdx.x;
+  float am = 0.0f, cm = 0.0f, dm = 0.0f, bm = __builtin_inff();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 p = rowp8[tile * 256 + (uint64_t)j * 64 + lane];
+    am = fmaxf(am, fabsf(p.x));
+    cm = fmaxf(cm, fabsf(p.z));
+    dm = fmaxf(dm, fabsf(p.w));
+    bm = fminf(bm, p.y);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    am = fmaxf(am, __shfl_xor(am, o, 64));
+    cm = fmaxf(cm, __shfl_xor(cm, o, 64));
+    dm = fmaxf(dm, __shfl_xor(dm, o, 64));
+    bm = fminf(bm, __shfl_xor(bm, o, 64));
+  }
+  if (lane == 0) tilep8[tile] = make_float4(am, cm, dm, bm);
+}
+
+hipError_t launch_make_scan8(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
+                             uint32_t ld8, int metric, int8_t* X8, float4* rowp8, float4* tilep8,
+                             unsigned long long* n_unsafe, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const dim3 grid((uint32_t)((n + 3) / 4));
+  if (x_half)
+    hipLaunchKernelGGL(make_scan8_kernel<__half>, grid, dim3(256), 0, st, (const __half*)X, row0, n, dims, ld, ld8,
+                       metric, X8, rowp8, n_unsafe);
+  else
+    hipLaunchKernelGGL(make_scan8_kernel<float>, grid, dim3(256), 0, st, (const float*)X, row0, n, dims, ld, ld8,
+                       metric, X8, rowp8, n_unsafe);
+  const uint64_t t0 = row0 >> 8, t1 = (row0 + n + 255) >> 8;
+  hipLaunchKernelGGL(tile_params8_kernel, dim3((uint32_t)(t1 - t0)), dim3(64), 0, st, rowp8, t0, tilep8);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void rowp8_pad_kernel(float4* __restrict__ rowp8, uint64_t row0, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rowp8[row0 + i] = make_float4(0.0f, __builtin_inff(), 0.0f, 0.0f);
+}
+__global__ __launch_bounds__(256) void tilep8_pad_kernel(float4* __restrict__ tilep8, uint64_t t0, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tilep8[t0 + i] = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());
+}
+hipError_t launch_rowp8_pad(float4* rowp8, uint64_t row0, uint64_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(rowp8_pad_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, rowp8, row0, n);
+  return hipGetLastError();
+}
+hipError_t launch_tilep8_pad(float4* tilep8, uint64_t t0, uint64_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(tilep8_pad_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, tilep8, t0, n);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void prep_queries8_kernel(const float* __restrict__ q_in, uint32_t nq, uint32_t dims,
+                                                           uint32_t ld8, int metric, int8_t* __restrict__ Q8,
+                                                           float4* __restrict__ qparams, float2* __restrict__ quv,
+                                                           float* __restrict__ thr) {
+  const uint32_t row = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint32_t kts = ld8 >> 6;
+  auto put = [&](uint32_t c, int8_t v) {  // stages 0..2 are stored a second time after the last stage
+    Q8[scanq8_index(row, c >> 6, c & 63u, ld8)] = v;
+    if (c < 192) Q8[scanq8_index(row, kts + (c >> 6), c & 63u, ld8)] = v;
+  };
+  if (row >= nq) {
+    for (uint32_t c = lane; c < ld8; c += 64) put(c, 0);
+    if (lane == 0) {
+      qparams[row] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+      quv[row] = make_float2(1.0f, 0.0f);
+      thr[row] = -__builtin_inff();  // a padding query never collects anything
+    }
+    return;
+  }
+  const float* in = q_in + (size_t)row * dims;
+  float ss = 0.0f;
+  for (uint32_t c = lane; c < dims; c += 64) ss += in[c] * in[c];
+  ss = wave_sum(ss);
+  const bool ok = norm_ok(ss);
+  const float beta = ok ? __builtin_sqrtf(ss) : 0.0f;
+  const float inv = beta > 0.0f ? 1.0f / beta : 0.0f;
+  float amax = 0.0f;
+  for (uint32_t c = lane; c < dims; c += 64) amax = fmaxf(amax, fabsf(in[c] * inv));
+  amax = wave_max(amax);
+  const float s = amax / 127.0f;
+  const float rs = amax > 0.0f ? 127.0f / amax : 0.0f;
+  float e2 = 0.0f;
+  for (uint32_t c = lane; c < ld8; c += 64) {
+    const float v = c < dims ? in[c] * inv : 0.0f;
+    float qf = rintf(v * rs);
+    qf = fminf(fmaxf(qf, -127.0f), 127.0f);
+    put(c, (int8_t)(int)qf);
+    const float res = v - s * qf;
+    e2 += res * res;
+  }
+  e2 = wave_sum(e2);
+  if (lane == 0) {
+    float g = 1.0f, u = 1.0f, v = 0.0f;
+    if (beta > 0.0f) {
+      if (metric == 1) {
+        g = 1.0f / beta;
+        u = beta;
+      } else if (metric == 0) {
+        g = 0.5f / beta;
+        u = 2.0f * beta;
+        v = ss * (1.0f - 1e-6f - 7e-8f * ((float)(dims >> 6) + 8.0f));  // |q|^2 rounded down
+      }
+    }
+    if (!ok) u = __builtin_nanf("");
+    qparams[row] = make_float4(s, i8_err_up(e2), g, 0.0f);
+    quv[row] = make_float2(u, v);
+    thr[row] = __builtin_inff();
+  }
+}
+
+hipError_t launch_prep_queries8(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld8, uint32_t q_rows,
+                                int metric, int8_t* Q8, float4* qparams, float2* quv, float* thr, hipStream_t st) {
+  hipLaunchKernelGGL(prep_queries8_kernel, dim3(q_rows), dim3(64), 0, st, q_in, nq, dims, ld8, metric, Q8, qparams,
+                     quv, thr);
+  return hipGetLastError();
+}
+
 // ---- fp16 storage ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void store_rows_f16_kernel(const float* __restrict__ src, uint32_t src_ld,
                                                              const uint64_t* __restrict__ ids, uint64_t row0,

@@ -1,0 +1,252 @@
+// Candidate bookkeeping of the int8 filter pipeline (k_flati8.hip), 256 keys wide: one wave holds a sorted run of
+// 256 (score, id) keys as 4 registers per lane (element e = r*64 + lane).
+//   sample_select256_kernel  first thresholds from the sample pass's dumped lower bounds
+//   select256_kernel         a pass's pool (unsorted) merged into the query's running best 256; publishes the
+//                            k'-th best score as the next pass's threshold
+//   rerank256_kernel         canonical (oracle-order) fp32 distances of the k' best lower bounds, top-k, certificate
+#include "ehx_kernels.h"
+
+namespace ehx {
+
+namespace {
+
+constexpr int kR = 4;  // registers per lane: 4 x 64 = 256 keys
+
+__device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a < b ? b : a; }
+
+// one compare-exchange layer of a bitonic network over the 256 keys: partner distance j, ascending where
+// (e & size) == 0 (size 512 = everywhere ascending)
+template <int SIZE, int J>
+__device__ __forceinline__ void cx_layer(uint64_t (&k)[kR], int lane) {
+  if (J >= 64) {
+    constexpr int jr = J >> 6;
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      if ((r & jr) == 0) {
+        const int p = r | jr;
+        const bool up = (((r << 6) | lane) & SIZE) == 0;
+        const uint64_t lo = umin64(k[r], k[p]), hi = umax64(k[r], k[p]);
+        k[r] = up ? lo : hi;
+        k[p] = up ? hi : lo;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      const uint64_t other = __shfl_xor(k[r], J, 64);
+      const bool up = (((r << 6) | lane) & SIZE) == 0;
+      const bool lower = (lane & J) == 0;
+      const uint64_t lo = umin64(k[r], other), hi = umax64(k[r], other);
+      k[r] = (lower == up) ? lo : hi;
+    }
+  }
+}
+
+template <int SIZE>
+__device__ __forceinline__ void cx_merge(uint64_t (&k)[kR], int lane) {  // layers j = SIZE/2 .. 1
+  if (SIZE >= 256) cx_layer<SIZE, 128>(k, lane);
+  if (SIZE >= 128) cx_layer<SIZE, 64>(k, lane);
+  if (SIZE >= 64) cx_layer<SIZE, 32>(k, lane);
+  if (SIZE >= 32) cx_layer<SIZE, 16>(k, lane);
+  if (SIZE >= 16) cx_layer<SIZE, 8>(k, lane);
+  if (SIZE >= 8) cx_layer<SIZE, 4>(k, lane);
+  if (SIZE >= 4) cx_layer<SIZE, 2>(k, lane);
+  cx_layer<SIZE, 1>(k, lane);
+}
+
+// ascending bitonic sort of the 256 keys
+__device__ __forceinline__ void wave_sort256(uint64_t (&k)[kR], int lane) {
+  cx_merge<2>(k, lane);
+  cx_merge<4>(k, lane);
+  cx_merge<8>(k, lane);
+  cx_merge<16>(k, lane);
+  cx_merge<32>(k, lane);
+  cx_merge<64>(k, lane);
+  cx_merge<128>(k, lane);
+  // last phase: everything ascending.  (e & 256) == 0 for every e < 256, so SIZE = 256 is "ascending everywhere".
+  cx_merge<256>(k, lane);
+}
+
+// best (ascending) <- the 256 smallest of best U v, v ascending: reverse v, elementwise min (a bitonic
+// sequence holding the 256 smallest), bitonic merge
+__device__ __forceinline__ void wave_merge256(uint64_t (&best)[kR], const uint64_t (&v)[kR], int lane) {
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    const uint64_t rv = __shfl(v[kR - 1 - r], 63 - lane, 64);  // element 255 - e
+    best[r] = umin64(best[r], rv);
+  }
+  cx_merge<256>(best, lane);
+}
+
+// element `idx` (0..255) of a key run, broadcast to the wave
+__device__ __forceinline__ uint64_t wave_pick256(const uint64_t (&k)[kR], uint32_t idx) {
+  const uint32_t r = idx >> 6;
+  uint64_t v = k[0];
+  if (r == 1) v = k[1];
+  if (r == 2) v = k[2];
+  if (r == 3) v = k[3];
+  return __shfl(v, (int)(idx & 63u), 64);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// first thresholds: thr[q] = the kprime-th smallest lower bound among the sample rows (a subset of the rows, hence
+// an upper bound of the query's final kprime-th best); +inf when the sample holds fewer valid scores
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sample_select256_kernel(const float* __restrict__ scores, uint32_t n_rows,
+                                                              uint32_t q_rows, uint32_t kprime,
+                                                              float* __restrict__ thr) {
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  uint64_t best[kR] = {kKeyInf, kKeyInf, kKeyInf, kKeyInf};
+  for (uint32_t r0 = 0; r0 < n_rows; r0 += 256) {
+    uint64_t v[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      const uint32_t row = r0 + (uint32_t)r * 64u + (uint32_t)lane;
+      uint64_t key = kKeyInf;
+      if (row < n_rows) {
+        const float sc = scores[(size_t)row * q_rows + q];
+        if (sc == sc && sc < __builtin_inff()) key = ((uint64_t)f32_to_ordered(sc) << 32) | 0xFFFFFFFFull;
+      }
+      v[r] = key;
+    }
+    wave_sort256(v, lane);
+    wave_merge256(best, v, lane);
+  }
+  const uint64_t kth = wave_pick256(best, kprime - 1);
+  if (lane == 0) thr[q] = kth == kKeyInf ? __builtin_inff() : ordered_to_f32((uint32_t)(kth >> 32));
+}
+
+hipError_t launch_sample_select256(const float* scores, uint32_t n_rows, uint32_t q_rows, uint32_t nq,
+                                   uint32_t kprime, float* thr, hipStream_t st) {
+  hipLaunchKernelGGL(sample_select256_kernel, dim3(nq), dim3(64), 0, st, scores, n_rows, q_rows, kprime, thr);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// one pass's pool -> running best 256 of the query.  Every key the scan collected is <= the pass's threshold;
+// everything it did not collect is above it, so the kprime-th best after the merge is again an upper bound of the
+// final kprime-th best and serves as the next pass's threshold.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void select256_kernel(const uint64_t* __restrict__ pool, uint32_t* __restrict__ pool_cnt,
+                                                       uint32_t pool_cap, uint32_t kprime, uint64_t* __restrict__ merged,
+                                                       uint32_t seed, float* __restrict__ thr) {
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  uint64_t best[kR];
+#pragma unroll
+  for (int r = 0; r < kR; ++r) best[r] = seed ? merged[(size_t)q * kMerged8 + r * 64 + lane] : kKeyInf;
+  uint32_t n = pool_cnt[q];
+  if (n > pool_cap) n = pool_cap;  // (overflowed pool: the query is flagged; keep what fits)
+  const uint64_t* p = pool + (size_t)q * pool_cap;
+  for (uint32_t b0 = 0; b0 < n; b0 += 256) {
+    uint64_t v[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      const uint32_t i = b0 + (uint32_t)r * 64u + (uint32_t)lane;
+      v[r] = i < n ? p[i] : kKeyInf;
+    }
+    // a chunk in which nothing beats the 256th best so far cannot change anything
+    const uint64_t bar = wave_pick256(best, 255);
+    const uint64_t vmin = umin64(umin64(v[0], v[1]), umin64(v[2], v[3]));
+    if (!__any(vmin < bar)) continue;
+    wave_sort256(v, lane);
+    wave_merge256(best, v, lane);
+  }
+#pragma unroll
+  for (int r = 0; r < kR; ++r) merged[(size_t)q * kMerged8 + r * 64 + lane] = best[r];
+  const uint64_t kth = wave_pick256(best, kprime - 1);
+  if (lane == 0) {
+    thr[q] = kth == kKeyInf ? __builtin_inff() : ordered_to_f32((uint32_t)(kth >> 32));
+    pool_cnt[q] = 0u;
+  }
+}
+
+hipError_t launch_select256(const uint64_t* pool, uint32_t* pool_cnt, uint32_t pool_cap, uint32_t nq, uint32_t kprime,
+                            uint64_t* merged, bool seed, float* thr, hipStream_t st) {
+  hipLaunchKernelGGL(select256_kernel, dim3(nq), dim3(64), 0, st, pool, pool_cnt, pool_cap, kprime, merged,
+                     seed ? 1u : 0u, thr);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// canonical re-rank of the int8 filter's candidates: the kprime best lower bounds of the query (merged[0..kprime))
+// get their distances recomputed in the oracle's order (canon_dist: one 4-lane group per candidate, 64 per round),
+// sorted by (distance, id), top-k emitted.  Certificate: every row that is NOT among them has a lower bound
+// >= the kprime-th kept one (rows the scan never collected were above a threshold that is itself >= it; keys
+// dropped by the merges are above it), so  D_lower(kprime-th) - margin > exact k-th distance  proves the top-k.
+// ---------------------------------------------------------------------------------------------
+template <typename XT>
+__global__ __launch_bounds__(256) void rerank256_kernel(const Rerank256Args a) {
+  __shared__ uint64_t keys[kMerged8];
+  const int tid = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  const int g = tid >> 2, sub = tid & 3;
+  const float* qv = a.Q + (size_t)q * a.ld;
+  const bool scale_x = a.metric == 2;
+  for (uint32_t c0 = 0; c0 < kMerged8; c0 += 64) {
+    const uint32_t ci = c0 + (uint32_t)g;
+    const uint64_t mk = a.merged[(size_t)q * kMerged8 + ci];
+    const uint32_t id = (uint32_t)mk;
+    const bool valid = ci < a.kprime && mk != kKeyInf && id < a.n;
+    float d = __builtin_inff();
+    if (c0 < a.kprime) {  // (uniform) rounds beyond kprime hold nothing to evaluate
+      if (valid) {
+        const XT* xv = (const XT*)a.X + (size_t)id * a.ld;
+        const float xs = scale_x ? a.inv_norm[id] : 1.0f;
+        d = canon_dist(a.metric == 0 ? 0 : 1, qv, xv, xs, scale_x, a.dims, sub);
+      }
+    }
+    if (sub == 0) keys[ci] = (valid && d == d) ? (((uint64_t)f32_to_ordered(d) << 32) | id) : kKeyInf;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    uint64_t k4[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) k4[r] = keys[r * 64 + tid];
+    wave_sort256(k4, tid);
+    const uint64_t key = k4[0];  // the 64 best: k <= EHX_MAX_K < 64
+    uint32_t nvalid = 0;
+#pragma unroll
+    for (int r = 0; r < kR; ++r) nvalid += (uint32_t)__builtin_popcountll(__ballot(k4[r] != kKeyInf));
+    const uint32_t cnt = nvalid < a.k ? nvalid : a.k;
+    if (tid < (int)a.k) {
+      const bool ok = (uint32_t)tid < cnt;
+      a.out_ids[(size_t)q * a.k + tid] = ok ? (uint64_t)(uint32_t)key : ~0ull;
+      a.out_dist[(size_t)q * a.k + tid] = ok ? ordered_to_f32((uint32_t)(key >> 32)) : __builtin_inff();
+    }
+    if (tid == 0) a.out_count[q] = cnt;
+    bool uncert;
+    const uint64_t last = a.merged[(size_t)q * kMerged8 + a.kprime - 1];  // the kprime-th best lower bound
+    if (a.ovf[q]) {
+      uncert = true;  // the pool overflowed in some pass: candidates may be missing
+    } else if (a.n <= a.kprime) {
+      uncert = false;  // (not reached: small spaces use the other engines) every row is a candidate
+    } else if (last == kKeyInf || cnt < a.k || a.k == 0) {
+      uncert = true;  // fewer than kprime lower bounds known, or candidates lost (NaN rows / queries)
+    } else {
+      const float2 uv = a.quv[q];
+      const float worst = __builtin_fmaf(uv.x, ordered_to_f32((uint32_t)(last >> 32)), uv.y);
+      const float qn = a.metric == 0 ? uv.y : (a.metric == 1 ? uv.x * uv.x : 1.0f);
+      const float kth = ordered_to_f32((uint32_t)(__shfl(key, (int)a.k - 1, 64) >> 32));
+      const float margin = cert_margin(a.metric, a.dims, qn, a.max_sumsq ? *a.max_sumsq : __builtin_inff(),
+                                       fmaxf(fabsf(kth), fabsf(worst)));
+      uncert = !(worst - margin > kth);  // (NaN u / v: a query the filter could not bound -> uncertified)
+    }
+    if (tid == 0) {
+      if (uncert) atomicAdd(a.n_uncertified, 1ull);
+      if (a.uncert_flags) a.uncert_flags[q] = uncert ? 1u : 0u;
+    }
+  }
+}
+
+hipError_t launch_rerank256(const Rerank256Args& a, hipStream_t st) {
+  if (a.x_half) hipLaunchKernelGGL(rerank256_kernel<__half>, dim3(a.nq), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(rerank256_kernel<float>, dim3(a.nq), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace ehx

@@ -131,6 +131,12 @@ class Space:
     def set_scan(self, scan):
         check(self._L.ehx_space_set_scan(self._h, scan))
 
+    def scan_engine(self):
+        """the engine that answers first right now: "f32" | "f16" | "i8" """
+        e = C.c_uint32()
+        check(self._L.ehx_space_scan_engine(self._h, C.byref(e)))
+        return ("f32", "f16", "i8")[e.value]
+
     def fill_synthetic(self, seed, row0, n_rows, normalize):
         check(self._L.ehx_fill_synthetic(self._h, seed, row0, n_rows, int(bool(normalize))))
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define EHX_ABI_VERSION 3
+#define EHX_ABI_VERSION 4
 
 /* ---- error codes (shim mapping: gRPC status for contract 1, fferr type for contract 2) ---- */
 enum {
@@ -71,7 +71,14 @@ enum {
   EHX_MODE_GRAPH = 1  /* HNSW-style level-0 best-first search over an HBM-resident graph      */
 };
 
-enum { EHX_SCAN_AUTO = 0, EHX_SCAN_F32 = 1 };
+/* scan engine selection of a flat space (ehx_params.scan, ehx_space_set_scan); results are identical for all */
+enum {
+  EHX_SCAN_AUTO = 0, /* the fastest certified filter the space supports: int8 where it pays, else fp16 */
+  EHX_SCAN_F32 = 1,  /* fp32 matrix-core scan only */
+  EHX_SCAN_F16 = 2   /* fp16 matrix-core filter (never the int8 one) */
+};
+/* what ehx_space_scan_engine reports: the engine that answers first right now */
+enum { EHX_ENGINE_F32 = 0, EHX_ENGINE_F16 = 1, EHX_ENGINE_I8 = 2 };
 
 #define EHX_MAX_K 48u /* largest k served by one scan pass (k + 8 slack < 64 candidate slots) */
 #define EHX_MAX_K_PAGED 1024u /* flat mode serves EHX_MAX_K < k <= this exactly too, by the exhaustive canonical pass in
@@ -95,9 +102,11 @@ typedef struct ehx_params {
                                the oracle's), 1 = strictly sequential everywhere, N > 1 = rounds of up to N
                                rows, ALSO for an ehx_set_batch made only of fresh keys (hnswlib-python's
                                multi-threaded add_items), 0xFFFFFFFF = no graph building (import one).    */
-  uint32_t scan;            /* flat mode: EHX_SCAN_AUTO (0) = fp16 matrix-core filter scan in front of
-                               the canonical fp32 re-rank, with an fp32 re-scan of every query the filter cannot
-                               certify — results identical to EHX_SCAN_F32 (1) = fp32 matrix-core scan only.   */
+  uint32_t scan;            /* flat mode: EHX_SCAN_AUTO (0) = a matrix-core FILTER scan (int8 on long rows and
+                               >= 16 Ki rows, else fp16) in front of the canonical fp32 re-rank; every query a
+                               filter cannot certify is re-run by the next engine (int8 -> fp16 -> fp32 scan ->
+                               exhaustive canonical pass) — results identical to EHX_SCAN_F32 (1) = fp32
+                               matrix-core scan only; EHX_SCAN_F16 (2) = start from the fp16 filter.          */
   uint32_t reserved[6];
 } ehx_params;
 
@@ -109,8 +118,9 @@ typedef struct ehx_stats_t {
   uint64_t n_dist;           /* distances actually evaluated (one per vector row fetched)            */
   uint64_t n_hops;           /* graph nodes expanded (graph mode)                                    */
   uint64_t n_rerank;         /* candidates re-ranked in canonical order                              */
-  uint64_t n_uncertified;    /* queries whose top-k could not be certified exact by any stage (only when
-                                more than 32 queries of one call need the exhaustive stage)         */
+  uint64_t n_uncertified;    /* always 0: a call never returns EHX_OK with an uncertified result (what the matrix-
+                                core scans cannot certify is answered by the exhaustive canonical pass; kept in
+                                the struct as the audit counter of that invariant)                  */
   uint64_t bytes_algorithmic;/* SURVEY §8d algorithmic bytes of the scans/searches served            */
   double   last_scan_ms;     /* device time of the last scan/search kernel (HIP events)              */
   double   last_total_ms;    /* device time of the last full ehx_knn* pipeline                       */
@@ -119,6 +129,8 @@ typedef struct ehx_stats_t {
   uint64_t n_filter_queries; /* queries answered through the fp16 filter scan                        */
   uint64_t n_filter_fallback;/* ... of which the filter could not certify and the fp32 scan re-ran   */
   uint64_t n_exhaustive;     /* queries answered by the exhaustive canonical pass (fp32 scan uncertified) */
+  uint64_t n_i8_queries;     /* queries answered through the int8 filter scan                         */
+  uint64_t n_i8_fallback;    /* ... of which it could not certify (pool overflow / margin): next engine */
 } ehx_stats_t;
 
 /* ---- process / device ---- */
@@ -141,9 +153,11 @@ int ehx_space_size(ehx_space* s, uint64_t* n); /* number of distinct keys       
 int ehx_space_dims(ehx_space* s, uint32_t* dims);
 int ehx_space_reserve(ehx_space* s, uint64_t rows);
 int ehx_space_set_ef(ehx_space* s, uint32_t ef);
-/* flat fp32 spaces: switch between EHX_SCAN_AUTO (fp16 filter + fp32 certified re-rank, the default) and
- * EHX_SCAN_F32 (fp32 scan only).  Results are identical; A/B measurement and diagnosis. */
+/* flat spaces: switch between EHX_SCAN_AUTO (certified filter scan, the default), EHX_SCAN_F16 and EHX_SCAN_F32.
+ * Results are identical; A/B measurement and diagnosis.  The scan copies stay current whatever is selected. */
 int ehx_space_set_scan(ehx_space* s, uint32_t scan);
+/* the engine that answers first on this space right now: EHX_ENGINE_* */
+int ehx_space_scan_engine(ehx_space* s, uint32_t* engine);
 
 /* ---- writes: Set/MultiSet (server.cc:113-149 -> Version::set -> ANNIndex::set, index.cc:20-37),
  *      OnlineStoreTable.Set / BatchOnlineTable.BatchSet (online.go:50-53,66-70) ---- */

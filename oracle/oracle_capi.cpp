@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see hnsw_oracle.hpp header).
 // extern "C" surface so tests/, smoke() and bench.py's cpu_baseline leg can drive
 // the restatement through ctypes.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -232,19 +233,59 @@ void orc_hnsw_export_vectors(void* p, float* out) {
 double orc_exhaustive(const float* X, size_t n, size_t dim, int metric, const float* Q, size_t nq,
                       size_t k, uint64_t* ids, float* dists, uint32_t* counts, int threads) {
   std::vector<float> Xn, Qn;
+  const size_t NB = 1024;  // rows per normalisation work item
   if (metric == METRIC_COSINE) {
     Xn.resize(n * dim);
-    parallel_for(n, threads, [&](size_t i, int) { normalize_vector(X + i * dim, &Xn[i * dim], dim); });
+    parallel_for((n + NB - 1) / NB, threads, [&](size_t b, int) {
+      const size_t i1 = std::min(n, (b + 1) * NB);
+      for (size_t i = b * NB; i < i1; i++) normalize_vector(X + i * dim, &Xn[i * dim], dim);
+    });
     X = Xn.data();
     Qn.resize(nq * dim);
     for (size_t i = 0; i < nq; i++) normalize_vector(Q + i * dim, &Qn[i * dim], dim);
     Q = Qn.data();
   }
   auto t0 = std::chrono::steady_clock::now();
-  parallel_for(nq, threads, [&](size_t i, int) {
-    size_t c;
-    exhaustive_knn(X, n, dim, metric, Q + i * dim, k, ids + i * k, dists + i * k, &c);
-    counts[i] = (uint32_t)c;
+  // Row-blocked scan: a thread takes a block of rows small enough to stay in its cache and runs every query over
+  // it, keeping the best k of each query it has seen; the per-thread lists are merged at the end.  Same distances
+  // (metric_dist) and the same total order (dist, id) as exhaustive_knn over the whole matrix, so the result is
+  // identical — only the rows are read from DRAM once instead of once per query.
+  typedef std::pair<float, uint64_t> Ent;
+  if (threads < 1) threads = 1;
+  const size_t RB = std::max<size_t>(16, (size_t)(128 * 1024) / (dim ? dim : 1));
+  const size_t nblocks = (n + RB - 1) / RB;
+  std::vector<std::vector<std::vector<Ent>>> heaps((size_t)threads);
+  parallel_for(nblocks, threads, [&](size_t b, int t) {
+    auto& hq = heaps[(size_t)t];
+    if (hq.empty()) hq.resize(nq);
+    const size_t i0 = b * RB, i1 = std::min(n, i0 + RB);
+    for (size_t qi = 0; qi < nq && k > 0; qi++) {
+      auto& h = hq[qi];  // max-heap on (dist, id)
+      const float* q = Q + qi * dim;
+      for (size_t i = i0; i < i1; i++) {
+        const Ent e(metric_dist(metric, q, X + i * dim, dim), (uint64_t)i);
+        if (h.size() < k) {
+          h.push_back(e);
+          std::push_heap(h.begin(), h.end());
+        } else if (e < h.front()) {
+          std::pop_heap(h.begin(), h.end());
+          h.back() = e;
+          std::push_heap(h.begin(), h.end());
+        }
+      }
+    }
+  });
+  parallel_for(nq, threads, [&](size_t qi, int) {
+    std::vector<Ent> all;
+    for (auto& hq : heaps)
+      if (!hq.empty()) all.insert(all.end(), hq[qi].begin(), hq[qi].end());
+    std::sort(all.begin(), all.end());
+    const size_t c = std::min(k, all.size());
+    counts[qi] = (uint32_t)c;
+    for (size_t j = 0; j < c; j++) {
+      dists[qi * k + j] = all[j].first;
+      ids[qi * k + j] = all[j].second;
+    }
   });
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }

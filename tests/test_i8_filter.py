@@ -1,0 +1,166 @@
+"""GPU parity tests of the int8 matrix-core filter engine (k_flati8.hip + k_select.hip), through the C ABI, against
+the oracle's exhaustive scan: ids AND distance bytes identical, on every metric — the filter only chooses
+candidates, the canonical fp32 re-rank and its certificate produce the answer, and whatever the int8 stage cannot
+certify (pool overflow under adversarial row order, ties, margins) must come back exact through the next engines.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+ehx = pytest.importorskip("embeddinghub_amd")
+
+METRICS = [(ehx.METRIC_L2SQ, pyoracle.METRIC_L2), (ehx.METRIC_IP, pyoracle.METRIC_IP),
+           (ehx.METRIC_COSINE, pyoracle.METRIC_COSINE)]
+
+
+def _keys(n, p="k"):
+    return ["%s%d" % (p, i) for i in range(n)]
+
+
+def _check(space, X, Q, k, ometric):
+    ids, dist, cnt = space.knn(Q, k)
+    oids, odist, ocnt = pyoracle.exhaustive(X, Q, k, ometric)
+    np.testing.assert_array_equal(cnt, ocnt)
+    for i in range(Q.shape[0]):
+        c = int(cnt[i])
+        assert list(ids[i, :c]) == list(oids[i, :c]), "query %d ids differ" % i
+        assert dist[i, :c].tobytes() == odist[i, :c].tobytes(), "query %d distances not bit-exact" % i
+    assert space.stats()["n_uncertified"] == 0
+
+
+def _space(d, em, n, **kw):
+    s = ehx.Space.unique("i8", d, metric=em, initial_capacity=n, **kw)
+    return s
+
+
+@pytest.mark.parametrize("n,d,nq,k", [
+    (20000, 768, 64, 10),     # the headline row length
+    (70000, 200, 300, 10),    # dims not a multiple of the 64-byte stage row; two query tiles
+    (40000, 1536, 33, 10),    # config-5 dims
+    (30000, 300, 1024, 5),    # four query tiles share every row chunk (lock-step path)
+    (17000, 520, 7, 48),      # EHX_MAX_K
+    (150000, 768, 128, 1),
+])
+@pytest.mark.parametrize("em,om", METRICS)
+def test_i8_engine_parity(n, d, nq, k, em, om):
+    rng = np.random.default_rng(n + d)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    Q[: min(nq, 4)] = X[:min(nq, 4)] + np.float32(1e-3) * rng.standard_normal((min(nq, 4), d)).astype(np.float32)
+    s = _space(d, em, n)
+    s.set_batch(_keys(n), X)
+    assert s.scan_engine() == "i8"
+    s.stats_reset()
+    _check(s, X, Q, k, om)
+    st = s.stats()
+    assert st["n_i8_queries"] == nq, st
+    if k <= 10:
+        assert st["n_i8_fallback"] <= nq // 8, "the int8 stage should certify ordinary data: %r" % (st,)
+    # the other engines agree byte for byte (each is checked against the oracle)
+    for scan in (ehx.SCAN_F16, ehx.SCAN_F32):
+        s.set_scan(scan)
+        _check(s, X, Q[: min(nq, 64)], k, om)
+    s.drop()
+
+
+@pytest.mark.parametrize("em,om", METRICS)
+def test_i8_heterogeneous_rows(em, om):
+    """row norms over two decades, one-hot rows, constant rows, zero rows, a dominant coordinate: per-row scales and
+    per-row error bounds must keep the lower bound valid and the certificate honest"""
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 24000, 384, 96, 10
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    X *= (10.0 ** rng.uniform(-1, 1, size=(n, 1))).astype(np.float32)
+    X[100:200] = 0.0
+    X[200:300] = np.eye(d, dtype=np.float32)[rng.integers(0, d, 100)] * np.float32(3.0)
+    X[300:400] = np.float32(0.5)
+    X[400:500, 0] *= np.float32(80.0)
+    X[5000:5050] = X[5000]  # a duplicate cluster (ties)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    Q[:8] = X[200:208]
+    Q[8:16] = X[5000]
+    Q[16:24] = X[400:408]
+    Q[24] = 0.0
+    s = _space(d, em, n)
+    s.set_batch(_keys(n), X)
+    assert s.scan_engine() == "i8"
+    _check(s, X, Q, k, om)
+    s.drop()
+
+
+@pytest.mark.parametrize("em,om", [METRICS[0], METRICS[2]])
+def test_i8_adversarial_row_order_overflows_the_pool_and_stays_exact(em, om):
+    """rows ordered from far to near for a group of queries: every row beats the threshold the earlier rows left, the
+    pools of those queries overflow, and the next engine answers them — exactly"""
+    rng = np.random.default_rng(9)
+    n, d, k = 60000, 256, 10
+    c = rng.standard_normal(d).astype(np.float32)
+    c /= np.linalg.norm(c)
+    noise = rng.standard_normal((n, d)).astype(np.float32)
+    noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+    w = np.linspace(0.0, 0.98, n, dtype=np.float32)[:, None]   # later rows lie closer and closer to c
+    X = (w * c[None, :] + (1 - w) * noise).astype(np.float32)
+    Q = rng.standard_normal((40, d)).astype(np.float32)
+    Q[:20] = c[None, :] + np.float32(0.01) * rng.standard_normal((20, d)).astype(np.float32)
+    s = _space(d, em, n)
+    for i0 in range(0, n, 16384):
+        s.set_batch(_keys(n)[i0:i0 + 16384], X[i0:i0 + 16384])
+    assert s.scan_engine() == "i8"
+    s.stats_reset()
+    _check(s, X, Q, k, om)
+    st = s.stats()
+    assert st["n_i8_queries"] == 40
+    assert st["n_i8_fallback"] >= 20, "the adversarial queries were expected to overflow their pools: %r" % (st,)
+    s.drop()
+
+
+def test_i8_growth_updates_and_fp16_rows():
+    rng = np.random.default_rng(21)
+    d, k = 512, 10
+    s = ehx.Space.unique("i8g", d, metric=ehx.METRIC_COSINE)          # default capacity: doubles many times
+    X = rng.standard_normal((20000, d)).astype(np.float32)
+    for i0 in range(0, 20000, 3000):
+        s.set_batch(_keys(20000)[i0:i0 + 3000], X[i0:i0 + 3000])
+    upd = rng.standard_normal((500, d)).astype(np.float32)
+    s.set_batch(_keys(20000)[7000:7500], upd)                         # rows rewritten in place: scan copy refreshed
+    X[7000:7500] = upd
+    Q = np.concatenate([upd[:16] + np.float32(1e-3), rng.standard_normal((48, d)).astype(np.float32)])
+    assert s.scan_engine() == "i8"
+    _check(s, X, Q, k, pyoracle.METRIC_COSINE)
+    s.drop()
+    # fp16 row storage: the int8 copy is made from the rounded rows; results = oracle on the rounded rows
+    h = ehx.Space.unique("i8h", d, metric=ehx.METRIC_L2SQ, dtype=ehx.DTYPE_F16, initial_capacity=20000)
+    h.set_batch(_keys(20000), X)
+    Xh = X.astype(np.float16).astype(np.float32)
+    assert h.scan_engine() == "i8"
+    _check(h, Xh, Q, k, pyoracle.METRIC_L2)
+    h.drop()
+
+
+def test_i8_synthetic_fill_matches_oracle_generator():
+    n, d = 100_000, 768
+    s = ehx.Space.unique("i8s", d, metric=ehx.METRIC_COSINE, initial_capacity=n)
+    s.fill_synthetic(ehx.SEED_CORPUS, 0, n, True)
+    X = pyoracle.gen_rows(ehx.SEED_CORPUS, 0, n, d, normalize=True)
+    Q = pyoracle.gen_rows(ehx.SEED_QUERY, 0, 256, d, normalize=True)
+    assert s.scan_engine() == "i8"
+    s.stats_reset()
+    _check(s, X, Q, 10, pyoracle.METRIC_COSINE)
+    st = s.stats()
+    assert st["n_i8_queries"] == 256 and st["n_i8_fallback"] == 0, st   # the bench distribution certifies at k' = 128
+    s.drop()
+
+
+def test_small_or_short_row_spaces_use_the_fp16_filter():
+    rng = np.random.default_rng(1)
+    a = ehx.Space.unique("small", 768, metric=ehx.METRIC_COSINE)
+    a.set_batch(_keys(3000), rng.standard_normal((3000, 768)).astype(np.float32))
+    assert a.scan_engine() == "f16"          # below the int8 engine's minimum row count
+    b = ehx.Space.unique("short", 128, metric=ehx.METRIC_L2SQ, initial_capacity=40000)
+    b.set_batch(_keys(40000), rng.standard_normal((40000, 128)).astype(np.float32))
+    assert b.scan_engine() == "f16"          # 128-dim rows: the int8 copy would be as long as the fp16 one
+    a.drop()
+    b.drop()
