@@ -29,7 +29,8 @@ class EhxError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("M", C.c_uint32), ("ef_construction", C.c_uint32),
                 ("ef", C.c_uint32), ("seed", C.c_uint64), ("initial_capacity", C.c_uint64),
-                ("build_batch", C.c_uint32), ("scan", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+                ("build_batch", C.c_uint32), ("scan", C.c_uint32), ("shards", C.c_uint32),
+                ("reserved", C.c_uint32 * 5)]
 
 
 class Stats(C.Structure):

@@ -20,6 +20,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -53,7 +54,8 @@ int fail(int code, const char* fmt, ...) {
 struct Engine {
   std::mutex mu;
   bool inited = false;
-  int device = 0;
+  int device = 0;            // devices[0]: where unsharded spaces live
+  std::vector<int> devices;  // ehx_init's device list: shard i of a sharded space lives on devices[i % size]
   int n_cus = 256;
   std::unordered_map<std::string, std::unique_ptr<ehx_space>> spaces;
   std::vector<std::unique_ptr<ehx_space>> graveyard;  // dropped spaces (tombstones), freed by ehx_shutdown
@@ -99,6 +101,15 @@ struct ehx_space {
                                // freed memory; reclaimed by ehx_shutdown
   bool implicit_keys = false;  // rows appended by ehx_fill_synthetic: key == decimal row id
   std::shared_mutex mu;        // writers: set/drop/reserve ; readers: knn/get
+  int device = 0;              // HIP device of this space's HBM state
+  // Row sharding behind the C ABI (ehx_params.shards > 1): the PARENT keeps the key maps and no rows; global row g
+  // lives in shard g % G at local row g / G (streamed Sets stay balanced); the shards are ordinary
+  // keyless spaces, one per device of ehx_init's list, searched concurrently and merged on shard 0's device.
+  bool keyless = false;            // a shard: rows are addressed by local id only, hidden from ehx_space_open
+  std::vector<ehx_space*> shards;  // parent only (the shards are owned by the registry under hidden names)
+  DevBuf<uint64_t> dGIds;          // parent scratch on shards[0]'s device: gathered [G][nq][k] ids,
+  DevBuf<float> dGDist;            //   distances,
+  DevBuf<uint32_t> dGCnt;          //   counts
 
   // HBM-resident state
   void* dX = nullptr;        // [cap][ld] rows, fp32 or fp16 (x_half)
@@ -231,6 +242,9 @@ struct ehx_space {
     dPool.release();
     dMerged8.release();
     dI8Ctl.release();
+    dGIds.release();
+    dGDist.release();
+    dGCnt.release();
     fr(dUncert16);
     fr(dAdj0);
     fr(dUpStart);
@@ -1089,12 +1103,18 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   }();
   static const bool use_sync = [] {
     const char* g = getenv("EHX_I8_SYNC");
-    return g ? atoi(g) != 0 : true;
+    return g ? atoi(g) != 0 : false;  // measured r02: the lock-step costs ~9 % of the scan time at 10 M x 768
   }();
   constexpr uint32_t kSampleTiles = 8;
-  // the int8 bound leaves ~60-75 rows per query it cannot exclude from the top-10 (scripts/studies/int8_filter_bound.py);
-  // more for a larger k (the k-th best sits where rows are denser)
-  const uint32_t kprime = k <= 16 ? 128u : std::min<uint32_t>(192u, 96u + 2u * k);
+  // The int8 bound leaves ~60-75 rows per query ON AVERAGE that it cannot exclude from the top-10 at 10 M rows
+  // (scripts/studies/int8_filter_bound.py), with a heavy tail — a query whose 10th neighbour is unusually far has
+  // several times as many — and a query whose list is too short costs a whole scan by the next engine.  So the
+  // threshold rank is the full width of the running list; the re-rank reads only as many candidates as it needs.
+  static const uint32_t kprime = [] {
+    const char* g = getenv("EHX_I8_KPRIME");
+    const long v = g ? atol(g) : (long)kMerged8;
+    return (uint32_t)(v < 64 ? 64 : (v > (long)kMerged8 ? (long)kMerged8 : v));
+  }();
   const uint32_t n_tiles = (uint32_t)((s->n + kTileRows16 - 1) / kTileRows16);
   struct Pass {
     uint32_t tile0;
@@ -1445,6 +1465,183 @@ int lookup_key(ehx_space* s, const char* key, size_t klen, uint64_t* id) {
   return EHX_OK;
 }
 
+
+// resolve the keys of a batch to row ids (upsert: an existing key keeps its label, index.cc:21-35); a key repeated
+// inside the batch resolves to one row and the LAST vector wins, as sequential Sets would leave it.  Fresh keys are
+// resolved against a batch-local map and committed to key_to_id / id_to_key only after their rows are in HBM with
+// statistics: a failing upload leaves the key maps and the row count untouched.
+void resolve_keys(ehx_space* s, size_t n, const char* const* keys, const size_t* klens, std::vector<uint64_t>* ids,
+                         uint64_t* next_out, std::vector<std::string>* new_keys) {
+  ids->resize(n);
+  uint64_t next = s->n;
+  std::unordered_map<std::string, uint64_t> fresh;
+  for (size_t i = 0; i < n; ++i) {
+    std::string k(keys[i], klens[i]);
+    auto it = s->key_to_id.find(k);
+    if (it != s->key_to_id.end()) {
+      (*ids)[i] = it->second;
+      continue;
+    }
+    auto f = fresh.find(k);
+    if (f != fresh.end()) {
+      (*ids)[i] = f->second;
+      continue;
+    }
+    (*ids)[i] = next;
+    fresh.emplace(k, next);
+    new_keys->push_back(std::move(k));
+    ++next;
+  }
+  *next_out = next;
+}
+
+// =====================================================================================================
+// Row-sharded spaces behind the C ABI (ehx_params.shards = G > 1).
+// One process drives the G devices of ehx_init's list: global row g lives in shard g % G at local row g / G; a
+// search runs on every shard concurrently (one host thread and one stream per shard), each shard's local top-k
+// (k * 12 + 4 bytes per query) is copied peer-to-peer over xGMI into one gather buffer on shard 0's device and
+// merge_lists_kernel — the same kernel the multi-process path uses behind its RCCL all-gather — turns local rows
+// into global ids (local * G + shard) and merges by (distance, id).  No other exchange step exists.
+// =====================================================================================================
+inline bool is_parent(const ehx_space* s) { return !s->shards.empty(); }
+
+// f(i) for every shard, each on its own thread (shard 0 on the caller's); first failure wins
+template <class F>
+int for_each_shard(ehx_space* p, F f) {
+  const size_t G = p->shards.size();
+  std::vector<int> rcs(G, 0);
+  std::vector<std::string> errs(G);
+  std::vector<std::thread> th;
+  th.reserve(G);
+  for (size_t i = 1; i < G; ++i)
+    th.emplace_back([&, i] {
+      rcs[i] = f(i);
+      if (rcs[i]) errs[i] = g_err;
+    });
+  rcs[0] = f(0);
+  if (rcs[0]) errs[0] = g_err;
+  for (auto& t : th) t.join();
+  for (size_t i = 0; i < G; ++i)
+    if (rcs[i]) {
+      snprintf(g_err, sizeof(g_err), "shard %zu: %s", i, errs[i].c_str());
+      return rcs[i];
+    }
+  return EHX_OK;
+}
+
+int write_rows_locked_fwd(ehx_space* s, size_t n, const std::vector<uint64_t>& ids, uint64_t next, const float* vecs);
+int fill_synthetic_locked(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize, uint64_t stride);
+
+// parent locked exclusively by the caller
+int sharded_set_batch(ehx_space* p, size_t n, const char* const* keys, const size_t* klens, const float* vecs) {
+  if (p->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
+  if (p->implicit_keys) return fail(EHX_EINVAL, "space '%s' holds synthetic rows with implicit keys", p->name.c_str());
+  const uint64_t G = p->shards.size();
+  std::vector<uint64_t> ids;
+  std::vector<std::string> new_keys;
+  uint64_t next = 0;
+  resolve_keys(p, n, keys, klens, &ids, &next, &new_keys);
+  std::vector<std::vector<uint64_t>> lids(G);
+  std::vector<std::vector<float>> rows(G);
+  for (size_t i = 0; i < n; ++i) {
+    const uint64_t sh = ids[i] % G;
+    lids[sh].push_back(ids[i] / G);
+    rows[sh].insert(rows[sh].end(), vecs + i * p->dims, vecs + (i + 1) * p->dims);
+  }
+  int rc = for_each_shard(p, [&](size_t i) -> int {
+    if (lids[i].empty()) return EHX_OK;
+    ehx_space* c = p->shards[i];
+    std::unique_lock<std::shared_mutex> wl(c->mu);
+    const uint64_t next_local = (next + G - 1 - i) / G;  // globals below `next` that belong to shard i
+    return write_rows_locked_fwd(c, lids[i].size(), lids[i], next_local, rows[i].data());
+  });
+  if (rc) return rc;  // (a failing shard leaves the parent's key maps and row count untouched)
+  const uint64_t old_n = p->n;
+  for (size_t i = 0; i < new_keys.size(); ++i) p->key_to_id.emplace(new_keys[i], old_n + i);
+  for (auto& k : new_keys) p->id_to_key.push_back(std::move(k));
+  p->n = next;
+  return EHX_OK;
+}
+
+int sharded_fill_synthetic(ehx_space* p, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize) {
+  if (p->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
+  if (!p->implicit_keys && p->n != 0) return fail(EHX_EINVAL, "space '%s' already holds keyed rows", p->name.c_str());
+  const uint64_t G = p->shards.size(), n0 = p->n;
+  int rc = for_each_shard(p, [&](size_t i) -> int {
+    // globals n0 .. n0+n_rows-1 with g % G == i: g0, g0 + G, ...; generator row of global g = row0 + (g - n0)
+    const uint64_t g0 = n0 + ((i + G - n0 % G) % G);
+    if (g0 >= n0 + n_rows) return EHX_OK;
+    const uint64_t cnt = (n0 + n_rows - 1 - g0) / G + 1;
+    ehx_space* c = p->shards[i];
+    std::unique_lock<std::shared_mutex> wl(c->mu);
+    return fill_synthetic_locked(c, seed, row0 + (g0 - n0), cnt, normalize, G);
+  });
+  if (rc) return rc;
+  p->implicit_keys = true;
+  p->n += n_rows;
+  return EHX_OK;
+}
+
+// queries are on the host (d_queries == nullptr) or on device `qdev`; outputs likewise.  Parent locked shared.
+int sharded_knn(ehx_space* p, size_t nq, const float* h_queries, const float* d_queries, int qdev, uint32_t k,
+                uint64_t* out_ids, float* out_dist, uint32_t* out_count, bool out_on_device, hipStream_t caller_stream) {
+  if (k == 0 || nq == 0) return EHX_OK;
+  if (k > 64) return fail(EHX_EUNSUPPORTED, "sharded spaces serve k <= 64 (k=%u)", k);
+  const size_t G = p->shards.size();
+  const int home = p->shards[0]->device;
+  std::lock_guard<std::mutex> sl(p->scratch_mu);
+  int rc;
+  HIP_TRY(hipSetDevice(home));
+  if ((rc = p->dGIds.ensure(G * nq * k))) return rc;
+  if ((rc = p->dGDist.ensure(G * nq * k))) return rc;
+  if ((rc = p->dGCnt.ensure(G * nq))) return rc;
+  if ((rc = p->dOutIds.ensure(nq * k))) return rc;
+  if ((rc = p->dOutDist.ensure(nq * k))) return rc;
+  if ((rc = p->dOutCount.ensure(nq))) return rc;
+  if (d_queries) {  // the caller's stream produced the queries: they must be complete before the shards read them
+    HIP_TRY(hipSetDevice(qdev));
+    HIP_TRY(hipStreamSynchronize(caller_stream));
+  }
+  const size_t qbytes = nq * p->dims * sizeof(float);
+  rc = for_each_shard(p, [&](size_t i) -> int {
+    ehx_space* c = p->shards[i];
+    std::shared_lock<std::shared_mutex> rl(c->mu);
+    std::lock_guard<std::mutex> cl(c->scratch_mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = c->dQraw.ensure(nq * c->dims))) return r;
+    if ((r = c->dOutIds.ensure(nq * k))) return r;
+    if ((r = c->dOutDist.ensure(nq * k))) return r;
+    if ((r = c->dOutCount.ensure(nq))) return r;
+    if (d_queries) HIP_TRY(hipMemcpyPeerAsync(c->dQraw.p, c->device, d_queries, qdev, qbytes, c->stream));
+    else HIP_TRY(hipMemcpyAsync(c->dQraw.p, h_queries, qbytes, hipMemcpyHostToDevice, c->stream));
+    if ((r = knn_device_locked(c, c->stream, nq, c->dQraw.p, k, c->dOutIds.p, c->dOutDist.p, c->dOutCount.p))) return r;
+    // the one exchange step: this shard's local top-k into its slot of the gather buffer on shard 0's device
+    HIP_TRY(hipMemcpyPeerAsync(p->dGIds.p + i * nq * k, home, c->dOutIds.p, c->device, nq * k * sizeof(uint64_t), c->stream));
+    HIP_TRY(hipMemcpyPeerAsync(p->dGDist.p + i * nq * k, home, c->dOutDist.p, c->device, nq * k * sizeof(float), c->stream));
+    HIP_TRY(hipMemcpyPeerAsync(p->dGCnt.p + i * nq, home, c->dOutCount.p, c->device, nq * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return EHX_OK;
+  });
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(home));
+  HIP_TRY(launch_merge_lists(p->dGIds.p, p->dGDist.p, p->dGCnt.p, (uint32_t)nq, k, (uint32_t)G, p->dOutIds.p,
+                             p->dOutDist.p, p->dOutCount.p, p->stream, nq * k * sizeof(uint64_t),
+                             nq * k * sizeof(float), nq * sizeof(uint32_t), (uint64_t)G, 1));
+  if (out_on_device) {
+    HIP_TRY(hipMemcpyPeerAsync(out_ids, qdev, p->dOutIds.p, home, nq * k * sizeof(uint64_t), p->stream));
+    HIP_TRY(hipMemcpyPeerAsync(out_dist, qdev, p->dOutDist.p, home, nq * k * sizeof(float), p->stream));
+    HIP_TRY(hipMemcpyPeerAsync(out_count, qdev, p->dOutCount.p, home, nq * sizeof(uint32_t), p->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(out_ids, p->dOutIds.p, nq * k * sizeof(uint64_t), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(out_dist, p->dOutDist.p, nq * k * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(out_count, p->dOutCount.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->n_queries += nq;
+  return EHX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1463,15 +1660,32 @@ int ehx_init(const int* device_ids, int n_devices) {
     return fail(EHX_ENODEVICE, "no HIP device available (%s); the engine has no CPU fallback",
                 e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
   }
-  int dev = (device_ids && n_devices > 0) ? device_ids[0] : 0;
-  if (dev < 0 || dev >= count) return fail(EHX_EINVAL, "device id %d out of range (0..%d)", dev, count - 1);
-  HIP_TRY(hipSetDevice(dev));
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, dev));
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(EHX_ENODEVICE, "device %d is %s; this engine is built for gfx950 only", dev, prop.gcnArchName);
-  E.device = dev;
-  E.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  std::vector<int> devs;
+  if (device_ids && n_devices > 0) devs.assign(device_ids, device_ids + n_devices);
+  else devs.push_back(0);
+  int n_cus = 0;
+  for (int dev : devs) {
+    if (dev < 0 || dev >= count) return fail(EHX_EINVAL, "device id %d out of range (0..%d)", dev, count - 1);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(EHX_ENODEVICE, "device %d is %s; this engine is built for gfx950 only", dev, prop.gcnArchName);
+    if (!n_cus) n_cus = prop.multiProcessorCount;
+  }
+  // the shards of one space exchange their local top-k lists by peer copies over xGMI: open every pair
+  for (int a : devs)
+    for (int b : devs) {
+      if (a == b) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
+        if (hipSetDevice(a) == hipSuccess) (void)hipDeviceEnablePeerAccess(b, 0);
+      }
+      (void)hipGetLastError();  // (already enabled / not supported: the copies then stage through the host)
+    }
+  HIP_TRY(hipSetDevice(devs[0]));
+  E.devices = devs;
+  E.device = devs[0];
+  E.n_cus = n_cus > 0 ? n_cus : 256;
   E.inited = true;
   return EHX_OK;
 }
@@ -1485,29 +1699,23 @@ int ehx_shutdown(void) {
   return EHX_OK;
 }
 
-int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metric, int dtype,
-                     const ehx_params* params, ehx_space** out) {
-  if (!name || !out) return fail(EHX_EINVAL, "name/out must not be NULL");
-  if (dims == 0 || dims > (1u << 16)) return fail(EHX_EINVAL, "dims=%u out of range", dims);
-  if (metric < EHX_METRIC_L2SQ || metric > EHX_METRIC_COSINE) return fail(EHX_EINVAL, "unknown metric %d", metric);
-  if (dtype != EHX_DTYPE_F32 && dtype != EHX_DTYPE_F16) return fail(EHX_EUNSUPPORTED, "dtype %d not supported", dtype);
-  if (dtype == EHX_DTYPE_F16 && params && params->mode == EHX_MODE_GRAPH)
-    return fail(EHX_EUNSUPPORTED, "fp16 row storage is a flat-mode feature (graph mode stores fp32 rows)");
-  int rc = ehx_init(nullptr, 0);
-  if (rc) return rc;
-  Engine& E = engine();
-  std::lock_guard<std::mutex> lk(E.mu);
-  HIP_TRY(hipSetDevice(E.device));
-  std::string nm(name, name_len);
+// one space on one device (E.mu held by the caller); parent = true: the key-map holder of a sharded space (no HBM)
+static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metric, int dtype, const ehx_params* params,
+                      int device, bool keyless, bool parent, ehx_space** out) {
+  int rc;
+  HIP_TRY(hipSetDevice(device));
   if (E.spaces.count(nm)) return fail(EHX_EEXISTS, "space '%s' already exists", nm.c_str());
   std::unique_ptr<ehx_space> s(new ehx_space);
   s->name = nm;
+  s->device = device;
+  s->keyless = keyless;
   s->dims = dims;
   s->ld = (uint32_t)round_up(dims, kBK);
   s->metric = metric;
   s->x_half = dtype == EHX_DTYPE_F16;
   s->esz = s->x_half ? 2 : sizeof(float);
   if (params) s->params = *params;
+  if (parent) s->params.shards = params->shards;
   if (s->params.mode != EHX_MODE_FLAT && s->params.mode != EHX_MODE_GRAPH)
     return fail(EHX_EINVAL, "unknown mode %u", s->params.mode);
   if (s->params.M == 0) s->params.M = 16;
@@ -1547,16 +1755,60 @@ int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metri
       HIP_TRY(hipMemset(s->dUnsafe8, 0, sizeof(unsigned long long)));
     }
   }
-  HIP_TRY(hipMalloc((void**)&s->dMaxSumsq, sizeof(float)));
-  HIP_TRY(hipMemset(s->dMaxSumsq, 0, sizeof(float)));
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
-  for (auto& pr : s->ring)
-    for (auto& e : pr) HIP_TRY(hipEventCreate(&e));
-  uint64_t cap0 = s->params.initial_capacity ? s->params.initial_capacity : 128;  // index.h:21
-  if ((rc = grow(s.get(), cap0))) return rc;
+  if (!parent) {
+    HIP_TRY(hipMalloc((void**)&s->dMaxSumsq, sizeof(float)));
+    HIP_TRY(hipMemset(s->dMaxSumsq, 0, sizeof(float)));
+    for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& pr : s->ring)
+      for (auto& e : pr) HIP_TRY(hipEventCreate(&e));
+    uint64_t cap0 = s->params.initial_capacity ? s->params.initial_capacity : 128;  // index.h:21
+    if ((rc = grow(s.get(), cap0))) return rc;
+  }
   *out = s.get();
   E.spaces[nm] = std::move(s);
+  return EHX_OK;
+}
+
+int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metric, int dtype,
+                     const ehx_params* params, ehx_space** out) {
+  if (!name || !out) return fail(EHX_EINVAL, "name/out must not be NULL");
+  if (dims == 0 || dims > (1u << 16)) return fail(EHX_EINVAL, "dims=%u out of range", dims);
+  if (metric < EHX_METRIC_L2SQ || metric > EHX_METRIC_COSINE) return fail(EHX_EINVAL, "unknown metric %d", metric);
+  if (dtype != EHX_DTYPE_F32 && dtype != EHX_DTYPE_F16) return fail(EHX_EUNSUPPORTED, "dtype %d not supported", dtype);
+  if (dtype == EHX_DTYPE_F16 && params && params->mode == EHX_MODE_GRAPH)
+    return fail(EHX_EUNSUPPORTED, "fp16 row storage is a flat-mode feature (graph mode stores fp32 rows)");
+  for (size_t i = 0; i < name_len; ++i)
+    if (name[i] == '\x01') return fail(EHX_EINVAL, "space names must not contain byte 0x01 (reserved for shards)");
+  int rc = ehx_init(nullptr, 0);
+  if (rc) return rc;
+  Engine& E = engine();
+  std::lock_guard<std::mutex> lk(E.mu);
+  const std::string nm(name, name_len);
+  const uint32_t G = params ? params->shards : 0;
+  if (G <= 1) return create_one(E, nm, dims, metric, dtype, params, E.device, false, false, out);
+  if (G > 64) return fail(EHX_EINVAL, "shards=%u exceeds 64", G);
+  if (params->mode == EHX_MODE_GRAPH && params->build_batch == 0xFFFFFFFFu)
+    return fail(EHX_EUNSUPPORTED, "sharded graph spaces build their graphs on the GPUs (no import)");
+  // the parent: key maps, routing, merge scratch on shard 0's device; then one keyless space per shard
+  ehx_space* parent = nullptr;
+  ehx_params pp = *params;
+  if ((rc = create_one(E, nm, dims, metric, dtype, &pp, E.devices[0], false, true, &parent))) return rc;
+  ehx_params cp = *params;
+  cp.shards = 0;
+  cp.initial_capacity = (params->initial_capacity + G - 1) / G;
+  for (uint32_t i = 0; i < G; ++i) {
+    ehx_space* c = nullptr;
+    const std::string cn = nm + '\x01' + std::to_string(i);
+    rc = create_one(E, cn, dims, metric, dtype, &cp, E.devices[i % E.devices.size()], true, false, &c);
+    if (rc) {
+      for (ehx_space* d : parent->shards) E.spaces.erase(d->name);
+      E.spaces.erase(nm);
+      return rc;
+    }
+    parent->shards.push_back(c);
+  }
+  *out = parent;
   return EHX_OK;
 }
 
@@ -1565,7 +1817,7 @@ int ehx_space_open(const char* name, size_t name_len, ehx_space** out) {
   Engine& E = engine();
   std::lock_guard<std::mutex> lk(E.mu);
   auto it = E.spaces.find(std::string(name, name_len));
-  if (it == E.spaces.end()) return fail(EHX_ENOTFOUND, "Not found");
+  if (it == E.spaces.end() || it->second->keyless) return fail(EHX_ENOTFOUND, "Not found");
   *out = it->second.get();
   return EHX_OK;
 }
@@ -1573,6 +1825,15 @@ int ehx_space_open(const char* name, size_t name_len, ehx_space** out) {
 int ehx_space_drop(ehx_space* s) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   Engine& E = engine();
+  if (is_parent(s)) {  // the shards first (each leaves its own tombstone), then the parent itself below
+    std::vector<ehx_space*> kids;
+    {
+      std::unique_lock<std::shared_mutex> wl(s->mu);
+      if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+      kids = s->shards;
+    }
+    for (ehx_space* c : kids) (void)ehx_space_drop(c);
+  }
   std::unique_ptr<ehx_space> owned;
   {
     std::lock_guard<std::mutex> lk(E.mu);
@@ -1587,7 +1848,7 @@ int ehx_space_drop(ehx_space* s) {
     // condition variable, find `dropped` set and return EHX_ENOTFOUND.
     std::unique_lock<std::shared_mutex> wl(s->mu);
     std::lock_guard<std::mutex> sl(s->scratch_mu);
-    (void)hipSetDevice(E.device);
+    (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
     s->dropped = true;
     s->release_device();
@@ -1607,6 +1868,10 @@ int ehx_space_freeze(ehx_space* s) {
   std::unique_lock<std::shared_mutex> wl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   s->frozen = true;
+  for (ehx_space* c : s->shards) {
+    std::unique_lock<std::shared_mutex> cl(c->mu);
+    c->frozen = true;
+  }
   return EHX_OK;
 }
 
@@ -1628,7 +1893,15 @@ int ehx_space_reserve(ehx_space* s, uint64_t rows) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   std::unique_lock<std::shared_mutex> wl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
-  HIP_TRY(hipSetDevice(engine().device));
+  if (is_parent(s)) {
+    const uint64_t G = s->shards.size();
+    for (ehx_space* c : s->shards) {
+      int rc = ehx_space_reserve(c, (rows + G - 1) / G);
+      if (rc) return rc;
+    }
+    return EHX_OK;
+  }
+  HIP_TRY(hipSetDevice(s->device));
   return grow(s, rows);
 }
 
@@ -1637,6 +1910,10 @@ int ehx_space_set_ef(ehx_space* s, uint32_t ef) {
   std::unique_lock<std::shared_mutex> wl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   s->params.ef = ef;
+  for (ehx_space* c : s->shards) {
+    int rc = ehx_space_set_ef(c, ef);
+    if (rc) return rc;
+  }
   return EHX_OK;
 }
 
@@ -1644,6 +1921,14 @@ int ehx_space_set_scan(ehx_space* s, uint32_t scan) {
   if (!valid_space(s) || scan > EHX_SCAN_F16) return fail(EHX_EINVAL, "bad argument");
   std::unique_lock<std::shared_mutex> wl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+  if (is_parent(s)) {
+    for (ehx_space* c : s->shards) {
+      int rc = ehx_space_set_scan(c, scan);
+      if (rc) return rc;
+    }
+    s->params.scan = scan;
+    return EHX_OK;
+  }
   if (scan != EHX_SCAN_F32 && !s->has16)
     return fail(EHX_EUNSUPPORTED, "space '%s' was created without the filter scan copies", s->name.c_str());
   s->params.scan = scan;
@@ -1656,6 +1941,7 @@ int ehx_space_scan_engine(ehx_space* s, uint32_t* engine) {
   if (!valid_space(s) || !engine) return fail(EHX_EINVAL, "NULL argument");
   std::shared_lock<std::shared_mutex> rl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+  if (is_parent(s)) return ehx_space_scan_engine(s->shards[0], engine);
   *engine = (uint32_t)resolve_engine(s);
   return EHX_OK;
 }
@@ -1668,6 +1954,10 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
   if (!keys || !klens || !vecs) return fail(EHX_EINVAL, "NULL argument");
   std::unique_lock<std::shared_mutex> wl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+  if (s->keyless) return fail(EHX_EINVAL, "a shard is written through its parent space");
+  auto write = [&](size_t cnt, const char* const* ks, const size_t* kl, const float* v) -> int {
+    return is_parent(s) ? sharded_set_batch(s, cnt, ks, kl, v) : set_batch_locked(s, cnt, ks, kl, v);
+  };
   if (s->params.mode == EHX_MODE_GRAPH && n > 1 && s->params.build_batch != 0xFFFFFFFFu) {
     // graph mode replays a batch in call order; when it re-writes keys (known ones, or the same key
     // twice) every row must be in HBM exactly when its turn comes, so such batches go row by row
@@ -1681,13 +1971,13 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
     }
     if (rewrite) {
       for (size_t i = 0; i < n; ++i) {
-        int rc = set_batch_locked(s, 1, keys + i, klens + i, vecs + i * s->dims);
+        int rc = write(1, keys + i, klens + i, vecs + i * s->dims);
         if (rc) return rc;
       }
       return EHX_OK;
     }
   }
-  return set_batch_locked(s, n, keys, klens, vecs);
+  return write(n, keys, klens, vecs);
 }
 
 // (re)build the derived copies of rows [row0, row0+n) after they were written; must follow row_stats:
@@ -1713,37 +2003,27 @@ static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n) {
   return EHX_OK;
 }
 
+static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>& ids, uint64_t next, const float* vecs,
+                             std::vector<std::string>* new_keys);
+
 static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, const size_t* klens, const float* vecs) {
   if (s->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
   if (s->implicit_keys) return fail(EHX_EINVAL, "space '%s' holds synthetic rows with implicit keys", s->name.c_str());
-  HIP_TRY(hipSetDevice(engine().device));
-  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev[3], 0));  // in-flight device searches
-  // resolve ids (upsert: an existing key keeps its label, index.cc:21-35); a key repeated inside the
-  // batch resolves to one row and the LAST vector wins, as sequential Sets would leave it.
-  std::vector<uint64_t> ids(n);
-  const uint64_t old_n = s->n;
-  uint64_t next = s->n;
-  // fresh keys are resolved against a batch-local map and committed to key_to_id / id_to_key only after their
-  // rows are in HBM with statistics: a failing upload leaves the key maps and the row count untouched
+  std::vector<uint64_t> ids;
   std::vector<std::string> new_keys;
-  std::unordered_map<std::string, uint64_t> fresh;
-  for (size_t i = 0; i < n; ++i) {
-    std::string k(keys[i], klens[i]);
-    auto it = s->key_to_id.find(k);
-    if (it != s->key_to_id.end()) {
-      ids[i] = it->second;
-      continue;
-    }
-    auto f = fresh.find(k);
-    if (f != fresh.end()) {
-      ids[i] = f->second;
-      continue;
-    }
-    ids[i] = next;
-    fresh.emplace(k, next);
-    new_keys.push_back(std::move(k));
-    ++next;
-  }
+  uint64_t next = 0;
+  resolve_keys(s, n, keys, klens, &ids, &next, &new_keys);
+  return write_rows_locked(s, n, ids, next, vecs, &new_keys);
+}
+
+// rows `vecs[i]` -> row ids[i] of the space (ids < next; ids >= s->n are appended, dense), then statistics, derived
+// copies, graph; finally publishes the keys (new_keys, in id order from s->n) and the new row count `next`
+static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>& ids, uint64_t next, const float* vecs,
+                             std::vector<std::string>* new_keys) {
+  if (s->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
+  HIP_TRY(hipSetDevice(s->device));
+  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev[3], 0));  // in-flight device searches
+  const uint64_t old_n = s->n;
   int rc = ensure_rows(s, next);
   if (rc) return rc;
   // upload through pinned staging in slabs; rows may be non-contiguous (updates) so copy per row
@@ -1786,8 +2066,10 @@ static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, con
   if ((rc = refresh_scan16(s, min_id, max_id - min_id + 1))) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
   // commit: the rows are resident and described — publish the keys and the new row count
-  for (size_t i = 0; i < new_keys.size(); ++i) s->key_to_id.emplace(new_keys[i], old_n + i);
-  for (auto& k : new_keys) s->id_to_key.push_back(std::move(k));
+  if (new_keys) {
+    for (size_t i = 0; i < new_keys->size(); ++i) s->key_to_id.emplace((*new_keys)[i], old_n + i);
+    for (auto& k : *new_keys) s->id_to_key.push_back(std::move(k));
+  }
   s->n = next;
   if (s->params.mode == EHX_MODE_GRAPH) {
     // new rows join the graph one at a time, in id order (ANNIndex::set -> addPoint, index.cc:36);
@@ -1815,6 +2097,12 @@ static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, con
   return EHX_OK;
 }
 
+namespace {
+int write_rows_locked_fwd(ehx_space* s, size_t n, const std::vector<uint64_t>& ids, uint64_t next, const float* vecs) {
+  return write_rows_locked(s, n, ids, next, vecs, nullptr);
+}
+}  // namespace
+
 int ehx_set(ehx_space* s, const char* key, size_t klen, const float* vec) {
   const char* keys[1] = {key};
   size_t klens[1] = {klen};
@@ -1827,7 +2115,8 @@ int ehx_get_by_id(ehx_space* s, uint64_t id, float* out_vec) {
   std::shared_lock<std::shared_mutex> rl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   if (id >= s->n) return fail(EHX_ENOTFOUND, "Not found");
-  HIP_TRY(hipSetDevice(engine().device));
+  if (is_parent(s)) return ehx_get_by_id(s->shards[id % s->shards.size()], id / s->shards.size(), out_vec);
+  HIP_TRY(hipSetDevice(s->device));
   if (s->x_half) {
     std::vector<_Float16> h(s->dims);
     HIP_TRY(hipMemcpy(h.data(), s->xrow(id), (size_t)s->dims * 2, hipMemcpyDeviceToHost));
@@ -1865,9 +2154,16 @@ int ehx_knn_device(ehx_space* s, void* stream, size_t n_queries, const float* d_
   if (n_queries && k && (!d_queries || !d_out_ids || !d_out_dist || !d_out_count))
     return fail(EHX_EINVAL, "NULL device pointer");
   std::shared_lock<std::shared_mutex> rl(s->mu);
-  std::lock_guard<std::mutex> sl(s->scratch_mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
-  HIP_TRY(hipSetDevice(engine().device));
+  if (is_parent(s)) {
+    if (n_queries == 0 || k == 0) return EHX_OK;
+    hipPointerAttribute_t at;
+    HIP_TRY(hipPointerGetAttributes(&at, d_queries));
+    return sharded_knn(s, n_queries, nullptr, d_queries, at.device, k, d_out_ids, d_out_dist, d_out_count, true,
+                       (hipStream_t)stream);
+  }
+  std::lock_guard<std::mutex> sl(s->scratch_mu);
+  HIP_TRY(hipSetDevice(s->device));
   return knn_device_locked(s, (hipStream_t)stream, n_queries, d_queries, k, d_out_ids, d_out_dist, d_out_count);
 }
 
@@ -1882,9 +2178,10 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
   }
   if (!queries || !out_ids || !out_dist) return fail(EHX_EINVAL, "NULL argument");
   std::shared_lock<std::shared_mutex> rl(s->mu);
-  std::lock_guard<std::mutex> sl(s->scratch_mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
-  HIP_TRY(hipSetDevice(engine().device));
+  if (is_parent(s)) return sharded_knn(s, n_queries, queries, nullptr, 0, k, out_ids, out_dist, out_count, false, nullptr);
+  std::lock_guard<std::mutex> sl(s->scratch_mu);
+  HIP_TRY(hipSetDevice(s->device));
   int rc;
   const size_t qbytes = n_queries * s->dims * sizeof(float);
   if ((rc = s->dQraw.ensure(n_queries * s->dims))) return rc;
@@ -2086,15 +2383,13 @@ int ehx_gen_rows_device(void* stream, uint64_t seed, uint64_t row0, uint64_t n_r
   return EHX_OK;
 }
 
-int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize) {
-  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
-  if (n_rows == 0) return EHX_OK;
-  std::unique_lock<std::shared_mutex> wl(s->mu);
-  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+namespace {
+// rows row0, row0 + stride, ... of dataset `seed` appended to the space (locked exclusively by the caller)
+int fill_synthetic_locked(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize, uint64_t stride) {
   if (s->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
   if (!s->implicit_keys && s->n != 0)
     return fail(EHX_EINVAL, "space '%s' already holds keyed rows", s->name.c_str());
-  HIP_TRY(hipSetDevice(engine().device));
+  HIP_TRY(hipSetDevice(s->device));
   if (s->n + n_rows >= (1ull << 32)) return fail(EHX_EUNSUPPORTED, "a shard holds at most 2^32-1 rows");
   int rc = grow(s, s->n + n_rows);
   if (rc) return rc;
@@ -2106,13 +2401,13 @@ int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_ro
     if ((rc = tmp.ensure(std::min<uint64_t>(slab, n_rows) * s->ld))) return rc;
     for (uint64_t r0 = 0; r0 < n_rows; r0 += slab) {
       const uint64_t m = std::min<uint64_t>(slab, n_rows - r0);
-      HIP_TRY(launch_gen_rows(seed, row0 + r0, m, s->dims, s->ld, normalize, tmp.p, s->stream));
+      HIP_TRY(launch_gen_rows(seed, row0 + r0 * stride, m, s->dims, s->ld, normalize, tmp.p, s->stream, stride));
       HIP_TRY(launch_store_rows_f16(tmp.p, s->ld, nullptr, s->n + r0, m, s->dims, s->ld, (__half*)s->dX, s->stream));
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     tmp.release();
   } else {
-    HIP_TRY(launch_gen_rows(seed, row0, n_rows, s->dims, s->ld, normalize, (float*)s->xrow(s->n), s->stream));
+    HIP_TRY(launch_gen_rows(seed, row0, n_rows, s->dims, s->ld, normalize, (float*)s->xrow(s->n), s->stream, stride));
   }
   HIP_TRY(launch_row_stats(s->dX, s->x_half, s->n, n_rows, s->dims, s->ld, s->metric, s->dInv, s->dRowp, s->dMaxSumsq,
                            s->stream));
@@ -2125,6 +2420,17 @@ int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_ro
   }
   return EHX_OK;
 }
+}  // namespace
+
+int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize) {
+  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  if (n_rows == 0) return EHX_OK;
+  std::unique_lock<std::shared_mutex> wl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+  if (s->keyless) return fail(EHX_EINVAL, "a shard is written through its parent space");
+  if (is_parent(s)) return sharded_fill_synthetic(s, seed, row0, n_rows, normalize);
+  return fill_synthetic_locked(s, seed, row0, n_rows, normalize, 1);
+}
 
 int ehx_graph_import(ehx_space* s, uint64_t n, const uint32_t* level0, const int32_t* levels, uint64_t n_upper,
                      const uint32_t* upper_node, const int32_t* upper_level, const uint64_t* upper_off,
@@ -2132,6 +2438,7 @@ int ehx_graph_import(ehx_space* s, uint64_t n, const uint32_t* level0, const int
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   std::unique_lock<std::shared_mutex> wl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+  if (is_parent(s)) return fail(EHX_EUNSUPPORTED, "sharded spaces build their graphs on the GPUs (no import)");
   if (s->params.mode != EHX_MODE_GRAPH) return fail(EHX_EINVAL, "space '%s' is not in graph mode", s->name.c_str());
   if (n != s->n) return fail(EHX_EINVAL, "graph has %llu nodes but the space holds %llu rows", (unsigned long long)n,
                              (unsigned long long)s->n);
@@ -2141,7 +2448,7 @@ int ehx_graph_import(ehx_space* s, uint64_t n, const uint32_t* level0, const int
   if (entry_point >= n || max_level < 0) return fail(EHX_EINVAL, "bad entry point / max level");
   const uint32_t M = s->params.M, M0 = 2 * M;
   if (M0 > 64) return fail(EHX_EUNSUPPORTED, "M=%u: level-0 degree exceeds one wave", M);
-  HIP_TRY(hipSetDevice(engine().device));
+  HIP_TRY(hipSetDevice(s->device));
   // host-side re-layout (pure index shuffling, no vector arithmetic)
   std::vector<uint32_t> adj((size_t)n * M0, 0xFFFFFFFFu), up_start(n, 0xFFFFFFFFu);
   for (uint64_t i = 0; i < n; ++i) {
@@ -2213,6 +2520,7 @@ int ehx_graph_export(ehx_space* s, uint32_t* level0, int32_t* levels, uint32_t* 
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   std::shared_lock<std::shared_mutex> rl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+  if (is_parent(s)) return fail(EHX_EUNSUPPORTED, "graph export works per shard");
   if (s->params.mode != EHX_MODE_GRAPH) return fail(EHX_EINVAL, "space '%s' is not in graph mode", s->name.c_str());
   const uint64_t n = s->g_n;
   const uint32_t M = s->params.M, M0 = 2 * M;
@@ -2220,7 +2528,7 @@ int ehx_graph_export(ehx_space* s, uint32_t* level0, int32_t* levels, uint32_t* 
   if (entry_point) *entry_point = s->g_entry;
   if (max_level) *max_level = s->g_maxlevel;
   if (n == 0) return EHX_OK;
-  HIP_TRY(hipSetDevice(engine().device));
+  HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipDeviceSynchronize());
   if (level0) {
     std::vector<uint32_t> adj(n * M0);
@@ -2248,8 +2556,35 @@ int ehx_graph_export(ehx_space* s, uint32_t* level0, int32_t* levels, uint32_t* 
 int ehx_stats(ehx_space* s, ehx_stats_t* out) {
   if (!valid_space(s) || !out) return fail(EHX_EINVAL, "NULL argument");
   std::shared_lock<std::shared_mutex> rl(s->mu);
-  std::lock_guard<std::mutex> sl(s->scratch_mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+  if (is_parent(s)) {  // the shards' work counters added up; the slowest shard's times (they run concurrently)
+    memset(out, 0, sizeof(*out));
+    for (ehx_space* c : s->shards) {
+      ehx_stats_t t;
+      int rc = ehx_stats(c, &t);
+      if (rc) return rc;
+      out->capacity += t.capacity;
+      out->n_dist += t.n_dist;
+      out->n_hops += t.n_hops;
+      out->n_rerank += t.n_rerank;
+      out->n_uncertified += t.n_uncertified;
+      out->bytes_algorithmic += t.bytes_algorithmic;
+      out->n_filter_queries += t.n_filter_queries;
+      out->n_filter_fallback += t.n_filter_fallback;
+      out->n_exhaustive += t.n_exhaustive;
+      out->n_i8_queries += t.n_i8_queries;
+      out->n_i8_fallback += t.n_i8_fallback;
+      out->last_scan_ms = std::max(out->last_scan_ms, t.last_scan_ms);
+      out->last_total_ms = std::max(out->last_total_ms, t.last_total_ms);
+      out->scan_ms_mean = std::max(out->scan_ms_mean, t.scan_ms_mean);
+      out->scan_launches = std::max(out->scan_launches, t.scan_launches);
+    }
+    out->n_rows = s->n;
+    out->n_queries = s->n_queries;
+    return EHX_OK;
+  }
+  std::lock_guard<std::mutex> sl(s->scratch_mu);
+  HIP_TRY(hipSetDevice(s->device));
   memset(out, 0, sizeof(*out));
   out->n_rows = s->n;
   out->capacity = s->cap;
@@ -2301,11 +2636,21 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
 int ehx_graph_counters(ehx_space* s, uint64_t* out, uint32_t n_out) {
   if (!valid_space(s) || !out) return fail(EHX_EINVAL, "NULL argument");
   if (n_out > kGraphCounters) return fail(EHX_EINVAL, "at most %u counters", kGraphCounters);
+  if (is_parent(s)) {
+    for (uint32_t i = 0; i < n_out; ++i) out[i] = 0;
+    uint64_t t[kGraphCounters];
+    for (ehx_space* c : s->shards) {
+      int rc = ehx_graph_counters(c, t, n_out);
+      if (rc) return rc;
+      for (uint32_t i = 0; i < n_out; ++i) out[i] += t[i];
+    }
+    return EHX_OK;
+  }
   std::lock_guard<std::mutex> sl(s->scratch_mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   unsigned long long g[kGraphCounters] = {};
   if (s->dGraphCounters) {
-    HIP_TRY(hipSetDevice(engine().device));
+    HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemcpy(g, s->dGraphCounters, sizeof(g), hipMemcpyDeviceToHost));
   }
   for (uint32_t i = 0; i < n_out; ++i) out[i] = g[i];
@@ -2314,8 +2659,17 @@ int ehx_graph_counters(ehx_space* s, uint64_t* out, uint32_t n_out) {
 
 int ehx_stats_reset(ehx_space* s) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  if (is_parent(s)) {
+    for (ehx_space* c : s->shards) {
+      int rc = ehx_stats_reset(c);
+      if (rc) return rc;
+    }
+    s->n_queries = 0;
+    return EHX_OK;
+  }
   std::lock_guard<std::mutex> sl(s->scratch_mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+  HIP_TRY(hipSetDevice(s->device));
   s->n_queries = 0;
   s->n_dist = 0;
   s->n_rerank = 0;

@@ -593,9 +593,9 @@ hipError_t launch_store_rows_f16(const float* src, uint32_t src_ld, const uint64
                                  uint32_t dims, uint32_t ld, __half* X, hipStream_t st);
 hipError_t launch_load_row_f16(const __half* X, uint64_t row, uint32_t dims, uint32_t ld, float* out, hipStream_t st);
 
-// EHX-GAUSS-1 rows generated straight into a [*, ld] matrix (optionally L2-normalised)
+// EHX-GAUSS-1 rows row0, row0 + row_stride, ... generated straight into a [*, ld] matrix (optionally L2-normalised)
 hipError_t launch_gen_rows(uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims, uint32_t ld,
-                           int normalize, float* out, hipStream_t st);
+                           int normalize, float* out, hipStream_t st, uint64_t row_stride = 1);
 
 // graph-mode search (k_graph.hip): one wave per query
 constexpr uint32_t kGraphCounters = 12;  // n_dist, n_hops0, n_hops_up, n_prefetch_hit, [4..11] profile builds
@@ -642,10 +642,11 @@ hipError_t launch_update_neigh(const InsertArgs& a, uint32_t n_items, const uint
 hipError_t launch_insert_link(const InsertArgs& a, uint32_t n_items, const uint32_t* tgt, const int32_t* tlevel,
                               const uint32_t* kind, const uint32_t* inc_off, const uint32_t* inc_ids, hipStream_t st);
 
-// k-way merge of per-shard (dist, id) result lists [n_lists][nq][k] -> [nq][k]
+// k-way merge of per-shard (dist, id) result lists [n_lists][nq][k] -> [nq][k]; an id of list l enters as
+// id * id_mul + l * id_step (row-sharded spaces: local row -> global row = local * G + shard)
 hipError_t launch_merge_lists(const uint64_t* ids, const float* dist, const uint32_t* count, uint32_t nq,
                               uint32_t k, uint32_t n_lists, uint64_t* out_ids, float* out_dist,
                               uint32_t* out_count, hipStream_t st, size_t ids_stride, size_t dist_stride,
-                              size_t count_stride);
+                              size_t count_stride, uint64_t id_mul = 1, uint64_t id_step = 0);
 
 }  // namespace ehx

@@ -720,6 +720,7 @@ __global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t* __restr
                                                          const uint32_t* __restrict__ count, uint32_t nq,
                                                          uint32_t k, uint32_t n_lists, size_t ids_stride,
                                                          size_t dist_stride, size_t count_stride,
+                                                         uint64_t id_mul, uint64_t id_step,
                                                          uint64_t* __restrict__ out_ids,
                                                          float* __restrict__ out_dist,
                                                          uint32_t* __restrict__ out_count) {
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t* __restr
     const uint32_t c = count ? ((const uint32_t*)((const char*)count + l * count_stride))[q] : k;
     total += c;
     float d = (lane < (int)k && (uint32_t)lane < c) ? dl[lane] : __builtin_inff();
-    uint64_t i = (lane < (int)k && (uint32_t)lane < c) ? il[lane] : ~0ull;
+    uint64_t i = (lane < (int)k && (uint32_t)lane < c) ? il[lane] * id_mul + (uint64_t)l * id_step : ~0ull;
     // reverse incoming list, elementwise min by (dist, id), bitonic merge on the pair
     const float rd = __shfl(d, 63 - lane, 64);
     const uint64_t ri = __shfl(i, 63 - lane, 64);
@@ -771,9 +772,9 @@ __global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t* __restr
 hipError_t launch_merge_lists(const uint64_t* ids, const float* dist, const uint32_t* count, uint32_t nq,
                               uint32_t k, uint32_t n_lists, uint64_t* out_ids, float* out_dist,
                               uint32_t* out_count, hipStream_t st, size_t ids_stride, size_t dist_stride,
-                              size_t count_stride) {
+                              size_t count_stride, uint64_t id_mul, uint64_t id_step) {
   hipLaunchKernelGGL(merge_lists_kernel, dim3(nq), dim3(64), 0, st, ids, dist, count, nq, k, n_lists, ids_stride,
-                     dist_stride, count_stride, out_ids, out_dist, out_count);
+                     dist_stride, count_stride, id_mul, id_step, out_ids, out_dist, out_count);
   return hipGetLastError();
 }
 

@@ -272,6 +272,9 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0;
 
   uint32_t rp_slot = 0u;  // LDS slot (tile % 3) of the current tile's row parameters
+  // tile parameters of the current tile: a scalar load issued a whole tile before its use (the epilogue must not
+  // wait for a global round trip)
+  float4 tp_cur = a.tilep[tile_begin];
   // =============================== tile epilogue ===============================
   auto epilogue = [&](uint32_t t) {
     const uint32_t tile = tile_begin + t;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       }
       return;
     }
-    const float4 tp = a.tilep[tile];  // uniform: (max|A|, max|C|, max|D|, min B) of the tile's rows
+    const float4 tp = tp_cur;  // uniform: (max|A|, max|C|, max|D|, min B) of the tile's rows (loaded a tile ago)
     const int lev0 = i8_alarm_level(tp, qq0), lev1 = i8_alarm_level(tp, qq1);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
@@ -439,6 +442,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
       qsrc = qbase + 3 * kStageI8;
       rsrc += kTileRows16 * 16;
+      tp_cur = a.tilep[tile_begin + t];  // (past the last tile: the array's padding entries)
       // tile t+1 (counting the new t) goes to the slot tile t-2 used: every wave left that epilogue long ago
       const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 1) % 3 == (t - 2) % 3
       rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;

@@ -479,7 +479,7 @@ hipError_t launch_rowp_pad(float2* rowp, uint64_t row0, uint64_t n, hipStream_t 
 
 // ---- EHX-GAUSS-1 --------------------------------------------------------------------------------
 // pass 1: one thread per 4 columns (one Philox call), coalesced 16-B stores
-__global__ __launch_bounds__(256) void gen_rows_kernel(uint64_t seed, uint64_t row0, uint64_t n_rows,
+__global__ __launch_bounds__(256) void gen_rows_kernel(uint64_t seed, uint64_t row0, uint64_t row_stride, uint64_t n_rows,
                                                        uint32_t dims, uint32_t ld, float* __restrict__ out) {
   const uint32_t cbs = ld / 4;  // ld % 4 == 0
   const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void gen_rows_kernel(uint64_t seed, uint64_t r
   const uint32_t cb = (uint32_t)(gid - r * cbs);
   float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if (cb * 4 < dims) {
-    ehx_datagen::normal4(seed, row0 + r, cb, z);
+    ehx_datagen::normal4(seed, row0 + r * row_stride, cb, z);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (cb * 4 + j >= dims) z[j] = 0.0f;
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(64) void normalize_rows_tiled_kernel(uint64_t n_row
 }
 
 hipError_t launch_gen_rows(uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims, uint32_t ld,
-                           int normalize, float* out, hipStream_t st) {
+                           int normalize, float* out, hipStream_t st, uint64_t row_stride) {
   if (n_rows == 0) return hipSuccess;
   const uint64_t work = n_rows * (ld / 4);
   // grid.x limit: chunk the launch if needed
@@ -553,7 +553,7 @@ hipError_t launch_gen_rows(uint64_t seed, uint64_t row0, uint64_t n_rows, uint32
     if (rows > max_rows) rows = max_rows;
     const uint64_t threads = rows * per_row_blocks_x256;
     hipLaunchKernelGGL(gen_rows_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, st, seed,
-                       row0 + done_rows, rows, dims, ld, out + done_rows * ld);
+                       row0 + done_rows * row_stride, row_stride, rows, dims, ld, out + done_rows * ld);
     done_rows += rows;
   }
   (void)work;

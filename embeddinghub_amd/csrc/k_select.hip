@@ -173,67 +173,114 @@ hipError_t launch_select256(const uint64_t* pool, uint32_t* pool_cnt, uint32_t p
 }
 
 // ---------------------------------------------------------------------------------------------
-// canonical re-rank of the int8 filter's candidates: the kprime best lower bounds of the query (merged[0..kprime))
-// get their distances recomputed in the oracle's order (canon_dist: one 4-lane group per candidate, 64 per round),
-// sorted by (distance, id), top-k emitted.  Certificate: every row that is NOT among them has a lower bound
-// >= the kprime-th kept one (rows the scan never collected were above a threshold that is itself >= it; keys
-// dropped by the merges are above it), so  D_lower(kprime-th) - margin > exact k-th distance  proves the top-k.
+// canonical re-rank of the int8 filter's candidates.  merged[0..kprime) are the query's best lower bounds in
+// ascending order.  They are evaluated in that order, 64 per round (canon_dist: one 4-lane group per candidate,
+// the oracle's summation order), wave 0 keeping the best 64 exact (distance, id) keys so far.  After a round, if
+// the NEXT candidate's lower bound (mapped to a distance, minus the certification margin) already exceeds the exact
+// k-th distance found so far, neither it nor any later candidate nor any row outside the list can enter the top-k:
+// the query is certified and the remaining candidates are never read.  A query that consumes all kprime candidates
+// is certified by the kprime-th bound itself (every row outside the list has a lower bound >= it: rows the scan
+// never collected were above a threshold that is itself >= it; keys dropped by the merges are above it).
 // ---------------------------------------------------------------------------------------------
 template <typename XT>
 __global__ __launch_bounds__(256) void rerank256_kernel(const Rerank256Args a) {
-  __shared__ uint64_t keys[kMerged8];
+  __shared__ uint64_t keys[64];
+  __shared__ int stop_flag;
   const int tid = threadIdx.x;
   const uint32_t q = blockIdx.x;
   const int g = tid >> 2, sub = tid & 3;
   const float* qv = a.Q + (size_t)q * a.ld;
   const bool scale_x = a.metric == 2;
-  for (uint32_t c0 = 0; c0 < kMerged8; c0 += 64) {
+  const uint64_t* mq = a.merged + (size_t)q * kMerged8;
+  const float2 uv = a.quv[q];
+  const float qn = a.metric == 0 ? uv.y : (a.metric == 1 ? uv.x * uv.x : 1.0f);
+  const float maxss = a.max_sumsq ? *a.max_sumsq : __builtin_inff();
+  uint64_t best = kKeyInf;  // wave 0: ascending best-64 exact keys so far (one per lane)
+  bool certified = false;
+  uint32_t evaluated = 0;
+  if (tid == 0) stop_flag = 0;
+  __syncthreads();
+  for (uint32_t c0 = 0; c0 < a.kprime; c0 += 64) {
     const uint32_t ci = c0 + (uint32_t)g;
-    const uint64_t mk = a.merged[(size_t)q * kMerged8 + ci];
+    const uint64_t mk = ci < a.kprime ? mq[ci] : kKeyInf;
     const uint32_t id = (uint32_t)mk;
-    const bool valid = ci < a.kprime && mk != kKeyInf && id < a.n;
+    const bool valid = mk != kKeyInf && id < a.n;
     float d = __builtin_inff();
-    if (c0 < a.kprime) {  // (uniform) rounds beyond kprime hold nothing to evaluate
-      if (valid) {
-        const XT* xv = (const XT*)a.X + (size_t)id * a.ld;
-        const float xs = scale_x ? a.inv_norm[id] : 1.0f;
-        d = canon_dist(a.metric == 0 ? 0 : 1, qv, xv, xs, scale_x, a.dims, sub);
+    if (valid) {
+      const XT* xv = (const XT*)a.X + (size_t)id * a.ld;
+      const float xs = scale_x ? a.inv_norm[id] : 1.0f;
+      d = canon_dist(a.metric == 0 ? 0 : 1, qv, xv, xs, scale_x, a.dims, sub);
+    }
+    // (a NaN distance — a row or query holding NaN — is never a neighbour: the key is dropped)
+    if (sub == 0) keys[g] = (valid && d == d) ? (((uint64_t)f32_to_ordered(d) << 32) | id) : kKeyInf;
+    __syncthreads();
+    if (tid < 64) {
+      uint64_t v = keys[tid];
+      // ascending sort of the round's 64 keys, then merge into the running best 64
+#pragma unroll
+      for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+          const uint64_t other = __shfl_xor(v, j, 64);
+          const bool up = (tid & k2) == 0;
+          const bool lower = (tid & j) == 0;
+          const uint64_t lo = umin64(v, other), hi = umax64(v, other);
+          v = (lower == up) ? lo : hi;
+        }
+      }
+      const uint64_t rv = __shfl(v, 63 - tid, 64);
+      best = umin64(best, rv);
+#pragma unroll
+      for (int j = 32; j > 0; j >>= 1) {
+        const uint64_t other = __shfl_xor(best, j, 64);
+        const uint64_t lo = umin64(best, other), hi = umax64(best, other);
+        best = (tid & j) == 0 ? lo : hi;
+      }
+      evaluated = c0 + 64;
+      // can the next candidate still matter?
+      const uint64_t kk = __shfl(best, a.k > 0 ? (int)a.k - 1 : 0, 64);
+      const uint32_t nxt = c0 + 64;
+      if (a.k > 0 && kk != kKeyInf && nxt < a.kprime) {
+        const uint64_t nk = mq[nxt];
+        if (nk != kKeyInf) {
+          const float kth = ordered_to_f32((uint32_t)(kk >> 32));
+          const float lb = __builtin_fmaf(uv.x, ordered_to_f32((uint32_t)(nk >> 32)), uv.y);
+          const float margin = cert_margin(a.metric, a.dims, qn, maxss, fmaxf(fabsf(kth), fabsf(lb)));
+          if (lb - margin > kth) {
+            certified = true;
+            if (tid == 0) stop_flag = 1;
+          }
+        }
       }
     }
-    if (sub == 0) keys[ci] = (valid && d == d) ? (((uint64_t)f32_to_ordered(d) << 32) | id) : kKeyInf;
+    __syncthreads();
+    if (stop_flag) break;
   }
-  __syncthreads();
   if (tid < 64) {
-    uint64_t k4[kR];
-#pragma unroll
-    for (int r = 0; r < kR; ++r) k4[r] = keys[r * 64 + tid];
-    wave_sort256(k4, tid);
-    const uint64_t key = k4[0];  // the 64 best: k <= EHX_MAX_K < 64
-    uint32_t nvalid = 0;
-#pragma unroll
-    for (int r = 0; r < kR; ++r) nvalid += (uint32_t)__builtin_popcountll(__ballot(k4[r] != kKeyInf));
+    const uint32_t nvalid = (uint32_t)__builtin_popcountll(__ballot(best != kKeyInf));
     const uint32_t cnt = nvalid < a.k ? nvalid : a.k;
     if (tid < (int)a.k) {
       const bool ok = (uint32_t)tid < cnt;
-      a.out_ids[(size_t)q * a.k + tid] = ok ? (uint64_t)(uint32_t)key : ~0ull;
-      a.out_dist[(size_t)q * a.k + tid] = ok ? ordered_to_f32((uint32_t)(key >> 32)) : __builtin_inff();
+      a.out_ids[(size_t)q * a.k + tid] = ok ? (uint64_t)(uint32_t)best : ~0ull;
+      a.out_dist[(size_t)q * a.k + tid] = ok ? ordered_to_f32((uint32_t)(best >> 32)) : __builtin_inff();
     }
     if (tid == 0) a.out_count[q] = cnt;
     bool uncert;
-    const uint64_t last = a.merged[(size_t)q * kMerged8 + a.kprime - 1];  // the kprime-th best lower bound
+    const uint64_t last = mq[a.kprime - 1];  // the kprime-th best lower bound
     if (a.ovf[q]) {
       uncert = true;  // the pool overflowed in some pass: candidates may be missing
-    } else if (a.n <= a.kprime) {
-      uncert = false;  // (not reached: small spaces use the other engines) every row is a candidate
-    } else if (last == kKeyInf || cnt < a.k || a.k == 0) {
-      uncert = true;  // fewer than kprime lower bounds known, or candidates lost (NaN rows / queries)
+    } else if (cnt < a.k || a.k == 0) {
+      uncert = a.n > cnt;  // candidates lost (NaN rows / queries) or fewer rows than k
+    } else if (certified) {
+      uncert = false;
+    } else if (last == kKeyInf) {
+      // fewer than kprime lower bounds exist below the (infinite) last threshold: every row was a candidate
+      // only if nothing overflowed and the list holds all rows
+      uncert = a.n > evaluated;
     } else {
-      const float2 uv = a.quv[q];
       const float worst = __builtin_fmaf(uv.x, ordered_to_f32((uint32_t)(last >> 32)), uv.y);
-      const float qn = a.metric == 0 ? uv.y : (a.metric == 1 ? uv.x * uv.x : 1.0f);
-      const float kth = ordered_to_f32((uint32_t)(__shfl(key, (int)a.k - 1, 64) >> 32));
-      const float margin = cert_margin(a.metric, a.dims, qn, a.max_sumsq ? *a.max_sumsq : __builtin_inff(),
-                                       fmaxf(fabsf(kth), fabsf(worst)));
+      const float kth = ordered_to_f32((uint32_t)(__shfl(best, (int)a.k - 1, 64) >> 32));
+      const float margin = cert_margin(a.metric, a.dims, qn, maxss, fmaxf(fabsf(kth), fabsf(worst)));
       uncert = !(worst - margin > kth);  // (NaN u / v: a query the filter could not bound -> uncertified)
     }
     if (tid == 0) {

@@ -107,7 +107,12 @@ typedef struct ehx_params {
                                filter cannot certify is re-run by the next engine (int8 -> fp16 -> fp32 scan ->
                                exhaustive canonical pass) — results identical to EHX_SCAN_F32 (1) = fp32
                                matrix-core scan only; EHX_SCAN_F16 (2) = start from the fp16 filter.          */
-  uint32_t reserved[6];
+  uint32_t shards;          /* 0 / 1: one shard on ehx_init's first device.  G > 1: the space is ROW-SHARDED inside this
+                               process — row g lives in shard g % G on device_ids[(g % G) % n_devices] of ehx_init;
+                               ehx_set* route by row id, ehx_knn* search every shard concurrently, copy each local
+                               top-k peer-to-peer (xGMI) to shard 0's device and merge there; ids stay the dense
+                               global row ids.  k <= 64; graph import / export are per-shard operations. */
+  uint32_t reserved[5];
 } ehx_params;
 
 /* Work and time counters, same definitions as the oracle. */
@@ -135,8 +140,10 @@ typedef struct ehx_stats_t {
 
 /* ---- process / device ---- */
 
-/* Once per process (idempotent).  device_ids==NULL or n_devices==0 -> device 0.  Only the first
- * listed device is used by a space; multi-GPU sharding is one process per GPU. */
+/* Once per process (idempotent).  device_ids==NULL or n_devices==0 -> device 0.  Unsharded spaces live on the first
+ * listed device; the shards of a space created with ehx_params.shards = G are spread over the whole list (one
+ * process drives all of them: what a Go / C++ caller of this ABI uses on an 8-GPU node).  The one-process-per-GPU
+ * form (torch.distributed + RCCL all-gather, embeddinghub_amd/sharded.py) lists one device per process. */
 int ehx_init(const int* device_ids, int n_devices);
 int ehx_shutdown(void);
 int ehx_abi_version(void);

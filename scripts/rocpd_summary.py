@@ -5,6 +5,7 @@ usage: rocpd_summary.py results.db [more.db ...] > profiles/summary.txt
 Per kernel: calls, total/avg/min/max duration (from the kernel dispatch records), registers and
 LDS as recorded; per (kernel, counter): mean value per dispatch for --pmc runs.
 """
+import os
 import sqlite3
 import sys
 
@@ -49,6 +50,18 @@ def summarize(path):
     if seq:
         print("# last scan-kernel dispatches in launch order (ms): " +
               " ".join("%.3f" % (r[1] / 1e6) for r in seq[-12:]))
+    if os.environ.get("ROCPD_SEQ"):
+        # every dispatch of the tail of the run in launch order: what one batch looks like
+        n = int(os.environ["ROCPD_SEQ"])
+        allseq = c.execute("""
+            select s.kernel_name, d.start, d.end from rocpd_kernel_dispatch d
+            join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start""").fetchall()
+        prev_end = None
+        print("# last %d dispatches in launch order: kernel, duration ms, gap to the previous kernel's end ms" % n)
+        for name, st, en in allseq[-n:]:
+            gap = (st - prev_end) / 1e6 if prev_end is not None else 0.0
+            print("#   %-52s %9.4f  gap %8.4f" % (name.split("(")[0][-52:], (en - st) / 1e6, gap))
+            prev_end = en
     print()
 
 
