@@ -1,0 +1,114 @@
+"""GPU tests of row sharding BEHIND THE C ABI (ehx_params.shards): one process, G shards — on a
+single-GPU box they all live on device 0, which exercises the routing (row g -> shard g % G, local row g / G), the
+concurrent per-shard searches, the gather and the merge exactly as on an 8-GPU node.  A sharded space must be
+indistinguishable from an unsharded one: same ids (global, dense, first-Set order), same distance bytes."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+ehx = pytest.importorskip("embeddinghub_amd")
+
+METRICS = [(ehx.METRIC_L2SQ, pyoracle.METRIC_L2), (ehx.METRIC_IP, pyoracle.METRIC_IP),
+           (ehx.METRIC_COSINE, pyoracle.METRIC_COSINE)]
+
+
+def _keys(n, p="k"):
+    return ["%s%d" % (p, i) for i in range(n)]
+
+
+def _check(space, X, Q, k, ometric):
+    ids, dist, cnt = space.knn(Q, k)
+    oids, odist, ocnt = pyoracle.exhaustive(X, Q, k, ometric)
+    np.testing.assert_array_equal(cnt, ocnt)
+    for i in range(Q.shape[0]):
+        c = int(cnt[i])
+        assert list(ids[i, :c]) == list(oids[i, :c]), "query %d ids differ" % i
+        assert dist[i, :c].tobytes() == odist[i, :c].tobytes(), "query %d distances not bit-exact" % i
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+@pytest.mark.parametrize("em,om", METRICS)
+def test_sharded_space_equals_the_oracle(G, em, om):
+    rng = np.random.default_rng(G)
+    n, d, nq, k = 9001, 96, 70, 10
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    s = ehx.Space.unique("shd", d, metric=em, shards=G)
+    for i0 in range(0, n, 2500):                       # several batches: growth inside every shard
+        s.set_batch(_keys(n)[i0:i0 + 2500], X[i0:i0 + 2500])
+    assert len(s) == n
+    _check(s, X, Q, k, om)
+    # upserts keep their global row id; Get returns exactly what was Set, whatever shard holds the row
+    upd = rng.standard_normal((40, d)).astype(np.float32)
+    s.set_batch(_keys(n)[100:140], upd)
+    X[100:140] = upd
+    assert len(s) == n
+    for i in (0, 99, 100, 139, n - 1):
+        assert s.get("k%d" % i).tobytes() == X[i].tobytes()
+        assert s.key_of(i) == "k%d" % i
+    _check(s, X, Q, k, om)
+    assert s.knn_keys(X[7], 1) == [["k7"]]
+    st = s.stats()
+    assert st["n_rows"] == n and st["n_uncertified"] == 0
+    s.drop()
+
+
+def test_sharded_synthetic_fill_is_the_same_corpus():
+    """ehx_fill_synthetic on a sharded space: global row g is generator row g, so the result equals the unsharded
+    space's and the oracle's over the oracle-generated rows"""
+    n, d, nq, k = 50_000, 768, 64, 10
+    s = ehx.Space.unique("shs", d, metric=ehx.METRIC_COSINE, shards=2, initial_capacity=n)
+    s.fill_synthetic(ehx.SEED_CORPUS, 0, 30_000, True)
+    s.fill_synthetic(ehx.SEED_CORPUS, 30_000, n - 30_000, True)      # a second fill continues the numbering
+    X = pyoracle.gen_rows(ehx.SEED_CORPUS, 0, n, d, normalize=True)
+    Q = pyoracle.gen_rows(ehx.SEED_QUERY, 0, nq, d, normalize=True)
+    _check(s, X, Q, k, pyoracle.METRIC_COSINE)
+    assert s.scan_engine() == "i8"                                   # 25 000 rows per shard: the int8 engine
+    assert s.get_by_id(12345).tobytes() == X[12345].tobytes()
+    s.drop()
+
+
+def test_sharded_device_entry_point_and_graph_mode():
+    import torch
+    rng = np.random.default_rng(4)
+    n, d, nq, k = 6000, 64, 128, 10
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    s = ehx.Space.unique("shdv", d, metric=ehx.METRIC_L2SQ, shards=4)
+    s.set_batch(_keys(n), X)
+    dq = torch.from_numpy(Q).cuda()
+    ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    dst = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    s.knn_device(dq, k, ids, dst, cnt, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    oids, odist, _ = pyoracle.exhaustive(X, Q, k, pyoracle.METRIC_L2)
+    np.testing.assert_array_equal(ids.cpu().numpy().astype(np.uint64), oids)
+    assert dst.cpu().numpy().tobytes() == odist.tobytes()
+    s.drop()
+    # graph mode: every shard builds its own HNSW; with ef >= the shard size the search is exhaustive per shard,
+    # so the merged answer is the exact one
+    g = ehx.Space.unique("shg", d, metric=ehx.METRIC_L2SQ, mode=ehx.MODE_GRAPH, shards=2, ef=800)
+    g.set_batch(_keys(1200), X[:1200])
+    gi, gd, gc = g.knn(Q[:16], k)
+    oi, od, _ = pyoracle.exhaustive(X[:1200], Q[:16], k, pyoracle.METRIC_L2)
+    np.testing.assert_array_equal(gi, oi)
+    assert gd.tobytes() == od.tobytes()
+    g.drop()
+
+
+def test_shards_are_hidden_and_dropped_with_their_parent():
+    s = ehx.Space.unique("shh", 8, shards=2)
+    s.set("a", np.ones(8, dtype=np.float32))
+    with pytest.raises(ehx.EhxError) as e:
+        ehx.Space.open(s.name + "\x010")
+    assert e.value.code == ehx._lib.ENOTFOUND
+    name = s.name
+    s.drop()
+    t = ehx.Space(name, 8, shards=2)      # the name (and the shard names) are free again
+    t.set("b", np.ones(8, dtype=np.float32))
+    assert t.knn_keys(np.ones(8, np.float32), 1) == [["b"]]
+    t.drop()
