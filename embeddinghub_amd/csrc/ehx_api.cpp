@@ -101,6 +101,10 @@ struct ehx_space {
                                // freed memory; reclaimed by ehx_shutdown
   bool implicit_keys = false;  // rows appended by ehx_fill_synthetic: key == decimal row id
   std::shared_mutex mu;        // writers: set/drop/reserve ; readers: knn/get
+  std::mutex wmu;              // every mutator takes wmu first, then mu: writers are serialised among themselves, and
+                               // a batch of fresh keys does its upload / statistics / scan copies holding wmu only —
+                               // the rows land beyond the published row count — and takes mu just to publish
+  hipStream_t wstream = nullptr;  // the writers' stream (uploads, row statistics, derived copies)
   int device = 0;              // HIP device of this space's HBM state
   // Row sharding behind the C ABI (ehx_params.shards > 1): the PARENT keeps the key maps and no rows; global row g
   // lives in shard g % G at local row g / G (streamed Sets stay balanced); the shards are ordinary
@@ -213,6 +217,20 @@ struct ehx_space {
   std::vector<KnnReq*> bq;
   bool bq_leader = false;
   std::atomic<uint64_t> n_coalesced_batches{0}, n_coalesced_queries{0};
+  // write-combiner: concurrent single-row ehx_set calls (runner/copy.go: 500 goroutines per chunk) become one batch
+  struct SetReq {
+    const char* key;
+    size_t klen;
+    const float* vec;
+    int rc = 0;
+    bool done = false;
+    char err[256] = "";
+  };
+  std::mutex wq_mu;
+  std::condition_variable wq_cv;
+  std::vector<SetReq*> wq;
+  bool wq_leader = false;
+  std::atomic<uint64_t> n_combined_sets{0}, n_combined_batches{0};
 
   // stats
   std::atomic<uint64_t> n_queries{0}, n_dist{0}, n_rerank{0}, bytes_algo{0};
@@ -294,6 +312,8 @@ struct ehx_space {
       }
     if (stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
+    if (wstream) (void)hipStreamDestroy(wstream);
+    wstream = nullptr;
     cap = 0;
     n = 0;
     g_n = 0;
@@ -1101,6 +1121,11 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
     const long v = g ? atol(g) : 4;
     return (uint32_t)(v < 2 ? 2 : (v > 64 ? 64 : v));
   }();
+  static const double safety = [] {
+    const char* g = getenv("EHX_I8_SAFETY");
+    const double v = g ? atof(g) : 4.0;
+    return v < 1.0 ? 1.0 : v;
+  }();
   static const bool use_sync = [] {
     const char* g = getenv("EHX_I8_SYNC");
     return g ? atoi(g) != 0 : false;  // measured r02: the lock-step costs ~9 % of the scan time at 10 M x 768
@@ -1120,9 +1145,13 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
     uint32_t tile0;
     ScanPlan plan;
   };
+  // First pass: up to 512 tiles (131 072 rows) under a threshold taken from the sample at a LOW rank, chosen so that
+  // the pass collects ~1000 keys per query (any threshold is sound, see sample_select256_kernel); then x4 in rows per
+  // pass under the 256th best so far.
+  constexpr uint32_t kFirstTiles = 512;
   std::vector<Pass> passes;
   {
-    uint32_t done = 0, cum = 4 * kSampleTiles;
+    uint32_t done = 0, cum = kFirstTiles;
     while ((uint64_t)cum * 2 < n_tiles) {
       passes.push_back({done, plan_scan((uint32_t)nq, cum - done, k, E.n_cus)});
       done = cum;
@@ -1130,6 +1159,9 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
     }
     passes.push_back({done, plan_scan((uint32_t)nq, n_tiles - done, k, E.n_cus)});
   }
+  const uint64_t first_rows = (uint64_t)passes.front().plan.n_tiles * kTileRows16;
+  const uint32_t sample_rank =
+      (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, 1024ull * kSampleTiles * kTileRows16 / first_rows));
   const ScanPlan p = passes.back().plan;  // (q_tiles, q_rows are the same for every pass)
   uint32_t grid_max = 0, chunks_max = 0;
   for (auto& ps : passes) {
@@ -1194,7 +1226,7 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
     a.sync = nullptr;
     HIP_TRY(scan(sp, 0));
     a.dump = nullptr;
-    HIP_TRY(launch_sample_select256(s->dSample8.p, kSampleTiles * kTileRows16, p.q_rows, (uint32_t)nq, kprime,
+    HIP_TRY(launch_sample_select256(s->dSample8.p, kSampleTiles * kTileRows16, p.q_rows, (uint32_t)nq, sample_rank,
                                     s->dThr8.p, st));
   }
   for (size_t i = 0; i < passes.size(); ++i) {
@@ -1210,8 +1242,17 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
       HIP_TRY(hipEventRecord(s->ev[2], st));
       s->ring_count++;
     }
-    HIP_TRY(launch_select256(s->dPool.p, pool_cnt, kPoolCap, (uint32_t)nq, kprime, s->dMerged8.p, i > 0, s->dThr8.p,
-                             st));
+    // The next pass's threshold: the 256th best so far is always valid; while only a fraction f of the rows has been
+    // seen, the final 256th best is expected near rank 256 f of the prefix, so rank 256 f x safety (>= 16) is a
+    // much tighter threshold that is still above it — fewer keys collected, fewer epilogue alarms in the middle
+    // passes.  Sound whatever happens (the certificate uses the smallest threshold ever applied, qparams.w).
+    uint32_t rank = kprime;
+    if (!last) {
+      const double f = (double)((uint64_t)(passes[i + 1].tile0) * kTileRows16) / (double)s->n;
+      rank = (uint32_t)std::min<double>(kprime, std::max<double>(16.0, std::ceil(kprime * f * safety)));
+    }
+    HIP_TRY(launch_select256(s->dPool.p, pool_cnt, kPoolCap, (uint32_t)nq, rank, s->dMerged8.p, i > 0, s->dThr8.p,
+                             s->dQp8.p, st));
   }
   Rerank256Args r;
   r.Q = s->dQ.p;
@@ -1221,6 +1262,7 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   r.merged = s->dMerged8.p;
   r.ovf = ovf;
   r.quv = s->dQuv.p;
+  r.qparams = s->dQp8.p;
   r.max_sumsq = s->dMaxSumsq;
   r.out_ids = d_ids;
   r.out_dist = d_dist;
@@ -1551,6 +1593,7 @@ int sharded_set_batch(ehx_space* p, size_t n, const char* const* keys, const siz
   int rc = for_each_shard(p, [&](size_t i) -> int {
     if (lids[i].empty()) return EHX_OK;
     ehx_space* c = p->shards[i];
+    std::lock_guard<std::mutex> cg(c->wmu);
     std::unique_lock<std::shared_mutex> wl(c->mu);
     const uint64_t next_local = (next + G - 1 - i) / G;  // globals below `next` that belong to shard i
     return write_rows_locked_fwd(c, lids[i].size(), lids[i], next_local, rows[i].data());
@@ -1573,6 +1616,7 @@ int sharded_fill_synthetic(ehx_space* p, uint64_t seed, uint64_t row0, uint64_t 
     if (g0 >= n0 + n_rows) return EHX_OK;
     const uint64_t cnt = (n0 + n_rows - 1 - g0) / G + 1;
     ehx_space* c = p->shards[i];
+    std::lock_guard<std::mutex> cg(c->wmu);
     std::unique_lock<std::shared_mutex> wl(c->mu);
     return fill_synthetic_locked(c, seed, row0 + (g0 - n0), cnt, normalize, G);
   });
@@ -1756,6 +1800,7 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
     }
   }
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&s->wstream, hipStreamNonBlocking));
   if (!parent) {
     HIP_TRY(hipMalloc((void**)&s->dMaxSumsq, sizeof(float)));
     HIP_TRY(hipMemset(s->dMaxSumsq, 0, sizeof(float)));
@@ -1843,6 +1888,7 @@ int ehx_space_drop(ehx_space* s) {
     E.spaces.erase(it);  // the name is free again; late users of the handle see the tombstone below
   }
   {
+    std::lock_guard<std::mutex> wg(s->wmu);  // (a streaming writer may be uploading without holding mu)
     // Wait for every in-flight user (readers hold mu shared, writers exclusive), then release the HBM.  The host
     // object is NOT freed: threads that fetched the handle before the drop, or are parked on its mutexes /
     // condition variable, find `dropped` set and return EHX_ENOTFOUND.
@@ -1865,6 +1911,7 @@ int ehx_space_drop(ehx_space* s) {
 
 int ehx_space_freeze(ehx_space* s) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  std::lock_guard<std::mutex> wg(s->wmu);
   std::unique_lock<std::shared_mutex> wl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   s->frozen = true;
@@ -1891,6 +1938,7 @@ int ehx_space_dims(ehx_space* s, uint32_t* dims) {
 
 int ehx_space_reserve(ehx_space* s, uint64_t rows) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  std::lock_guard<std::mutex> wg(s->wmu);
   std::unique_lock<std::shared_mutex> wl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   if (is_parent(s)) {
@@ -1947,11 +1995,33 @@ int ehx_space_scan_engine(ehx_space* s, uint32_t* engine) {
 }
 
 static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, const size_t* klens, const float* vecs);
+static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>& ids, uint64_t next, const float* vecs,
+                             std::vector<std::string>* new_keys, bool append_only = false);
+static bool all_fresh_keys(const ehx_space* s, size_t n, const std::vector<uint64_t>& ids);
 
 int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t* klens, const float* vecs) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   if (n == 0) return EHX_OK;
   if (!keys || !klens || !vecs) return fail(EHX_EINVAL, "NULL argument");
+  std::lock_guard<std::mutex> wg(s->wmu);
+  if (!is_parent(s) && s->params.mode == EHX_MODE_FLAT) {
+    // Streaming fast path (copy.go's BatchSet chunks, MultiSet): a batch made only of fresh keys is a pure append.
+    // The key lookup needs the lock shared only, and the upload runs with no lock on the space at all.
+    std::vector<uint64_t> ids;
+    std::vector<std::string> new_keys;
+    uint64_t next = 0;
+    bool fast = false;
+    {
+      std::shared_lock<std::shared_mutex> rl(s->mu);
+      if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+      if (s->keyless) return fail(EHX_EINVAL, "a shard is written through its parent space");
+      if (!s->frozen && !s->implicit_keys) {
+        resolve_keys(s, n, keys, klens, &ids, &next, &new_keys);
+        fast = new_keys.size() == n && all_fresh_keys(s, n, ids);
+      }
+    }
+    if (fast) return write_rows_locked(s, n, ids, next, vecs, &new_keys, true);
+  }
   std::unique_lock<std::shared_mutex> wl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   if (s->keyless) return fail(EHX_EINVAL, "a shard is written through its parent space");
@@ -1982,29 +2052,28 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
 
 // (re)build the derived copies of rows [row0, row0+n) after they were written; must follow row_stats:
 // graph mode: the search copy; flat fp32 spaces: the fp16 scan copy
-static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n) {
+static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n, hipStream_t st = nullptr) {
+  if (!st) st = s->stream;
   if (s->dXs && n)
-    HIP_TRY(launch_make_search_copy(s->xf32(), s->dInv, row0, n, s->ld, s->metric, s->dXs, s->stream));
+    HIP_TRY(launch_make_search_copy(s->xf32(), s->dInv, row0, n, s->ld, s->metric, s->dXs, st));
   if ((!s->has16 && !s->has8) || n == 0) return EHX_OK;  // (kept current whatever engine is selected right now)
   unsigned long long u = 0, u8 = 0;
   if (s->has16) {
     HIP_TRY(launch_make_scan16(s->dX, s->x_half, row0, n, s->dims, s->ld, s->ld16, s->metric, s->dX16, s->dRowp16,
-                               s->dUnsafe, s->stream));
-    HIP_TRY(hipMemcpyAsync(&u, s->dUnsafe, sizeof(u), hipMemcpyDeviceToHost, s->stream));
+                               s->dUnsafe, st));
+    HIP_TRY(hipMemcpyAsync(&u, s->dUnsafe, sizeof(u), hipMemcpyDeviceToHost, st));
   }
   if (s->has8) {
     HIP_TRY(launch_make_scan8(s->dX, s->x_half, row0, n, s->dims, s->ld, s->ld8, s->metric, s->dX8, s->dRowp8,
-                              s->dTilep8, s->dUnsafe8, s->stream));
-    HIP_TRY(hipMemcpyAsync(&u8, s->dUnsafe8, sizeof(u8), hipMemcpyDeviceToHost, s->stream));
+                              s->dTilep8, s->dUnsafe8, st));
+    HIP_TRY(hipMemcpyAsync(&u8, s->dUnsafe8, sizeof(u8), hipMemcpyDeviceToHost, st));
   }
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipStreamSynchronize(st));
   s->h_unsafe = u;
   s->h_unsafe8 = u8;
   return EHX_OK;
 }
 
-static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>& ids, uint64_t next, const float* vecs,
-                             std::vector<std::string>* new_keys);
 
 static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, const size_t* klens, const float* vecs) {
   if (s->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
@@ -2016,15 +2085,35 @@ static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, con
   return write_rows_locked(s, n, ids, next, vecs, &new_keys);
 }
 
+// every key of the batch is new and distinct: the rows are a pure append
+static bool all_fresh_keys(const ehx_space* s, size_t n, const std::vector<uint64_t>& ids) {
+  for (size_t i = 0; i < n; ++i)
+    if (ids[i] != s->n + i) return false;
+  return true;
+}
+
 // rows `vecs[i]` -> row ids[i] of the space (ids < next; ids >= s->n are appended, dense), then statistics, derived
-// copies, graph; finally publishes the keys (new_keys, in id order from s->n) and the new row count `next`
+// copies, graph; finally publishes the keys (new_keys, in id order from s->n) and the new row count `next`.
+//   append_only = false: the caller holds s->mu exclusively (rows may be rewritten in place, graphs change).
+//   append_only = true : flat spaces, every id >= s->n.  The caller holds s->wmu only: searches keep running while
+//     the rows are uploaded, described and copied BEYOND the published row count (every kernel masks rows >= n),
+//     on the writers' stream; s->mu is taken exclusively just to grow the arrays (rare) and to publish.
 static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>& ids, uint64_t next, const float* vecs,
-                             std::vector<std::string>* new_keys) {
+                             std::vector<std::string>* new_keys, bool append_only) {
   if (s->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
   HIP_TRY(hipSetDevice(s->device));
-  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev[3], 0));  // in-flight device searches
+  hipStream_t ws = s->wstream ? s->wstream : s->stream;
+  // rows rewritten in place: in-flight device searches (enqueued without the lock being held any more) finish first
+  if (!append_only && s->ev_valid) HIP_TRY(hipStreamWaitEvent(ws, s->ev[3], 0));
   const uint64_t old_n = s->n;
-  int rc = ensure_rows(s, next);
+  int rc;
+  if (append_only && next >= s->cap) {
+    std::unique_lock<std::shared_mutex> gl(s->mu);  // the arrays move: no search may be running
+    if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+    rc = ensure_rows(s, next);
+  } else {
+    rc = ensure_rows(s, next);
+  }
   if (rc) return rc;
   // upload through pinned staging in slabs; rows may be non-contiguous (updates) so copy per row
   // (fp16 spaces: rows are rounded to binary16, round-to-nearest-even, while they are staged)
@@ -2048,13 +2137,13 @@ static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>
       if (ids[i0 + i] != ids[i0] + i) { contiguous = false; break; }
     if (contiguous) {
       HIP_TRY(hipMemcpy2DAsync(s->xrow(ids[i0]), (size_t)s->ld * s->esz, stage, row_bytes,
-                               row_bytes, m, hipMemcpyHostToDevice, s->stream));
+                               row_bytes, m, hipMemcpyHostToDevice, ws));
     } else {
       for (size_t i = 0; i < m; ++i)
         HIP_TRY(hipMemcpyAsync(s->xrow(ids[i0 + i]), stage + i * row_bytes, row_bytes,
-                               hipMemcpyHostToDevice, s->stream));
+                               hipMemcpyHostToDevice, ws));
     }
-    HIP_TRY(hipStreamSynchronize(s->stream));  // staging buffer is reused
+    HIP_TRY(hipStreamSynchronize(ws));  // staging buffer is reused
     for (size_t i = 0; i < m; ++i) {
       min_id = std::min(min_id, ids[i0 + i]);
       max_id = std::max(max_id, ids[i0 + i]);
@@ -2062,15 +2151,22 @@ static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>
   }
   // per-row statistics over the touched id range (idempotent for untouched rows in between)
   HIP_TRY(launch_row_stats(s->dX, s->x_half, min_id, max_id - min_id + 1, s->dims, s->ld, s->metric, s->dInv,
-                           s->dRowp, s->dMaxSumsq, s->stream));
-  if ((rc = refresh_scan16(s, min_id, max_id - min_id + 1))) return rc;
-  HIP_TRY(hipStreamSynchronize(s->stream));
+                           s->dRowp, s->dMaxSumsq, ws));
+  if ((rc = refresh_scan16(s, min_id, max_id - min_id + 1, ws))) return rc;
+  HIP_TRY(hipStreamSynchronize(ws));
   // commit: the rows are resident and described — publish the keys and the new row count
-  if (new_keys) {
-    for (size_t i = 0; i < new_keys->size(); ++i) s->key_to_id.emplace((*new_keys)[i], old_n + i);
-    for (auto& k : *new_keys) s->id_to_key.push_back(std::move(k));
+  {
+    std::unique_lock<std::shared_mutex> pl(s->mu, std::defer_lock);
+    if (append_only) {
+      pl.lock();
+      if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+    }
+    if (new_keys) {
+      for (size_t i = 0; i < new_keys->size(); ++i) s->key_to_id.emplace((*new_keys)[i], old_n + i);
+      for (auto& k : *new_keys) s->id_to_key.push_back(std::move(k));
+    }
+    s->n = next;
   }
-  s->n = next;
   if (s->params.mode == EHX_MODE_GRAPH) {
     // new rows join the graph one at a time, in id order (ANNIndex::set -> addPoint, index.cc:36);
     // rows overwritten in place keep their links (hnswlib's updatePoint repair is not built yet)
@@ -2103,11 +2199,68 @@ int write_rows_locked_fwd(ehx_space* s, size_t n, const std::vector<uint64_t>& i
 }
 }  // namespace
 
+// Single-row Sets (the reference's usage: one Set per RPC / per goroutine, runner/copy.go:146-161 runs 500 at a time)
+// are combined like the single-query searches are: the first caller becomes the leader, takes every request that
+// queued up meanwhile (up to 4096) and writes them as ONE batch; under load the batch size grows by itself.  A call
+// returns after its row is published, so a following ehx_knn from the same thread sees it (index_test.cc:39-49).
+constexpr size_t kCombineMaxBatch = 4096;
+
 int ehx_set(ehx_space* s, const char* key, size_t klen, const float* vec) {
-  const char* keys[1] = {key};
-  size_t klens[1] = {klen};
-  if (!key) return fail(EHX_EINVAL, "key is NULL");
-  return ehx_set_batch(s, 1, keys, klens, vec);
+  if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  if (!key || !vec) return fail(EHX_EINVAL, "key / vector is NULL");
+  ehx_space::SetReq me;
+  me.key = key;
+  me.klen = klen;
+  me.vec = vec;
+  std::unique_lock<std::mutex> lk(s->wq_mu);
+  s->wq.push_back(&me);
+  std::vector<ehx_space::SetReq*> group;
+  std::vector<const char*> ks;
+  std::vector<size_t> kl;
+  std::vector<float> rows;
+  while (!me.done) {
+    if (s->wq_leader) {
+      s->wq_cv.wait(lk, [&] { return me.done || !s->wq_leader; });
+      continue;
+    }
+    s->wq_leader = true;
+    while (!me.done && !s->wq.empty()) {
+      const size_t m = std::min(s->wq.size(), kCombineMaxBatch);
+      group.assign(s->wq.begin(), s->wq.begin() + m);
+      s->wq.erase(s->wq.begin(), s->wq.begin() + m);
+      lk.unlock();
+      int rc;
+      if (m == 1) {
+        const char* k1[1] = {group[0]->key};
+        size_t l1[1] = {group[0]->klen};
+        rc = ehx_set_batch(s, 1, k1, l1, group[0]->vec);
+      } else {
+        ks.resize(m);
+        kl.resize(m);
+        rows.resize(m * s->dims);
+        for (size_t i = 0; i < m; ++i) {
+          ks[i] = group[i]->key;
+          kl[i] = group[i]->klen;
+          memcpy(rows.data() + i * s->dims, group[i]->vec, s->dims * sizeof(float));
+        }
+        rc = ehx_set_batch(s, m, ks.data(), kl.data(), rows.data());
+        s->n_combined_batches += 1;
+        s->n_combined_sets += m;
+      }
+      lk.lock();
+      for (auto* r : group) {
+        r->rc = rc;
+        if (rc) snprintf(r->err, sizeof(r->err), "%s", g_err);
+        r->done = true;
+      }
+      s->wq_cv.notify_all();
+    }
+    s->wq_leader = false;
+    s->wq_cv.notify_all();
+  }
+  lk.unlock();
+  if (me.rc) snprintf(g_err, sizeof(g_err), "%s", me.err);
+  return me.rc;
 }
 
 int ehx_get_by_id(ehx_space* s, uint64_t id, float* out_vec) {
@@ -2425,6 +2578,7 @@ int fill_synthetic_locked(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n
 int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   if (n_rows == 0) return EHX_OK;
+  std::lock_guard<std::mutex> wg(s->wmu);
   std::unique_lock<std::shared_mutex> wl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   if (s->keyless) return fail(EHX_EINVAL, "a shard is written through its parent space");
@@ -2436,6 +2590,7 @@ int ehx_graph_import(ehx_space* s, uint64_t n, const uint32_t* level0, const int
                      const uint32_t* upper_node, const int32_t* upper_level, const uint64_t* upper_off,
                      const uint32_t* upper_ids, uint32_t entry_point, int32_t max_level) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
+  std::lock_guard<std::mutex> wg(s->wmu);
   std::unique_lock<std::shared_mutex> wl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   if (is_parent(s)) return fail(EHX_EUNSUPPORTED, "sharded spaces build their graphs on the GPUs (no import)");

@@ -447,7 +447,7 @@ struct ScanArgsI8 {
   const int8_t* X;        // scan copy, scan8_index layout; cap % 256 == 0
   const float4* rowp;     // [cap + 512] (A, B, C, D) per row; padding rows (0, +inf, 0, 0)
   const float4* tilep;    // [cap/256 + 2] (max|A|, max|C|, max|D|, min B) per 256-row tile
-  const float4* qparams;  // [q_tiles*256] (s_q, e_q, gamma_q, -)
+  const float4* qparams;  // [q_tiles*256] (s_q, e_q, gamma_q, smallest threshold the query was scanned with so far)
   const float* thr;       // [q_tiles*256] score threshold of this pass per query (-inf: padding query)
   float* dump = nullptr;  // sample pass: every lower bound -> dump[row - tile0*256][q_tiles*256]
   uint64_t* cand;         // [grid][512][64] staging slots
@@ -492,13 +492,14 @@ hipError_t launch_tilep8_pad(float4* tilep8, uint64_t t0, uint64_t n, hipStream_
 // int8 query tiles + (s_q, e_q, gamma_q) + (u, v) with D = u*S + v; thr[q] = +inf for q < nq, -inf for padding
 hipError_t launch_prep_queries8(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld8, uint32_t q_rows,
                                 int metric, int8_t* Q8, float4* qparams, float2* quv, float* thr, hipStream_t st);
-// sample pass -> first thresholds: thr[q] = the kprime-th smallest of scores[0..n_rows)[q] (+inf if fewer)
+// sample pass -> first thresholds: thr[q] = the rank-th (<= 64) smallest of scores[0..n_rows)[q] (+inf if fewer)
 hipError_t launch_sample_select256(const float* scores, uint32_t n_rows, uint32_t q_rows, uint32_t nq,
-                                   uint32_t kprime, float* thr, hipStream_t st);
+                                   uint32_t rank, float* thr, hipStream_t st);
 // merge one pass's pool into the query's running best kMerged8 keys (seed: keep what `merged` holds); publishes
-// thr[q] = score of the kprime-th best (+inf while fewer are known) and empties the pool (pool_cnt = 0)
+// thr[q] = score of the kprime-th best (+inf while fewer are known), lowers qparams[q].w to the threshold the merged
+// pass was scanned with, and empties the pool (pool_cnt = 0)
 hipError_t launch_select256(const uint64_t* pool, uint32_t* pool_cnt, uint32_t pool_cap, uint32_t nq, uint32_t kprime,
-                            uint64_t* merged, bool seed, float* thr, hipStream_t st);
+                            uint64_t* merged, bool seed, float* thr, float4* qparams, hipStream_t st);
 struct Rerank256Args {
   const float* Q;          // prepared (canonical) queries [*][ld]
   const void* X;
@@ -507,6 +508,7 @@ struct Rerank256Args {
   const uint64_t* merged;  // [nq][kMerged8] keys (S_lower, id), ascending
   const uint32_t* ovf;     // [nq] pool overflow flags
   const float2* quv;       // [nq] D = u*S + v
+  const float4* qparams;   // [nq] .w = the smallest threshold the query was scanned with (select256_kernel)
   const float* max_sumsq;
   uint64_t* out_ids;
   float* out_dist;

@@ -14,7 +14,16 @@ namespace {
 template <typename XT>
 __device__ __forceinline__ float seq_sumsq(const XT* __restrict__ x, uint32_t dims) {
   float s = 0.0f;
-  for (uint32_t i = 0; i < dims; ++i) {
+  uint32_t i = 0;
+  // eight loads in flight ahead of the (strictly sequential) adds: the ORDER of the sum is unchanged
+  for (; i + 8 <= dims; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ld_row(x, i + j);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s = ex_add(s, ex_mul(v[j], v[j]));
+  }
+  for (; i < dims; ++i) {
     const float v = ld_row(x, i);
     s = ex_add(s, ex_mul(v, v));
   }
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(64) void prep_queries8_kernel(const float* __restri
   if (row >= nq) {
     for (uint32_t c = lane; c < ld8; c += 64) put(c, 0);
     if (lane == 0) {
-      qparams[row] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+      qparams[row] = make_float4(0.0f, 0.0f, 1.0f, __builtin_inff());
       quv[row] = make_float2(1.0f, 0.0f);
       thr[row] = -__builtin_inff();  // a padding query never collects anything
     }
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(64) void prep_queries8_kernel(const float* __restri
       }
     }
     if (!ok) u = __builtin_nanf("");
-    qparams[row] = make_float4(s, i8_err_up(e2), g, 0.0f);
+    qparams[row] = make_float4(s, i8_err_up(e2), g, __builtin_inff());  // .w: smallest threshold used so far
     quv[row] = make_float2(u, v);
     thr[row] = __builtin_inff();
   }

@@ -22,6 +22,7 @@ import "C"
 import (
 	"encoding/json"
 	"fmt"
+	"runtime"
 	"unsafe"
 
 	"github.com/featureform/fferr"
@@ -32,7 +33,8 @@ import (
 
 // MI355XConfig is the JSON blob carried in metadata (cf. pc.RedisConfig, redis_config.go:18-39).
 type MI355XConfig struct {
-	Devices []int  `json:"devices"` // HIP device ids; this process uses Devices[0]
+	Devices []int  `json:"devices"` // HIP device ids (ehx_init): unsharded tables live on Devices[0]
+	Shards  uint32 `json:"shards"`  // > 1: every table is row-sharded over Devices inside this process (ehx_params.shards)
 	Metric  string `json:"metric"`  // "cosine" (default, as redis.go:253 / pinecone.go:251), "l2", "ip"
 	Mode    string `json:"mode"`    // "flat" (exact, default) | "graph"
 	EF      uint32 `json:"ef"`
@@ -44,6 +46,13 @@ type MI355XConfig struct {
 type mi355xOnlineStore struct {
 	cfg MI355XConfig
 	BaseProvider
+}
+
+// ehx_last_error() is a THREAD-LOCAL string and a goroutine may change OS threads between two cgo calls: every method
+// that reports an engine error pins its goroutine for the duration of the failing call and the read of its message.
+func pinned() func() {
+	runtime.LockOSThread()
+	return runtime.UnlockOSThread
 }
 
 func mi355xOnlineStoreFactory(serialized pc.SerializedConfig) (Provider, error) {
@@ -59,6 +68,7 @@ func mi355xOnlineStoreFactory(serialized pc.SerializedConfig) (Provider, error) 
 	if len(devs) > 0 {
 		dev = &devs[0]
 	}
+	defer pinned()()
 	if rc := C.ehx_init(dev, C.int(len(devs))); rc != C.EHX_OK {
 		return nil, fferr.NewConnectionError(string(pt.MI355XOnline), fmt.Errorf("%s", C.GoString(C.ehx_last_error())))
 	}
@@ -100,7 +110,9 @@ func (s *mi355xOnlineStore) create(feature, variant string, dims int32) (*mi355x
 	name := spaceName(feature, variant)
 	cname := C.CString(name)
 	defer C.free(unsafe.Pointer(cname))
+	defer pinned()()
 	var p C.ehx_params
+	p.shards = C.uint32_t(s.cfg.Shards)
 	if s.cfg.Mode == "graph" {
 		p.mode = C.EHX_MODE_GRAPH
 	}
@@ -167,12 +179,15 @@ func (t *mi355xTable) fail() error {
 		fmt.Errorf("%s", C.GoString(C.ehx_last_error())))
 }
 
-// OnlineStoreTable.Set (online.go:51): called from 500 goroutines per chunk (runner/copy.go:34).
+// OnlineStoreTable.Set (online.go:51): called from 500 goroutines per chunk (runner/copy.go:34); the engine combines
+// concurrent single-row Sets into batches (write-combiner in ehx_set; integration/c/set_hammer.c is the C mirror of
+// this call pattern and runs in the GPU test suite).
 func (t *mi355xTable) Set(entity string, value interface{}) error {
 	vec, ok := value.([]float32)
 	if !ok || len(vec) != t.dims {
 		return fferr.NewDataTypeNotFoundErrorf(value, "expected []float32 of length %d", t.dims) // redis.go:408-413
 	}
+	defer pinned()()
 	ckey := C.CString(entity)
 	defer C.free(unsafe.Pointer(ckey))
 	if rc := C.ehx_set(t.sp, ckey, C.size_t(len(entity)), (*C.float)(unsafe.Pointer(&vec[0]))); rc != C.EHX_OK {
@@ -188,6 +203,7 @@ func (t *mi355xTable) BatchSet(items []SetItem) error {
 	if n == 0 {
 		return nil
 	}
+	defer pinned()()
 	flat := make([]float32, 0, n*t.dims)
 	keys := make([]*C.char, n)
 	lens := make([]C.size_t, n)
@@ -215,6 +231,7 @@ func (t *mi355xTable) BatchSet(items []SetItem) error {
 
 // OnlineStoreTable.Get (online.go:52): returns exactly what was Set (vectorstore_test.go:107-113).
 func (t *mi355xTable) Get(entity string) (interface{}, error) {
+	defer pinned()()
 	out := make([]float32, t.dims)
 	ckey := C.CString(entity)
 	defer C.free(unsafe.Pointer(ckey))
@@ -234,6 +251,7 @@ func (t *mi355xTable) Nearest(feature, variant string, vector []float32, k int32
 	if len(vector) != t.dims || k <= 0 {
 		return nil, fferr.NewInvalidArgumentError(fmt.Errorf("expected a %d-dim vector and k > 0", t.dims))
 	}
+	defer pinned()()
 	ids := make([]C.uint64_t, k)
 	dist := make([]C.float, k)
 	off := make([]C.uint64_t, k+1)

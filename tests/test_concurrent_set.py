@@ -1,0 +1,183 @@
+"""GPU tests of the write path under concurrency (the reference's contract is
+runner/copy.go:29-34,146-161 — 500 concurrent Sets per chunk — and serving reads running all the while):
+
+ * streamed appends (batches of fresh keys) upload, get their statistics and scan copies WITHOUT the space's lock
+   and only publish under it: searches keep running, never see a half-written row, and see a row as soon as the
+   Set that wrote it has returned;
+ * concurrent single-row Sets are combined into batches (write-combiner) and stay linearizable per thread;
+ * the C program integration/c/set_hammer.c drives the C ABI from 500 OS threads (no Python in that process).
+"""
+import os
+import subprocess
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+ehx = pytest.importorskip("embeddinghub_amd")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _row(i, d):
+    """row i of the stream: cheap to recompute anywhere, unit norm, every row its own nearest neighbour"""
+    r = np.random.default_rng(1000 + i)
+    v = r.standard_normal(d).astype(np.float32)
+    v[i % d] += np.float32(40.0)
+    return v / np.linalg.norm(v)
+
+
+def test_streamed_appends_run_beside_searches_and_never_tear():
+    d, base, chunk, n_chunks, k = 256, 40_000, 2048, 12, 5
+    total = base + chunk * n_chunks
+    X = np.stack([_row(i, d) for i in range(total)])
+    keys = ["k%d" % i for i in range(total)]
+    s = ehx.Space.unique("stream", d, metric=ehx.METRIC_COSINE, initial_capacity=total)
+    s.set_batch(keys[:base], X[:base])
+    published = [base]          # rows whose Set has RETURNED (the writer bumps it after each call)
+    errs, searches = [], [0]
+    stop = threading.Event()
+
+    def writer():
+        try:
+            for c in range(n_chunks):
+                i0 = base + c * chunk
+                s.set_batch(keys[i0:i0 + chunk], X[i0:i0 + chunk])
+                published[0] = i0 + chunk
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+        finally:
+            stop.set()
+
+    def reader(seed):
+        r = np.random.default_rng(seed)
+        try:
+            while not stop.is_set():
+                lo = published[0]                       # every row below lo is published before this search starts
+                probe = np.concatenate([r.integers(0, lo, 24), r.integers(max(base, lo - chunk), lo, 8)])
+                ids, dist, cnt = s.knn(X[probe], k)
+                searches[0] += 1
+                n_after = len(s)
+                for j, p in enumerate(probe):
+                    assert cnt[j] == k
+                    assert ids[j, 0] == p, "row %d (published) not found first: %r" % (p, ids[j])
+                    assert dist[j, 0] < 1e-5
+                    assert (ids[j] < n_after).all(), "a result names a row that was never published"
+                    # every returned row is complete: Get returns exactly what was Set
+                    g = s.get_by_id(int(ids[j, 1]))
+                    assert g.tobytes() == X[int(ids[j, 1])].tobytes(), "row %d read back torn" % ids[j, 1]
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+            stop.set()
+
+    ths = [threading.Thread(target=writer)] + [threading.Thread(target=reader, args=(7 + i,)) for i in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+        assert not t.is_alive(), "a thread hung"
+    assert not errs, errs
+    assert searches[0] >= 3, "the searches did not overlap the stream (%d ran)" % searches[0]
+    assert len(s) == total
+    # the final state is the oracle's
+    Q = X[np.random.default_rng(5).integers(0, total, 64)] + np.float32(1e-3)
+    ids, dist, cnt = s.knn(Q, 10)
+    oids, odist, _ = pyoracle.exhaustive(X, Q, 10, pyoracle.METRIC_COSINE)
+    np.testing.assert_array_equal(ids, oids)
+    assert dist.tobytes() == odist.tobytes()
+    s.drop()
+
+
+def test_search_throughput_beside_a_stream_of_sets():
+    """the point of the lock-free append: searching while a writer streams must keep most of its idle rate"""
+    import torch
+    d, base, chunk, B, k = 768, 200_000, 8192, 1024, 10
+    rng = np.random.default_rng(2)
+    s = ehx.Space.unique("thr", d, metric=ehx.METRIC_COSINE, initial_capacity=base + 40 * chunk)
+    for i0 in range(0, base, 50_000):
+        x = rng.standard_normal((50_000, d)).astype(np.float32)
+        s.set_batch(["b%d" % i for i in range(i0, i0 + 50_000)], x)
+    q = torch.from_numpy(rng.standard_normal((B, d)).astype(np.float32)).cuda()
+    ids = torch.empty((B, k), dtype=torch.int64, device="cuda")
+    dst = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    cnt = torch.empty((B,), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def search_rate(seconds, stop=None):
+        n, t0 = 0, time.perf_counter()
+        while (time.perf_counter() - t0 < seconds) if stop is None else not stop.is_set():
+            s.knn_device(q, k, ids, dst, cnt, stream=st)
+            torch.cuda.synchronize()
+            n += 1
+        return n * B / (time.perf_counter() - t0)
+    search_rate(0.3)
+    alone = search_rate(1.0)
+    rows = rng.standard_normal((20 * chunk, d)).astype(np.float32)
+    keys = ["c%d" % i for i in range(rows.shape[0])]
+    stop = threading.Event()
+    wt = [0.0]
+
+    def writer():
+        t0 = time.perf_counter()
+        for i0 in range(0, rows.shape[0], chunk):
+            s.set_batch(keys[i0:i0 + chunk], rows[i0:i0 + chunk])
+        wt[0] = time.perf_counter() - t0
+        stop.set()
+    th = threading.Thread(target=writer)
+    th.start()
+    beside = search_rate(0, stop)
+    th.join()
+    set_rate = rows.shape[0] / wt[0]
+    print("search alone %.0f q/s, beside the stream %.0f q/s (%.0f %%), Set %.0f rows/s" % (
+        alone, beside, 100 * beside / alone, set_rate))
+    assert len(s) == base + rows.shape[0]
+    assert beside >= 0.5 * alone, "searches starve beside a stream of Sets: %.0f vs %.0f q/s" % (beside, alone)
+    s.drop()
+
+
+def test_write_combiner_keeps_single_sets_linearizable():
+    d, n_threads, per = 48, 48, 40
+    s = ehx.Space.unique("comb", d, metric=ehx.METRIC_L2SQ)
+    errs = []
+
+    def worker(t):
+        r = np.random.default_rng(t)
+        try:
+            for i in range(per):
+                v = r.standard_normal(d).astype(np.float32) + np.float32(100.0 * t)
+                s.set("t%d-%d" % (t, i), v)
+                # linearizable per thread: the row is visible to the very next search of this thread
+                assert s.knn_keys(v, 1) == [["t%d-%d" % (t, i)]]
+                if i % 5 == 0:
+                    s.set("shared", v)          # upsert of one contested key: goes through the locked path
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+        assert not t.is_alive()
+    assert not errs, errs[:3]
+    assert len(s) == n_threads * per + 1
+    for t in (0, 17, n_threads - 1):
+        r = np.random.default_rng(t)
+        for i in range(per):
+            v = r.standard_normal(d).astype(np.float32) + np.float32(100.0 * t)
+            assert s.get("t%d-%d" % (t, i)).tobytes() == v.tobytes()
+    s.drop()
+
+
+def test_c_abi_from_500_threads(tmp_path):
+    """integration/c/set_hammer.c: 500 pthreads inside ehx_set / ehx_knn_keys at once, no Python in the process"""
+    exe = tmp_path / "set_hammer"
+    subprocess.check_call(["gcc", "-O2", "-pthread", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "integration", "c", "set_hammer.c"), "-o", str(exe), "-ldl"])
+    p = subprocess.run([str(exe), ehx._lib.LIB_PATH], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    assert "set_hammer ok" in p.stdout
