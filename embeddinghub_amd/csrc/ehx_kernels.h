@@ -609,7 +609,9 @@ struct GraphArgs {
   const uint32_t* adj0;     // [n][M0], pad 0xFFFFFFFF, stored order
   const uint32_t* up_start; // [n]: first upper list of the node (levels 1..L consecutive) or ~0
   const uint32_t* up_lists; // [*][M], pad 0xFFFFFFFF
-  uint32_t* visited;        // [nq][vis_words], zeroed before the launch
+  uint32_t* visited;        // [nq][vis_words], all-zero before the launch and again after it
+  uint32_t* vislog;         // [nq][vislog_cap] rows a query marked (it clears their words when done)
+  uint32_t vislog_cap;
   uint64_t* out_ids;        // [nq][k]
   float* out_dist;
   uint32_t* out_count;

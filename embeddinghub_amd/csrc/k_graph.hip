@@ -23,7 +23,10 @@
 //     (oracle-order) arithmetic, so on an imported graph the traversal, the returned ids and the
 //     distances are bit-identical to the oracle;
 //   * visited set: one bit per row per in-flight query in HBM (n/8 bytes per query — 1.25 MB at 10 M
-//     rows, 1.3 GB for a 1024-query batch out of 288 GB), test-and-set with atomicOr;
+//     rows, 1.3 GB for a 1024-query batch out of 288 GB), test-and-set with atomicOr.  The bitmap is all-zero
+//     between launches: a query logs every row it marks (vislog, 48 ef + 256 entries) and clears exactly those
+//     words when it is done — a few thousand stores instead of a 1.3-GB memset per batch (a query that outgrows
+//     its log clears its whole bitmap instead);
 //   * work counters as SURVEY §8d: n_dist = rows actually fetched, n_hops0 / n_hops_up = expansions.
 #include "ehx_kernels.h"
 
@@ -119,6 +122,8 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   uint32_t* ids_l = (uint32_t*)(batch + 64);
   uint8_t* F = (uint8_t*)(ids_l + 64);
   uint32_t* vis = a.visited + (size_t)qi * a.vis_words;
+  uint32_t* vlog = a.vislog + (size_t)qi * a.vislog_cap;
+  uint32_t n_logged = 0;  // rows marked visited so far (wave-uniform)
   for (uint32_t i = lane; i < a.ef_cap; i += 64) F[i] = 0;
 
 #if EHX_G_COOP
@@ -229,7 +234,9 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   if (lane == 0) {
     R[0] = ((uint64_t)f32_to_ordered(curdist) << 32) | ((uint64_t)cur << 1);
     atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+    if (a.vislog_cap) vlog[0] = cur;
   }
+  n_logged = 1;
   __syncthreads();
   uint32_t scan_from = 0;  // every entry of R before this index is expanded
   uint32_t pf_node = kNoNode, pf_nb = kNoNode, pf_word = 0;
@@ -294,7 +301,12 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     if (c2 != kNoNode && lane < (int)a.M0) pf_nb = load_here(a.adj0 + (size_t)c2 * a.M0 + lane);
     const uint64_t fmask = __ballot(fresh);
     const uint32_t nfresh = __builtin_popcountll(fmask);
-    if (fresh) ids_l[__builtin_popcountll(fmask & ((1ull << lane) - 1ull))] = nb;
+    if (fresh) {
+      const uint32_t slot = (uint32_t)__builtin_popcountll(fmask & ((1ull << lane) - 1ull));
+      ids_l[slot] = nb;
+      if (n_logged + slot < a.vislog_cap) vlog[n_logged + slot] = nb;
+    }
+    n_logged += nfresh;
     __syncthreads();
     n_dist += nfresh;
     EHX_PROF(1)
@@ -408,6 +420,14 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     EHX_PROF(7)
   }
 
+  // ---- leave the visited bitmap all-zero: clear the words of the logged rows (or everything, if the log overflowed)
+  if (a.vislog_cap == 0) {
+    // (A/B mode: the host clears the bitmaps with a memset before every launch)
+  } else if (n_logged <= a.vislog_cap) {
+    for (uint32_t i = lane; i < n_logged; i += 64) vis[vlog[i] >> 5] = 0u;
+  } else {
+    for (uint32_t i = lane; i < a.vis_words; i += 64) vis[i] = 0u;
+  }
   // ---- results: the k closest of R (already sorted by (dist, id)) ----
   const uint32_t cnt = nR < a.k ? nR : a.k;
   for (uint32_t j = lane; j < a.k; j += 64) {

@@ -85,6 +85,22 @@ class Space:
         lens = (C.c_size_t * len(ks))(*[len(k) for k in ks])
         check(self._L.ehx_set_batch(self._h, len(ks), arr, lens, pv))
 
+    def prepare_batch(self, keys, vecs):
+        """Marshal a batch once (key arrays, contiguous fp32 rows) so that set_prepared() is ONE C call with no Python
+        work in front of it — what a cgo / C++ caller's BatchSet looks like; used by the concurrency measurements,
+        where a Python writer thread would otherwise hold the GIL for milliseconds per chunk."""
+        v, pv = _f32(vecs)
+        v = v.reshape(-1, self.dims)
+        ks = [k.encode() if isinstance(k, str) else bytes(k) for k in keys]
+        if len(ks) != v.shape[0]:
+            raise ValueError("keys/vecs length mismatch")
+        arr = (C.c_char_p * len(ks))(*ks)
+        lens = (C.c_size_t * len(ks))(*[len(k) for k in ks])
+        return (len(ks), arr, lens, pv, v, ks)
+
+    def set_prepared(self, prep):
+        check(self._L.ehx_set_batch(self._h, prep[0], prep[1], prep[2], prep[3]))
+
     def graph_import(self, level0, levels, upper, entry_point, max_level):
         """Attach an HNSW graph over the rows already Set (graph mode).
 

@@ -35,9 +35,12 @@ static ehx_space* g_space;
 static int g_failures;
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 
-static void fill(float* v, int tid, int i) { /* deterministic, distinct, not normalised */
-  for (int c = 0; c < DIMS; ++c) v[c] = (float)((tid * 31 + i * 7 + c * 13) % 97) - 48.0f + 0.001f * (float)tid;
-  v[(tid + i) % DIMS] += 500.0f; /* a dominant coordinate: every row is its own nearest neighbour by far */
+static void fill(float* v, int tid, int i) { /* deterministic pseudo-random direction per (tid, i) */
+  uint32_t x = (uint32_t)(tid * 7919 + i * 104729 + 12345);
+  for (int c = 0; c < DIMS; ++c) {
+    x = x * 1664525u + 1013904223u; /* LCG */
+    v[c] = (float)((x >> 8) & 0xFFFF) / 32768.0f - 1.0f;
+  }
 }
 
 static void fail_msg(const char* what, int rc) {
