@@ -388,10 +388,8 @@ struct ScanArgs {
   uint32_t xcd_map;      // 1: blocks of one chunk share an XCD (grid % 8 == 0, n_chunks % 8 == 0)
 };
 
-size_t scan_lds_bytes();
-uint32_t scan_lists_per_chunk();  // sorted key lists each (query, chunk) publishes: 1 (4-wave kernel) or 2 (8-wave)
-hipError_t launch_flat_scan(const ScanArgs& a, hipStream_t st);   // dispatches on EHX_SCAN_VARIANT (default 8)
-hipError_t launch_flat_scan4(const ScanArgs& a, hipStream_t st);  // k_flat.hip: 4 waves, one per SIMD
+uint32_t scan_lists_per_chunk();  // sorted key lists each (query, chunk) publishes: 2 (one per wave row)
+hipError_t launch_flat_scan(const ScanArgs& a, hipStream_t st);   // the fp32 matrix-core scan
 hipError_t launch_flat_scan8(const ScanArgs& a, hipStream_t st);  // k_flat8.hip: 8 waves, two per SIMD
 
 // ---- fp16-MFMA filter scan (k_flat16.hip) ----

@@ -1,33 +1,13 @@
-// Exhaustive ("flat") kNN on the gfx950 matrix cores.
-//
-// Replaces, for the brute-force configuration, the distance loop the reference runs inside
-// hnswlib (searchKnn -> fstdistfunc_, call site embeddinghub/embeddingstore/index.cc:41): the
-// B x N query-by-row distance matrix is a dense contraction, so it runs on
-// v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain) and is never materialised: each
-// 128(rows) x 256(queries) tile is filtered in registers against per-query running thresholds and
-// only the survivors reach a per-query candidate list.  A canonical re-rank (rerank_kernel below)
-// then recomputes the surviving distances in exactly the oracle's (hnswlib SSE) summation order,
-// so ids and distances are bit-identical to the exhaustive oracle.
-//
-// Layout / mapping (gfx950, wave64):
-//   * workgroup = 256 threads = 4 waves, one per SIMD, 1 workgroup per CU; wave (wr, wc) =
-//     (w>>1, w&1) owns 64 rows x 128 queries = 2x4 MFMA 32x32 blocks = 128 accumulator registers
-//     (AGPRs), leaving the whole architectural VGPR file to fragments and the epilogue.  fp32 MFMA
-//     issues every 64 cycles with 64-cycle dependent latency, so 8 independent accumulators from
-//     one wave keep the SIMD's matrix pipe saturated;
-//   * MFMA A = corpus rows, B = queries, so a lane's 16 accumulator values of one block all belong
-//     to ONE query (col = lane&31) -> one threshold per block;
-//   * both operand tiles ([128|256][32] fp32) are staged by global_load_lds (16 B/lane, no VGPR
-//     round trip) into a double buffer; the 16-B chunk index of a row is XOR-swizzled with
-//     (row>>1)&7 on the SOURCE address and on the ds_read_b128 side (LDS image stays lane-linear),
-//     which makes the fragment reads bank-conflict free;
-//   * a lane's ds_read_b128 gives 4 consecutive k for its (row, k-half); MFMA step t of a group
-//     uses component t of both operands, i.e. the k order is permuted identically for A and B;
-//   * grid = q_tiles x n_chunks persistent workgroups; each walks a contiguous range of row tiles
-//     for one query tile, keeping per-query state (count, threshold key) in LDS and the 64
-//     candidate slots per query in a per-block global scratch (L2 resident).  With grid % 8 == 0
-//     the q_tiles blocks that stream the same rows are placed on the same XCD so the rows are
-//     fetched from HBM once and hit in that XCD's L2 for the other query tiles.
+// Flat (exhaustive) kNN: what surrounds the scan kernels (k_flati8.hip, k_flat16.hip, k_flat8.hip) —
+//   flat_merge_kernel     per-chunk sorted key lists -> the query's running best 64
+//   sample_select_kernel  first thresholds of the fp16 filter's cascade
+//   rerank_kernel         canonical (oracle-order) fp32 distances of the candidates, top-k, certificate
+//   exhaustive_kernel     the canonical distance of EVERY row (last engine of the chain; paged k > 48)
+//   merge_lists_kernel    k-way merge of per-shard results (multi-GPU)
+// The scan replaces, for the brute-force configuration, the distance loop the reference runs inside hnswlib
+// (searchKnn -> fstdistfunc_, call site embeddinghub/embeddingstore/index.cc:41); the re-rank recomputes the
+// surviving distances in exactly the oracle's (hnswlib SSE) summation order, so ids and distances are
+// bit-identical to the exhaustive oracle.
 #include <cstdlib>
 
 #include "ehx_kernels.h"
@@ -38,23 +18,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-
-constexpr int kThreads = 256;
-constexpr uint32_t kXStage = kTileRows * kBK * 4;                  // 16 KiB
-constexpr uint32_t kQStage = kTileQ * kBK * 4;                     // 32 KiB
-constexpr uint32_t kXOff = 0;                                      // Xs[2]
-constexpr uint32_t kQOff = 2 * kXStage;                            // Qs[2]
-constexpr uint32_t kThrKeyOff = kQOff + 2 * kQStage;               // u64 thr_key[256]
-constexpr uint32_t kThrFOff = kThrKeyOff + 256 * 8;                // f32 thr_f[256]
-constexpr uint32_t kCntOff = kThrFOff + 256 * 4;                   // i32 cnt[256]
-constexpr uint32_t kFlagOff = kCntOff + 256 * 4;                   // i32 flags[4]
-constexpr uint32_t kLdsBytes = kFlagOff + 16;
-static_assert(kTileRows == 128 && kTileQ == 256 && kBK == 32, "kernel geometry is hard-wired");
-
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_uniform) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
-}
 
 // ascending bitonic sort of one u64 per lane across the 64-lane wave
 __device__ __forceinline__ uint64_t wave_sort64(uint64_t key, int lane) {
@@ -85,380 +48,12 @@ __device__ __forceinline__ uint64_t wave_bitonic_merge64(uint64_t key, int lane)
   return key;
 }
 
-#define EHX_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
-
 }  // namespace
 
-size_t scan_lds_bytes() { return kLdsBytes; }
+// the fp32 scan publishes two sorted key lists per (query, chunk): one per wave row of the 8-wave kernel (k_flat8.hip)
+uint32_t scan_lists_per_chunk() { return 2u; }
 
-__global__ __launch_bounds__(kThreads, 1) void flat_scan_kernel(const ScanArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 1, wc = w & 1;
-  const int h = lane >> 5, i31 = lane & 31;
-
-  // ---- block -> (query tile, chunk) ----
-  uint32_t qt, chunk;
-  {
-    const uint32_t b = blockIdx.x;
-    if (a.xcd_map) {
-      const uint32_t xcd = b & 7u, slot = b >> 3;
-      qt = slot % a.q_tiles;
-      chunk = xcd * (a.n_chunks >> 3) + slot / a.q_tiles;
-    } else {
-      qt = b % a.q_tiles;
-      chunk = b / a.q_tiles;
-    }
-  }
-  uint64_t* thr_key = (uint64_t*)(smem + kThrKeyOff);
-  float* thr_f = (float*)(smem + kThrFOff);
-  int* cnt = (int*)(smem + kCntOff);
-  int* flags = (int*)(smem + kFlagOff);
-  uint64_t* cand = a.cand + (size_t)blockIdx.x * (256u * kCandSlots);
-
-  thr_key[tid] = kKeyInf;
-  thr_f[tid] = __builtin_inff();
-  cnt[tid] = 0;
-  if (tid < 4) flags[tid] = 0;
-
-  const uint32_t tile_begin = a.tile0 + chunk * a.tiles_per_chunk;
-  uint32_t tile_end = tile_begin + a.tiles_per_chunk;
-  if (tile_end > a.tile0 + a.n_tiles) tile_end = a.tile0 + a.n_tiles;
-  const uint32_t my_tiles = tile_end > tile_begin ? tile_end - tile_begin : 0u;
-  const uint32_t ktiles = a.ld / kBK;
-  const uint32_t total_steps = my_tiles * ktiles;
-
-  // ---- per-lane constants for the staging loads ----
-  // One global_load_lds instruction moves 8 tile rows x 128 B: lane L -> row ins*8+(L>>3), physical
-  // 16-B chunk p = L&7, logical chunk c = p ^ ((row>>1)&7).  Per stage a wave issues 4 X
-  // instructions (ins = w*4+u) and 8 Q instructions (ins = w*8+u).
-  const float* Qtile = a.Q + (size_t)qt * kTileQ * a.ld;
-  uint32_t stx_off[4], stq_off[8];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const uint32_t row = ((uint32_t)w * 4 + u) * 8 + (lane >> 3);
-    stx_off[u] = row * a.ld + (((lane & 7) ^ ((row >> 1) & 7)) * 4);
-  }
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const uint32_t row = ((uint32_t)w * 8 + u) * 8 + (lane >> 3);
-    stq_off[u] = row * a.ld + (((lane & 7) ^ ((row >> 1) & 7)) * 4);
-  }
-
-  // ---- per-lane constants for the fragment reads ----
-  // row r = base + i31 ; chunk for group j = (2j+h) ^ ((r>>1)&7) = (2j) ^ hs, hs = h ^ ((i31>>1)&7)
-  const uint32_t hs = (uint32_t)h ^ ((uint32_t)(i31 >> 1) & 7u);
-  uint32_t joff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) joff[j] = (((uint32_t)(2 * j)) ^ hs) * 16;
-  const uint32_t a_row_off = (uint32_t)(wr * 64 + i31) * 128;   // + rb*4096
-  const uint32_t b_row_off = (uint32_t)(wc * 128 + i31) * 128;  // + cb*4096
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
-
-  // ---- software-pipelined main loop -------------------------------------------------------
-  // A stage (one BK=32 slice of both operand tiles) is consumed as 4 groups of 32 MFMAs; the
-  // fragments of group g+1 are read from LDS into the idle register set while group g's MFMAs
-  // issue, and the single workgroup barrier per stage plus the staging loads of stage s+2 sit
-  // inside stage s's last group, so the matrix pipe does not wait for LDS latency or DMA issue.
-  f32x4 fa0[2], fb0[4], fa1[2], fb1[4];
-
-#define EHX_GROUP(A, B, An, Bn, XS, QS)                                   \
-  do {                                                                    \
-    An[0] = *(const f32x4*)((XS));                                        \
-    An[1] = *(const f32x4*)((XS) + 4096);                                 \
-    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                   \
-      acc[0][cb] = EHX_MFMA(A[0][0], B[cb][0], acc[0][cb]);               \
-      acc[1][cb] = EHX_MFMA(A[1][0], B[cb][0], acc[1][cb]);               \
-    }                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                    \
-    Bn[0] = *(const f32x4*)((QS));                                        \
-    Bn[1] = *(const f32x4*)((QS) + 4096);                                 \
-    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                   \
-      acc[0][cb] = EHX_MFMA(A[0][1], B[cb][1], acc[0][cb]);               \
-      acc[1][cb] = EHX_MFMA(A[1][1], B[cb][1], acc[1][cb]);               \
-    }                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                    \
-    Bn[2] = *(const f32x4*)((QS) + 2 * 4096);                             \
-    Bn[3] = *(const f32x4*)((QS) + 3 * 4096);                             \
-    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                   \
-      acc[0][cb] = EHX_MFMA(A[0][2], B[cb][2], acc[0][cb]);               \
-      acc[1][cb] = EHX_MFMA(A[1][2], B[cb][2], acc[1][cb]);               \
-    }                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                    \
-    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                   \
-      acc[0][cb] = EHX_MFMA(A[0][3], B[cb][3], acc[0][cb]);               \
-      acc[1][cb] = EHX_MFMA(A[1][3], B[cb][3], acc[1][cb]);               \
-    }                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                    \
-  } while (0)
-
-  if (total_steps > 0) {
-    {  // stage 0 -> buffer 0
-      const float* Xt = (const float*)a.X + (size_t)tile_begin * kTileRows * a.ld;
-      char* gxs = smem + kXOff + (uint32_t)w * 4096;
-      char* gqs = smem + kQOff + (uint32_t)w * 8192;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) glds16(Xt + stx_off[u], gxs + u * 1024);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) glds16(Qtile + stq_off[u], gqs + u * 1024);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    fa0[0] = *(const f32x4*)(smem + kXOff + a_row_off + joff[0]);
-    fa0[1] = *(const f32x4*)(smem + kXOff + a_row_off + 4096 + joff[0]);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) fb0[c] = *(const f32x4*)(smem + kQOff + b_row_off + c * 4096 + joff[0]);
-    if (total_steps > 1) {  // stage 1 -> buffer 1
-      const uint32_t nt = 1u / ktiles, nkt = 1u - nt * ktiles;
-      const float* Xt = (const float*)a.X + (size_t)(tile_begin + nt) * kTileRows * a.ld + nkt * kBK;
-      const float* Qt = Qtile + nkt * kBK;
-      char* gxs = smem + kXOff + kXStage + (uint32_t)w * 4096;
-      char* gqs = smem + kQOff + kQStage + (uint32_t)w * 8192;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) glds16(Xt + stx_off[u], gxs + u * 1024);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) glds16(Qt + stq_off[u], gqs + u * 1024);
-    }
-  }
-
-  uint32_t kt = 0, t = 0;
-  for (uint32_t step = 0; step < total_steps; ++step) {
-    const uint32_t buf = step & 1;
-    const char* xs = smem + kXOff + buf * kXStage + a_row_off;
-    const char* qs = smem + kQOff + buf * kQStage + b_row_off;
-    const char* xn = smem + kXOff + (buf ^ 1) * kXStage + a_row_off;
-    const char* qn = smem + kQOff + (buf ^ 1) * kQStage + b_row_off;
-    EHX_GROUP(fa0, fb0, fa1, fb1, xs + joff[1], qs + joff[1]);
-    EHX_GROUP(fa1, fb1, fa0, fb0, xs + joff[2], qs + joff[2]);
-    EHX_GROUP(fa0, fb0, fa1, fb1, xs + joff[3], qs + joff[3]);
-    // ---- last group of the stage (fragments in set 1) with the hand-over inside ----
-    const bool has_next = step + 1 < total_steps;
-    const bool has_next2 = step + 2 < total_steps;
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-      acc[0][cb] = EHX_MFMA(fa1[0][0], fb1[cb][0], acc[0][cb]);
-      acc[1][cb] = EHX_MFMA(fa1[1][0], fb1[cb][0], acc[1][cb]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // stage s+1 has landed (issued a whole stage ago) and every wave has finished reading stage s
-    // (its last fragments were fetched during group 2): one barrier, then refill buffer `buf`.
-    if (has_next) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      fa0[0] = *(const f32x4*)(xn + joff[0]);
-      fa0[1] = *(const f32x4*)(xn + 4096 + joff[0]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) fb0[c] = *(const f32x4*)(qn + c * 4096 + joff[0]);
-    }
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-      acc[0][cb] = EHX_MFMA(fa1[0][1], fb1[cb][1], acc[0][cb]);
-      acc[1][cb] = EHX_MFMA(fa1[1][1], fb1[cb][1], acc[1][cb]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const uint32_t nstep = step + 2;
-    const uint32_t nt = has_next2 ? nstep / ktiles : 0u;
-    const uint32_t nkt = has_next2 ? nstep - nt * ktiles : 0u;
-    const float* Xt = (const float*)a.X + (size_t)(tile_begin + nt) * kTileRows * a.ld + nkt * kBK;
-    const float* Qt = Qtile + nkt * kBK;
-    char* gxs = smem + kXOff + buf * kXStage + (uint32_t)w * 4096;
-    char* gqs = smem + kQOff + buf * kQStage + (uint32_t)w * 8192;
-    if (has_next2) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) glds16(Xt + stx_off[u], gxs + u * 1024);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) glds16(Qt + stq_off[u], gqs + u * 1024);
-    }
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-      acc[0][cb] = EHX_MFMA(fa1[0][2], fb1[cb][2], acc[0][cb]);
-      acc[1][cb] = EHX_MFMA(fa1[1][2], fb1[cb][2], acc[1][cb]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (has_next2) {
-#pragma unroll
-      for (int u = 2; u < 4; ++u) glds16(Xt + stx_off[u], gxs + u * 1024);
-#pragma unroll
-      for (int u = 4; u < 8; ++u) glds16(Qt + stq_off[u], gqs + u * 1024);
-    }
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-      acc[0][cb] = EHX_MFMA(fa1[0][3], fb1[cb][3], acc[0][cb]);
-      acc[1][cb] = EHX_MFMA(fa1[1][3], fb1[cb][3], acc[1][cb]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    if (++kt == ktiles) {
-      kt = 0;
-      // ================= tile epilogue: threshold filter + candidate append =================
-      // Phase 1 (branch-free, fully unrolled): approximate distance s = dot*a_row + b_row of every
-      // accumulator, recorded only as one bit "s <= threshold of its query" (4 words x 32 bits per
-      // lane; word = rb*2 + (cb>>1), bit = (cb&1)*16 + reg).  The accumulators are left untouched.
-      // Phase 2 (rare, loops): only lanes with set bits extract the dot product with a select
-      // chain, recompute s with the same fma, and append (score,id) keys to the candidate slots.
-      const uint32_t tile_row0 = (tile_begin + t) * kTileRows;
-      const int qbase = wc * 128 + i31;
-      uint32_t pend[4] = {0u, 0u, 0u, 0u};
-      {
-        float thrf[4];
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) thrf[cb] = thr_f[qbase + cb * 32];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const uint32_t r = (uint32_t)(wr * 64 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
-            const float2 ab = a.rowp[tile_row0 + r];
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-              const float sc = __builtin_fmaf(acc[rb][cb][reg], ab.x, ab.y);
-              pend[rb * 2 + (cb >> 1)] |= (sc <= thrf[cb]) ? (1u << ((cb & 1) * 16 + reg)) : 0u;
-            }
-          }
-        }
-      }
-      const bool lane_any = (pend[0] | pend[1] | pend[2] | pend[3]) != 0u;
-      // block-uniform decision (LDS flag) so every wave takes the same barrier path
-      if (lane_any) flags[1] = 1;
-      __syncthreads();
-      const int tile_hot = flags[1];
-      __syncthreads();
-      if (tile_hot) {
-        if (tid == 0) flags[1] = 0;
-        // kprime < kCandSlots guarantees progress (a compacted list has free slots); the round
-        // bound only turns a logic error into an error code instead of a hung GPU
-        for (int round = 0;; ++round) {
-#pragma unroll
-          for (int wd = 0; wd < 4; ++wd) {
-            const int rb = wd >> 1, cp = wd & 1;
-            uint32_t retry = 0u;
-            while (__any(pend[wd] != 0u)) {
-              if (pend[wd] != 0u) {
-                const int b = __builtin_ctz(pend[wd]);
-                pend[wd] &= pend[wd] - 1u;
-                float dot = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) dot = (b == i) ? acc[rb][2 * cp][i] : dot;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) dot = (b == 16 + i) ? acc[rb][2 * cp + 1][i] : dot;
-                const int reg = b & 15;
-                const int cb = 2 * cp + (b >> 4);
-                const uint32_t r = (uint32_t)(wr * 64 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
-                const uint32_t grow = tile_row0 + r;
-                const float2 ab = a.rowp[grow];
-                const float sc = __builtin_fmaf(dot, ab.x, ab.y);
-                const int q = qbase + cb * 32;
-                const uint64_t key = ((uint64_t)f32_to_ordered(sc) << 32) | grow;
-                if (grow < a.n && key < thr_key[q]) {
-                  const int pos = atomicAdd(&cnt[q], 1);
-                  if (pos < (int)kCandSlots) {
-                    cand[q * kCandSlots + pos] = key;
-                  } else {
-                    flags[0] = 1;
-                    retry |= 1u << b;
-                  }
-                }
-              }
-            }
-            pend[wd] = retry;
-          }
-          __syncthreads();
-          // ---- compaction: wave w owns queries w*64 .. w*64+63 ----
-          const int overflow = flags[0];
-          const int trigger = (int)a.kprime + ((int)kCandSlots - (int)a.kprime) / 2;
-          {
-            const int c = cnt[w * 64 + lane];
-            const bool need = c >= trigger || (overflow && c > (int)kCandSlots);
-            uint64_t mask = __ballot(need);
-            while (mask) {
-              const int qq = __builtin_ctzll(mask);
-              mask &= mask - 1;
-              const int q = w * 64 + qq;
-              const int cq = cnt[q];
-              const int nv = cq < (int)kCandSlots ? cq : (int)kCandSlots;
-              uint64_t key = lane < nv ? cand[q * kCandSlots + lane] : kKeyInf;
-              key = wave_sort64(key, lane);
-              if (lane < (int)a.kprime) cand[q * kCandSlots + lane] = key;
-              const uint64_t kth = __shfl(key, (int)a.kprime - 1, 64);
-              if (lane == 0) {
-                cnt[q] = nv < (int)a.kprime ? nv : (int)a.kprime;
-                if (nv >= (int)a.kprime) {
-                  thr_key[q] = kth;
-                  thr_f[q] = ordered_to_f32((uint32_t)(kth >> 32));
-                }
-              }
-            }
-          }
-          __syncthreads();
-          if (!overflow) break;
-          if (round >= 512) {
-            if (tid == 0) atomicAdd(a.err, 1u);
-            break;
-          }
-          if (tid == 0) flags[0] = 0;
-          __syncthreads();
-        }
-      }
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
-      ++t;
-    }
-  }
-#undef EHX_GROUP
-
-  // ---- final: sort every query's slots and publish the top-k' keys of this chunk ----
-  __syncthreads();
-  for (int qq = 0; qq < 64; ++qq) {
-    const int q = w * 64 + qq;
-    const int cq = cnt[q];
-    const int nv = cq < (int)kCandSlots ? cq : (int)kCandSlots;
-    uint64_t key = lane < nv ? cand[q * kCandSlots + lane] : kKeyInf;
-    key = wave_sort64(key, lane);
-    if (lane < (int)a.kprime)
-      a.part[((size_t)(qt * kTileQ + q) * a.lists_total + a.list0 + chunk) * a.kprime + lane] = key;
-  }
-}
-
-static int scan_variant() {
-  static const int variant = [] {
-    const char* v = getenv("EHX_SCAN_VARIANT");
-    return v ? atoi(v) : 8;
-  }();
-  return variant;
-}
-uint32_t scan_lists_per_chunk() { return scan_variant() == 4 ? 1u : 2u; }
-
-hipError_t launch_flat_scan(const ScanArgs& a, hipStream_t st) {
-  const int variant = scan_variant();
-  if (variant == 4 && a.x_half) return hipErrorInvalidValue;  // the 4-wave A/B variant scans fp32 rows only
-  return variant == 4 ? launch_flat_scan4(a, st) : launch_flat_scan8(a, st);
-}
-
-hipError_t launch_flat_scan4(const ScanArgs& a, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)flat_scan_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  const uint32_t grid = a.q_tiles * a.n_chunks;
-  hipLaunchKernelGGL(flat_scan_kernel, dim3(grid), dim3(kThreads), kLdsBytes, st, a);
-  return hipGetLastError();
-}
+hipError_t launch_flat_scan(const ScanArgs& a, hipStream_t st) { return launch_flat_scan8(a, st); }
 
 // ---------------------------------------------------------------------------------------------
 // merge of the per-chunk sorted key lists: one wave per query
