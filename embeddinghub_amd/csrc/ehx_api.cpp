@@ -1382,7 +1382,8 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   if (k == 0 || nq == 0) return EHX_OK;
   if (nq > (1u << 24)) return fail(EHX_EINVAL, "too many queries in one call: %zu", nq);
   if (s->params.mode == EHX_MODE_GRAPH) {
-    if (k > EHX_MAX_K) return fail(EHX_EUNSUPPORTED, "graph mode: k=%u exceeds EHX_MAX_K=%u", k, EHX_MAX_K);
+    // searchKnn(q, k) keeps max(ef, k) results and returns the k best (index.cc:41): any k the result list holds
+    if (k > EHX_MAX_K_PAGED) return fail(EHX_EUNSUPPORTED, "graph mode: k=%u exceeds %u", k, EHX_MAX_K_PAGED);
     return knn_graph_locked(s, st, nq, d_queries, k, d_ids, d_dist, d_count);
   }
   if (k > EHX_MAX_K) {

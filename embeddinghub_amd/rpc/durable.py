@@ -88,6 +88,20 @@ class _SpaceLog:
                 os.fsync(f.fileno())
         self.count += len(keys)
 
+    def mark(self):
+        """sizes of the three files: a point rollback() can return to"""
+        for f in self.f:
+            f.flush()
+        return [os.path.getsize(p) for p in self.paths], self.count
+
+    def rollback(self, mark):
+        """cut the log back to `mark` (an append whose rows the engine then refused must not survive a restart)"""
+        sizes, count = mark
+        for f, size in zip(self.f, sizes):
+            f.flush()
+            f.truncate(size)
+        self.count = count
+
     def replay(self, chunk=65536):
         """Yield (keys, vectors[n, dims]) chunks in append order."""
         if not self.count:
@@ -124,8 +138,15 @@ class DurableSpace:
 
     def set_batch(self, keys, vecs):
         with self._mu:  # the log order is the apply order
-            self._inner.set_batch(keys, vecs)  # raises SpaceNotWritable before anything is logged
+            # log first, then apply: a write is never served without being persisted.  If the engine refuses the
+            # rows (immutable space, allocation failure ...) the log is cut back, so a restart does not replay them.
+            mark = self._log.mark()
             self._log.append(keys, vecs)
+            try:
+                self._inner.set_batch(keys, vecs)
+            except BaseException:
+                self._log.rollback(mark)
+                raise
 
     def freeze(self):
         with self._mu:
@@ -145,7 +166,7 @@ class DurableStore:
 
     def __init__(self, inner, data_dir, sync=False):
         self._inner, self._dir, self._sync = inner, data_dir, sync
-        self._mu = threading.Lock()
+        self._mu = threading.RLock()  # held across a whole create / delete: the two never interleave for one name
         self._spaces = {}
         self.rebuilt_rows = 0
         os.makedirs(data_dir, exist_ok=True)
@@ -203,7 +224,11 @@ class DurableStore:
             self._cat.flush()
             os.fsync(self._cat.fileno())
 
-    def _open(self, name, dims):
+    def _open(self, name, dims, fresh=False):
+        if fresh:
+            # a directory left behind by a crash between the catalog's DELETE record and the removal of the files
+            # must not be adopted: its rows belong to the deleted space
+            shutil.rmtree(self._space_dir(name), ignore_errors=True)
         inner = self._inner.create_space(name, dims)
         sp = DurableSpace(inner, _SpaceLog(self._space_dir(name), dims, self._sync), self, name)
         self._spaces[name] = sp
@@ -213,11 +238,10 @@ class DurableStore:
     def create_space(self, name, dims):
         with self._mu:
             sp = self._spaces.get(name)
-        if sp is not None:
-            return sp
-        self._catalog(_CREATE, name, dims)
-        with self._mu:
-            return self._spaces.get(name) or self._open(name, dims)
+            if sp is not None:
+                return sp
+            self._catalog(_CREATE, name, dims)
+            return self._open(name, dims, fresh=True)
 
     def get_space(self, name):
         with self._mu:
@@ -226,12 +250,13 @@ class DurableStore:
     def delete_space(self, name):
         with self._mu:
             sp = self._spaces.pop(name, None)
-        if sp is None:
-            return
-        self._catalog(_DELETE, name, sp.dims)
-        sp._log.close()
-        shutil.rmtree(self._space_dir(name), ignore_errors=True)
-        self._inner.delete_space(name)
+            if sp is None:
+                return
+            self._catalog(_DELETE, name, sp.dims)
+            with sp._mu:  # no write of this space is between its log append and its apply
+                sp._log.close()
+            shutil.rmtree(self._space_dir(name), ignore_errors=True)
+            self._inner.delete_space(name)  # (handlers still holding the engine space get EHX_ENOTFOUND: tombstone)
 
     def close(self):
         with self._mu:

@@ -83,7 +83,8 @@ enum { EHX_ENGINE_F32 = 0, EHX_ENGINE_F16 = 1, EHX_ENGINE_I8 = 2 };
 #define EHX_MAX_K 48u /* largest k served by one scan pass (k + 8 slack < 64 candidate slots) */
 #define EHX_MAX_K_PAGED 1024u /* flat mode serves EHX_MAX_K < k <= this exactly too, by the exhaustive canonical pass in
                                   pages of 64 results: the whole shard is read once per page and query — fine for the
-                                  occasional large request, not a batch path */
+                                  occasional large request, not a batch path; graph mode serves any k <= this from its
+                                  result list of max(ef, k) entries, as hnswlib's searchKnn does */
 
 typedef struct ehx_space ehx_space; /* opaque; owned by the process-global registry */
 

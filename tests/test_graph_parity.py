@@ -35,6 +35,8 @@ def _build(n, d, em, om, seed=0, M=16):
     (1500, 768, 16, 10, (10, 64)),          # BASELINE dims
     (700, 20, 9, 5, (10,)),                 # SIMD4 distance path
     (500, 19, 7, 3, (16,)),                 # residual distance path
+    (4000, 64, 12, 100, (10, 300)),         # k > 48: searchKnn keeps max(ef, k) results (ef 10 -> 100)
+    (2500, 32, 6, 300, (64,)),              # k spanning several 64-wide output passes
 ])
 def test_strict_parity_on_oracle_graph(n, d, nq, k, efs, em, om):
     X, h, s, rng = _build(n, d, em, om, seed=n + d)

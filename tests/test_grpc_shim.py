@@ -299,3 +299,30 @@ def test_durable_store_rebuilds_on_load_over_engine(tmp_path):
         made.append(srv.EngineStore())
         return made[-1]
     _durable_roundtrip(make, tmp_path, n=20000, d=64)
+
+
+def test_durable_store_crash_consistency(tmp_path):
+    """(1) a directory left behind by a crash between the DELETE record and the removal of the files is
+    not adopted by a later CreateSpace of the same name; (2) a write the engine refuses is not left in the log."""
+    import shutil
+    from embeddinghub_amd.rpc.durable import DurableStore
+    from embeddinghub_amd.rpc.server import SpaceNotWritable
+    rng = np.random.default_rng(3)
+    st = DurableStore(OracleStore(), str(tmp_path))
+    sp = st.create_space("a", 8)
+    sp.set_batch(["x", "y"], rng.standard_normal((2, 8)).astype(np.float32))
+    keep = str(tmp_path / "saved")
+    shutil.copytree(st._space_dir("a"), keep)
+    st.delete_space("a")
+    shutil.copytree(keep, st._space_dir("a"))          # "the crash": the files survive the catalog's DELETE record
+    sp = st.create_space("a", 8)                        # same name, fresh space
+    assert len(sp) == 0
+    sp.set("z", rng.standard_normal(8).astype(np.float32))
+    sp.freeze()
+    with pytest.raises(SpaceNotWritable):
+        sp.set("w", rng.standard_normal(8).astype(np.float32))
+    st.close()
+    st2 = DurableStore(OracleStore(), str(tmp_path))    # restart: only "z" comes back, neither x / y nor the refused w
+    sp2 = st2.get_space("a")
+    assert len(sp2) == 1 and sp2.keys_sorted() == ["z"]
+    st2.close()

@@ -43,6 +43,8 @@ def _space(d, em, n, **kw):
     (30000, 300, 1024, 5),    # four query tiles share every row chunk (lock-step path)
     (17000, 520, 7, 48),      # EHX_MAX_K
     (150000, 768, 128, 1),
+    (18000, 4096, 20, 10),    # long rows: 64 stages per tile, integer dots beyond 2^24
+    (20000, 768, 2500, 10),   # more queries than one launch's 4 query tiles x 256 chunks layout usually sees
 ])
 @pytest.mark.parametrize("em,om", METRICS)
 def test_i8_engine_parity(n, d, nq, k, em, om):
