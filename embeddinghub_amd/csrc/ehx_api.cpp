@@ -1141,9 +1141,7 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   }();
   static const double safety = [] {
     const char* g = getenv("EHX_I8_SAFETY");
-    // default: off (1e9 = always the 256th best).  Measured r02: a factor of 4 gives +9 % at 1 M rows but leaves
-    // 0.2 % of the queries uncertified at 10 M rows (each costing a whole fp16 pass) — not understood yet.
-    const double v = g ? atof(g) : 1e9;
+    const double v = g ? atof(g) : 4.0;  // (1e9: always the 256th best)
     return v < 1.0 ? 1.0 : v;
   }();
   static const bool use_sync = [] {
@@ -1297,6 +1295,28 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   r.ld = s->ld;
   r.metric = s->metric;
   HIP_TRY(launch_rerank256(r, st));
+  if (getenv("EHX_I8_DEBUG")) {  // diagnosis only: what the uncertified queries of this batch look like
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<uint32_t> fl(nq), ov(nq);
+    std::vector<float4> qp(nq);
+    std::vector<float2> uv(nq);
+    std::vector<uint64_t> mg(nq * kMerged8);
+    std::vector<float> od(nq * k);
+    HIP_TRY(hipMemcpy(fl.data(), s->dUflags.p, nq * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ov.data(), ovf, nq * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(qp.data(), s->dQp8.p, nq * sizeof(float4), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(uv.data(), s->dQuv.p, nq * sizeof(float2), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mg.data(), s->dMerged8.p, nq * kMerged8 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(od.data(), d_dist, nq * k * 4, hipMemcpyDeviceToHost));
+    int shown = 0;
+    for (size_t q = 0; q < nq && shown < 6; ++q) {
+      if (!fl[q]) continue;
+      ++shown;
+      auto S = [&](int i) { return mg[q * kMerged8 + i] == ~0ull ? INFINITY : ordered_to_f32((uint32_t)(mg[q * kMerged8 + i] >> 32)); };
+      fprintf(stderr, "[i8 debug] q=%zu ovf=%u tmin=%g S[0]=%g S[63]=%g S[127]=%g S[255]=%g kth_dist=%g u=%g v=%g\n", q, ov[q],
+              qp[q].w, S(0), S(63), S(127), S(255), od[q * k + k - 1], uv[q].x, uv[q].y);
+    }
+  }
   HIP_TRY(hipEventRecord(s->ev[3], st));
   s->ev_valid = true;
   if (count_stats) {
@@ -1811,7 +1831,11 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
     s->ld8 = (uint32_t)round_up(dims, 256);
     // the int8 scan copy pays when its rows are clearly shorter than the fp16 copy's (both are padded to a whole
     // number of LDS ring revolutions: 256 bytes here, 128 halves there)
-    s->has8 = s->has16 && s->params.scan == EHX_SCAN_AUTO && !env_f16 && (uint64_t)s->ld8 * 10 < (uint64_t)s->ld16 * 2 * 8;
+    // ... and while its error bound (~1.3e-2 in dot units whatever d) stays well below the spread of the scores
+    // (~1/sqrt(d) for isotropic rows): beyond d = 2048 most queries would lose their certificate at 256 candidates
+    // (measured at d = 4096: 12 of 20) and pay for a second pass, so longer rows start at the fp16 filter
+    s->has8 = s->has16 && s->params.scan == EHX_SCAN_AUTO && !env_f16 && dims <= 2048 &&
+              (uint64_t)s->ld8 * 10 < (uint64_t)s->ld16 * 2 * 8;
     if (const char* mr = getenv("EHX_I8_MIN_ROWS")) s->i8_min_rows = std::max<uint64_t>(4096, strtoull(mr, nullptr, 10));
     if (s->has16) {
       HIP_TRY(hipMalloc((void**)&s->dUnsafe, sizeof(unsigned long long)));

@@ -125,6 +125,11 @@ __device__ __forceinline__ float canon_dist(int metric, const float* __restrict_
         tail = ex_add(tail, ex_mul(q[m], xv));
       }
     }
+    if (metric != 0 && body) {
+      // hnswlib 0.5.x residual variants of the inner product: both halves are already distances (1 - sum) and are
+      // combined as  res + res_tail - 1.0f  (space_ip.h; oracle/hnsw_oracle.hpp:ip_dist)
+      return ex_sub(ex_add(ex_sub(1.0f, res), ex_sub(1.0f, tail)), 1.0f);
+    }
     res = body ? ex_add(res, tail) : tail;
   }
   if (metric != 0) res = ex_sub(1.0f, res);
@@ -244,6 +249,7 @@ __device__ __forceinline__ float canon_dist_lane_t(const float* __restrict__ q, 
         tail = ex_add(tail, ex_mul(q[m], xv));
       }
     }
+    if (METRIC01 != 0 && body) return ex_sub(ex_add(ex_sub(1.0f, res), ex_sub(1.0f, tail)), 1.0f);  // see canon_dist
     res = body ? ex_add(res, tail) : tail;
   }
   if (METRIC01 != 0) res = ex_sub(1.0f, res);
@@ -347,6 +353,7 @@ __device__ __forceinline__ float canon_dist_group_t(const float* __restrict__ qp
         tail = ex_add(tail, ex_mul(qp[pos], xs[pos]));
       }
     }
+    if (METRIC01 != 0 && body) return ex_sub(ex_add(ex_sub(1.0f, res), ex_sub(1.0f, tail)), 1.0f);  // see canon_dist
     res = body ? ex_add(res, tail) : tail;
   }
   if (METRIC01 != 0) res = ex_sub(1.0f, res);

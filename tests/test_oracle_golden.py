@@ -170,7 +170,7 @@ def test_distance_bit_exact_vs_numpy_emulation(dim):
             el2, eip = _sse_l2(a, b), _sse_ip(a, b)
         else:
             # residual variants: SIMD body over the largest multiple of 16 (dim>16) or 4 (dim>4),
-            # scalar tail, added; dim<=4 scalar
+            # scalar tail; L2: the two sums added; inner product: see below; dim<=4 scalar
             body = (dim >> 4 << 4) if dim > 16 else ((dim >> 2 << 2) if dim > 4 else 0)
             l2b = _sse_l2(a[:body], b[:body]) if body else np.float32(0)
             ipb = _sse_ip_sum(a[:body], b[:body]) if body else np.float32(0)
@@ -181,7 +181,11 @@ def test_distance_bit_exact_vs_numpy_emulation(dim):
                 t2 = np.float32(t2 + np.float32(d * d))
                 ti = np.float32(ti + np.float32(a[i] * b[i]))
             el2 = np.float32(l2b + t2) if body else t2
-            eip = np.float32(np.float32(1.0) - (np.float32(ipb + ti) if body else ti))
+            if body:  # hnswlib 0.5.x: both halves are distances (1 - sum), combined as res + res_tail - 1.0f
+                eip = np.float32(np.float32(np.float32(np.float32(1.0) - ipb) + np.float32(np.float32(1.0) - ti))
+                                 - np.float32(1.0))
+            else:
+                eip = np.float32(np.float32(1.0) - ti)
         assert np.float32(pyoracle.dist(METRIC_L2, a, b)).tobytes() == np.float32(el2).tobytes()
         assert np.float32(pyoracle.dist(METRIC_IP, a, b)).tobytes() == np.float32(eip).tobytes()
 

@@ -57,6 +57,9 @@ def group_distance(metric, qp, xs, dims):
                 tail = f32(tail + f32(dlt * dlt))
             else:
                 tail = f32(tail + f32(a * b))
+        if metric != pyoracle.METRIC_L2 and body:
+            # hnswlib 0.5.x residual variants: both halves are distances (1 - sum), combined as res + res_tail - 1
+            return f32(f32(f32(f32(1) - res) + f32(f32(1) - tail)) - f32(1))
         res = f32(res + tail) if body else tail
     return f32(f32(1) - res) if metric != pyoracle.METRIC_L2 else res
 
