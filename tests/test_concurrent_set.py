@@ -112,7 +112,7 @@ def test_search_throughput_beside_a_stream_of_sets():
         n, t0 = 0, time.perf_counter()
         while (time.perf_counter() - t0 < seconds) if stop is None else not stop.is_set():
             s.knn_device(q, k, ids, dst, cnt, stream=st)
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()  # (not device-wide: that would wait for the writer's stream too)
             n += 1
         return n * B / (time.perf_counter() - t0)
     search_rate(0.3)
