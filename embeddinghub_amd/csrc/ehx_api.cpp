@@ -513,7 +513,7 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
     return fail(EHX_EUNSUPPORTED, "graph mode: rows must be inserted in id order (graph covers %llu, next row %llu)",
                 (unsigned long long)s->g_n, (unsigned long long)id0);
   const uint32_t M = s->params.M, M0 = 2 * M;
-  if (M0 + 1 > 64 || M < 2) return fail(EHX_EUNSUPPORTED, "M=%u not supported by the insertion kernels (2M+1 <= 64)", M);
+  if (M0 > 64 || M < 2) return fail(EHX_EUNSUPPORTED, "M=%u not supported by the insertion kernels (2M <= 64)", M);
   uint32_t efc = s->params.ef_construction > M ? s->params.ef_construction : M;  // max(efC, M)
   if (efc > 2048) return fail(EHX_EUNSUPPORTED, "ef_construction=%u exceeds 2048", efc);
   int rc;
@@ -1810,14 +1810,9 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
   if (s->params.ef == 0) s->params.ef = 10;
   if (s->params.seed == 0) s->params.seed = 100;
   if (s->params.mode == EHX_MODE_GRAPH) {
-    // one wave per list: a level-0 list holds 2M ids (search, import: M <= 32); GPU-side insertion re-selects
-    // a full list among its 2M entries plus the new one, so it needs 2M + 1 <= 64
+    // one wave per list: a level-0 list holds 2M ids, so M <= 32 (search, import and GPU-side insertion alike)
     if (s->params.M < 2 || s->params.M > 32)
       return fail(EHX_EUNSUPPORTED, "graph mode: M=%u outside [2, 32]", s->params.M);
-    if (s->params.M > 31 && s->params.build_batch != 0xFFFFFFFFu)
-      return fail(EHX_EUNSUPPORTED,
-                  "graph mode: M=32 spaces cannot build their graph on the GPU (2M+1 candidates exceed one wave); "
-                  "create the space with build_batch = 0xFFFFFFFF and import the graph (ehx_graph_import)");
   }
   if (s->params.scan > EHX_SCAN_F16) return fail(EHX_EINVAL, "unknown scan engine %u", s->params.scan);
   {

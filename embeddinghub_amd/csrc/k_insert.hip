@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64) void insert_link_kernel(const InsertArgs a, con
                                                          const uint32_t* __restrict__ kind,
                                                          const uint32_t* __restrict__ inc_off,
                                                          const uint32_t* __restrict__ inc_ids) {
-  __shared__ uint64_t cand[64];
+  __shared__ uint64_t cand[65];  // a full level-0 list of M = 32 holds 64 ids; the incoming one is the 65th candidate
   __shared__ uint64_t kept[64];
   const int lane = threadIdx.x;
   const uint32_t w = blockIdx.x;
@@ -423,15 +423,28 @@ __global__ __launch_bounds__(64) void insert_link_kernel(const InsertArgs a, con
       continue;
     }
     // full: candidates = {new} u list with distances to s, heuristic with the level's max degree
-    const uint32_t id = (uint32_t)lane < cnt ? nb : ((uint32_t)lane == cnt ? nid : kNone);
-    uint64_t key = kKeyInf;
-    if (id != kNone) {
+    auto key_of = [&](uint32_t id) {
       const float d = row_row_dist(metric01, scale, a.X + (size_t)id * a.ld, scale ? a.inv_norm[id] : 1.0f,
                                    a.X + (size_t)s * a.ld, ss, a.dims);
-      key = ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)id << 1);
+      return ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)id << 1);
+    };
+    if (cnt < 64) {
+      const uint32_t id = (uint32_t)lane < cnt ? nb : ((uint32_t)lane == cnt ? nid : kNone);
+      uint64_t key = kKeyInf;
+      if (id != kNone) key = key_of(id);
+      key = wsort64(key, lane);
+      cand[lane] = key;
+    } else {
+      // 64 list entries fill the wave: sort them, then slot the incoming key in at its rank (keys are distinct:
+      // the id is part of the key and the incoming id is not in the list)
+      uint64_t nkey = 0;
+      if (lane == 0) nkey = key_of(nid);
+      nkey = ((uint64_t)__shfl((int)(nkey >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)nkey, 0, 64);
+      const uint64_t key = wsort64(key_of(nb), lane);
+      const uint32_t rank = __builtin_popcountll(__ballot(key < nkey));
+      cand[(uint32_t)lane + ((uint32_t)lane >= rank ? 1u : 0u)] = key;
+      if (lane == 0) cand[rank] = nkey;
     }
-    key = wsort64(key, lane);
-    cand[lane] = key;
     __syncthreads();
     const uint32_t nk = select_heuristic(a, cand, cnt + 1, width, kept, lane);
     // rewrite farthest first
