@@ -167,6 +167,11 @@ struct ehx_space {
   unsigned long long* dGraphCounters = nullptr;  // n_dist, n_hops0, n_hops_up, n_prefetch_hit, [4..11] profile builds
 
   // key map (explicit keys only)
+  // key <-> row id.  Their own lock (taken INSIDE mu when both are held, or alone): a streamed batch inserts its
+  // 8192 keys — milliseconds of hashing and allocation — without stopping the searches, which only need mu for the
+  // device arrays and the row count; the row count is published after the keys, so every id a search can return
+  // already has its key.
+  std::shared_mutex kmu;
   std::unordered_map<std::string, uint64_t> key_to_id;
   std::vector<std::string> id_to_key;
 
@@ -852,10 +857,13 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
     const char* g = getenv("EHX_GRAPH_VISLOG");  // "0": per-batch memset of the bitmaps instead (A/B runs)
     return g ? atoi(g) != 0 : true;
   }();
-  // Measured (r02, batch 1024): clearing 256 MB of bitmaps per batch with a memset costs more than the log's stores and
-  // evicts rows from the Infinity Cache (2 M x 768: 2.28 -> 2.07 ms per batch with the log); on small bitmaps the memset
-  // is nearly free and the log's extra store per visited row is not (1 M x 128: 1.02 ms vs 1.12 ms).
-  const bool log_now = use_vislog && (size_t)nq * vis_words * sizeof(uint32_t) >= (192u << 20);
+  // Measured (r02, batch 1024, memset inside the timed region; gpurun_out of scripts/gpu_session_n.sh): the memset
+  // costs n/8 bytes per query, streamed; the log costs one store per visited row plus one RANDOM 4-byte store per row
+  // when the query clears its words — ~27 ef of them.  6.25 M x 128: ef 50 log 0.41 / memset 0.47 ms, ef 200 1.11 /
+  // 1.11, ef 800 4.27 / 3.89; 2 M x 768: ef 100 2.06 / 2.05, ef 400 6.99 / 6.81; small bitmaps (1 M x 128): the
+  // memset is nearly free.  Hence: the log when the bitmaps are large AND the index has more than 32 000 rows per ef.
+  const bool log_now = use_vislog && (size_t)nq * vis_words * sizeof(uint32_t) >= (192u << 20) &&
+                       s->n >= (uint64_t)32000 * ef;
   const uint32_t vislog_cap = log_now ? 48u * ef + 256u : 0u;
   if ((rc = s->dInsVislog.ensure((size_t)nq * (vislog_cap ? vislog_cap : 1u)))) return rc;
   if (!s->dGraphCounters) {
@@ -865,7 +873,6 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
   HIP_TRY(hipEventRecord(s->ev[0], st));
   HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, q_rows, s->metric, s->dQ.p, st));
-  if (!log_now) HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, (size_t)nq * vis_words * sizeof(uint32_t), st));
   GraphArgs a;
   a.Q = s->dQ.p;
   a.X = s->xf32();
@@ -897,6 +904,8 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   hipEvent_t* pr = s->ring[s->ring_count % ehx_space::kRing];
   HIP_TRY(hipEventRecord(s->ev[1], st));
   HIP_TRY(hipEventRecord(pr[0], st));
+  // (inside the timed kernel region: clearing the bitmaps is part of what a batch costs, log or memset)
+  if (!log_now) HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, (size_t)nq * vis_words * sizeof(uint32_t), st));
   HIP_TRY(launch_graph_search(a, st));
   HIP_TRY(hipEventRecord(pr[1], st));
   HIP_TRY(hipEventRecord(s->ev[2], st));
@@ -1518,6 +1527,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
 }
 
 int key_for_id(ehx_space* s, uint64_t id, std::string* out) {
+  std::shared_lock<std::shared_mutex> kl(s->kmu);
   if (id < s->id_to_key.size() && !s->implicit_keys) {
     *out = s->id_to_key[id];
     return EHX_OK;
@@ -1542,6 +1552,7 @@ int lookup_key(ehx_space* s, const char* key, size_t klen, uint64_t* id) {
     *id = v;
     return EHX_OK;
   }
+  std::shared_lock<std::shared_mutex> kl(s->kmu);
   auto it = s->key_to_id.find(std::string(key, klen));
   if (it == s->key_to_id.end()) return EHX_ENOTFOUND;
   *id = it->second;
@@ -1557,6 +1568,7 @@ void resolve_keys(ehx_space* s, size_t n, const char* const* keys, const size_t*
                          uint64_t* next_out, std::vector<std::string>* new_keys) {
   ids->resize(n);
   uint64_t next = s->n;
+  std::shared_lock<std::shared_mutex> kl(s->kmu);
   std::unordered_map<std::string, uint64_t> fresh;
   fresh.reserve(n);
   new_keys->reserve(n);
@@ -1643,8 +1655,11 @@ int sharded_set_batch(ehx_space* p, size_t n, const char* const* keys, const siz
   });
   if (rc) return rc;  // (a failing shard leaves the parent's key maps and row count untouched)
   const uint64_t old_n = p->n;
-  for (size_t i = 0; i < new_keys.size(); ++i) p->key_to_id.emplace(new_keys[i], old_n + i);
-  for (auto& k : new_keys) p->id_to_key.push_back(std::move(k));
+  {
+    std::unique_lock<std::shared_mutex> kl(p->kmu);
+    for (size_t i = 0; i < new_keys.size(); ++i) p->key_to_id.emplace(new_keys[i], old_n + i);
+    for (auto& k : new_keys) p->id_to_key.push_back(std::move(k));
+  }
   p->n = next;
   return EHX_OK;
 }
@@ -1941,9 +1956,12 @@ int ehx_space_drop(ehx_space* s) {
     (void)hipDeviceSynchronize();
     s->dropped = true;
     s->release_device();
-    s->key_to_id.clear();
-    s->id_to_key.clear();
-    s->id_to_key.shrink_to_fit();
+    {
+      std::unique_lock<std::shared_mutex> kl(s->kmu);
+      s->key_to_id.clear();
+      s->id_to_key.clear();
+      s->id_to_key.shrink_to_fit();
+    }
     s->h_levels.clear();
     s->h_levels.shrink_to_fit();
   }
@@ -2077,6 +2095,7 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
     bool rewrite = false;
     {
       std::set<std::string> seen;
+      std::shared_lock<std::shared_mutex> kl(s->kmu);
       for (size_t i = 0; i < n && !rewrite; ++i) {
         std::string k(keys[i], klens[i]);
         rewrite = s->key_to_id.count(k) != 0 || !seen.insert(std::move(k)).second;
@@ -2212,15 +2231,23 @@ static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>
   if ((rc = refresh_scan16(s, min_id, max_id - min_id + 1, ws))) return rc;
   if ((rc = sync_stream(s, ws))) return rc;
   // commit: the rows are resident and described — publish the keys and the new row count
+  // (the keys first, under their own lock — searches keep running — then the row count, under the space's lock for
+  // the length of one store)
+  if (new_keys) {
+    std::shared_lock<std::shared_mutex> rl(s->mu, std::defer_lock);
+    if (append_only) {
+      rl.lock();  // (shared: keeps a drop out, not the searches)
+      if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+    }
+    std::unique_lock<std::shared_mutex> kl(s->kmu);
+    for (size_t i = 0; i < new_keys->size(); ++i) s->key_to_id.emplace((*new_keys)[i], old_n + i);
+    for (auto& k : *new_keys) s->id_to_key.push_back(std::move(k));
+  }
   {
     std::unique_lock<std::shared_mutex> pl(s->mu, std::defer_lock);
     if (append_only) {
       pl.lock();
       if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
-    }
-    if (new_keys) {
-      for (size_t i = 0; i < new_keys->size(); ++i) s->key_to_id.emplace((*new_keys)[i], old_n + i);
-      for (auto& k : *new_keys) s->id_to_key.push_back(std::move(k));
     }
     s->n = next;
   }

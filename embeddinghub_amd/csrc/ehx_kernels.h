@@ -40,6 +40,23 @@ __host__ __device__ inline float ordered_to_f32(uint32_t o) {
 // __fmul_rn/__fadd_rn are plain * and + (contractible) and __fsqrt_rn is the approximate native
 // sqrt, so they are NOT used; the library is built with -ffp-contract=off and relies on hipcc's
 // default -fhip-fp32-correctly-rounded-divide-sqrt for / and sqrt.
+// LDS hand-over between the lanes of ONE wave (kernels launched with 64 threads per workgroup): the LDS accesses of
+// a wave execute in program order, so a compiler-level fence is all a write -> read across lanes needs — no
+// s_barrier and no drain of the LDS queue, which __syncthreads() would put on the dependent chain
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A value that is the same in every lane but reaches the wave through a shuffle or an LDS read is "divergent" to the
+// compiler: everything derived from it sits in vector registers behind exec-mask branches.  readfirstlane moves it
+// to a scalar register, and loop bookkeeping built on it runs on the scalar unit.
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ float wave_uniform(float x) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x)));
+}
+
 __device__ __forceinline__ float ex_add(float a, float b) { return a + b; }
 __device__ __forceinline__ float ex_sub(float a, float b) { return a - b; }
 __device__ __forceinline__ float ex_mul(float a, float b) { return a * b; }
@@ -358,6 +375,79 @@ __device__ __forceinline__ float canon_dist_group_t(const float* __restrict__ qp
   }
   if (METRIC01 != 0) res = ex_sub(1.0f, res);
   return res;
+}
+
+// Two rows of exactly 16 * N16 floats by one 4-lane group, all 2 * N16 loads of the lane in flight before the first
+// product (a 128-dim row is ONE ring block of canon_dist_group_t: with more than 16 fresh neighbours the second pass
+// would wait a second memory round trip).  Same arithmetic and order per row as canon_dist_group_t.
+template <int METRIC01, int N16>
+__device__ __forceinline__ void canon_dist_group_pair(const float* __restrict__ qp, const float* __restrict__ xa,
+                                                      const float* __restrict__ xb, int sub, float& res_a, float& res_b) {
+  const float4* a4 = (const float4*)xa + sub;
+  const float4* b4 = (const float4*)xb + sub;
+  const float4* q4 = (const float4*)qp + sub;
+  float4 ra[N16], rb[N16];
+#pragma unroll
+  for (int i = 0; i < N16; ++i) ra[i] = a4[i * 4];
+#pragma unroll
+  for (int i = 0; i < N16; ++i) rb[i] = b4[i * 4];
+  float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+  for (int i = 0; i < N16; ++i) canon_group_step<METRIC01>(ra[i], q4[i * 4], pa);
+#pragma unroll
+  for (int i = 0; i < N16; ++i) canon_group_step<METRIC01>(rb[i], q4[i * 4], pb);
+  const float a0 = __shfl(pa, 0, 4), a1 = __shfl(pa, 1, 4), a2 = __shfl(pa, 2, 4), a3 = __shfl(pa, 3, 4);
+  const float b0 = __shfl(pb, 0, 4), b1 = __shfl(pb, 1, 4), b2 = __shfl(pb, 2, 4), b3 = __shfl(pb, 3, 4);
+  res_a = ex_add(ex_add(ex_add(a0, a1), a2), a3);
+  res_b = ex_add(ex_add(ex_add(b0, b1), b2), b3);
+  if (METRIC01 != 0) {
+    res_a = ex_sub(1.0f, res_a);
+    res_b = ex_sub(1.0f, res_b);
+  }
+}
+
+// Canonical distances of the search-copy rows ids_l[0..count) (LDS) to the permuted query qs (LDS), by one wave:
+// lane p (< count) returns the distance of row p, other lanes +inf.  16 rows per pass, one 4-lane group per row
+// (canon_dist_group_t); rows of 32 / 64 / 96 / 128 / 192 / 256 dims go 32 per pass, two per group, with the loads
+// of both rows in flight together (canon_dist_group_pair) — at 128 dims and 27 fresh neighbours per expansion that is
+// one memory round trip per expansion instead of two (6.25 M x 128-class workloads: -20 % kernel time).
+template <int METRIC01>
+__device__ __forceinline__ float wave_group_dists(const float* __restrict__ qs, const float* __restrict__ Xs, uint32_t ld,
+                                                  uint32_t dims, const uint32_t* ids_l, uint32_t count, int lane) {
+  float mine = __builtin_inff();
+  const bool pairable = dims <= 256 && (dims == 32 || dims == 64 || dims == 96 || dims == 128 || dims == 192 || dims == 256);
+  if (pairable && count > 16) {
+    for (uint32_t base = 0; base < count; base += 32) {
+      const uint32_t ra = base + ((uint32_t)lane >> 2), rb = ra + 16;
+      float res_a = __builtin_inff(), res_b = __builtin_inff();
+      if (ra < count) {
+        const bool have_b = rb < count;  // a missing second row: the first one again, result dropped
+        const float* xa = Xs + (size_t)ids_l[ra] * ld;
+        const float* xb = Xs + (size_t)ids_l[have_b ? rb : ra] * ld;
+        const int sub = lane & 3;
+        switch (dims) {
+          case 32: canon_dist_group_pair<METRIC01, 2>(qs, xa, xb, sub, res_a, res_b); break;
+          case 64: canon_dist_group_pair<METRIC01, 4>(qs, xa, xb, sub, res_a, res_b); break;
+          case 96: canon_dist_group_pair<METRIC01, 6>(qs, xa, xb, sub, res_a, res_b); break;
+          case 128: canon_dist_group_pair<METRIC01, 8>(qs, xa, xb, sub, res_a, res_b); break;
+          case 192: canon_dist_group_pair<METRIC01, 12>(qs, xa, xb, sub, res_a, res_b); break;
+          default: canon_dist_group_pair<METRIC01, 16>(qs, xa, xb, sub, res_a, res_b); break;
+        }
+        if (!have_b) res_b = __builtin_inff();
+      }
+      const float got_a = __shfl(res_a, (lane & 15) << 2, 64), got_b = __shfl(res_b, (lane & 15) << 2, 64);
+      if (((uint32_t)lane & ~31u) == base && (uint32_t)lane < count) mine = (lane & 16) ? got_b : got_a;
+    }
+    return mine;
+  }
+  for (uint32_t base = 0; base < count; base += 16) {
+    const uint32_t r = base + ((uint32_t)lane >> 2);
+    float res = __builtin_inff();
+    if (r < count) res = canon_dist_group_t<METRIC01>(qs, Xs + (size_t)ids_l[r] * ld, lane & 3, dims);
+    const float got = __shfl(res, (lane & 15) << 2, 64);
+    if (((uint32_t)lane & ~15u) == base && (uint32_t)lane < count) mine = got;
+  }
+  return mine;
 }
 
 // runtime-dispatch form (metric: 0 = L2^2, 1 = 1 - inner product; scale_x: cosine rows) used by the

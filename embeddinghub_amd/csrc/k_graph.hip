@@ -47,6 +47,25 @@ constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 #define EHX_G_NEXT_EARLY 1  // decide the next node before the merge and request its adjacency / visited words there
 #endif
 
+#ifndef EHX_G_WSYNC
+#define EHX_G_WSYNC 1       // one wave per workgroup: LDS accesses of a wave execute in order, so a compiler-level
+#endif                      // fence orders write -> read across lanes; no s_barrier, no drain of the LDS queue
+#ifndef EHX_G_UNIFORM
+#define EHX_G_UNIFORM 1     // wave-uniform values that come out of a shuffle or LDS are moved to scalar registers
+#endif                      // (readfirstlane): the loop bookkeeping then runs on the scalar unit, with scalar branches
+
+#if EHX_G_WSYNC
+#define EHX_GSYNC() wave_lds_sync()
+#else
+#define EHX_GSYNC() __syncthreads()
+#endif
+
+#if EHX_G_UNIFORM
+#define EHX_UNIFORM(x) wave_uniform((uint32_t)(x))
+#else
+#define EHX_UNIFORM(x) ((uint32_t)__shfl((int)(x), 0, 64))
+#endif
+
 #ifdef EHX_GRAPH_PROFILE
 #define EHX_PROF_DECL unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t_ = wall_clock64()
 #define EHX_PROF(i)                              \
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
 #else
   for (uint32_t i = lane; i < a.ld; i += 64) qs[i] = a.Q[(size_t)qi * a.ld + i];
 #endif
-  __syncthreads();
+  EHX_GSYNC();
 
   unsigned long long n_dist = 0, n_hops0 = 0, n_hops_up = 0;
 
@@ -141,16 +160,7 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   // canonical distances of rows ids_l[0..count): 16 rows per pass, one 4-lane group per row reading the
   // search copy (canon_dist_group_t); lane p (< count) gets the distance of row p
   auto lane_dist = [&](uint32_t count) -> float {
-    float mine = __builtin_inff();
-    for (uint32_t base = 0; base < count; base += 16) {
-      const uint32_t r = base + ((uint32_t)lane >> 2);
-      float res = __builtin_inff();
-      if (r < count)
-        res = canon_dist_group_t<METRIC01>(qs, a.Xs + (size_t)ids_l[r] * a.ld, lane & 3, a.dims);
-      const float got = __shfl(res, (lane & 15) << 2, 64);
-      if (((uint32_t)lane & ~15u) == base && (uint32_t)lane < count) mine = got;
-    }
-    return mine;
+    return wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l, count, lane);
   };
 #else
   auto lane_dist = [&](uint32_t count) -> float {
@@ -164,8 +174,8 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   // ---- entry point ----
   uint32_t cur = a.entry_point;
   if (lane == 0) ids_l[0] = cur;
-  __syncthreads();
-  float curdist = __shfl(lane_dist(1), 0, 64);
+  EHX_GSYNC();
+  float curdist = __uint_as_float(EHX_UNIFORM(__float_as_uint(lane_dist(1))));
   n_dist += 1;
 
   // ---- upper levels: greedy descent ----
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
       const uint32_t cnt = __builtin_popcountll(vmask);  // lists are packed from slot 0
       n_hops_up += 1;
       if (lane < (int)cnt) ids_l[lane] = nb;
-      __syncthreads();
+      EHX_GSYNC();
       n_dist += cnt;
       uint32_t best_i = kNoNode;
       float best_d = curdist;
@@ -198,6 +208,8 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
             mi = oi;
           }
         }
+        m = __uint_as_float(EHX_UNIFORM(__float_as_uint(m)));  // (the butterfly leaves the minimum in every lane)
+        mi = EHX_UNIFORM(mi);
         if (m < best_d) {
           best_d = m;
           best_i = mi;
@@ -205,10 +217,10 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
       }
       if (best_i != kNoNode) {
         curdist = best_d;
-        cur = ids_l[best_i];
+        cur = EHX_UNIFORM(ids_l[best_i]);
         changed = true;
       }
-      __syncthreads();
+      EHX_GSYNC();
     }
   }
 
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     if (a.vislog_cap) vlog[0] = cur;
   }
   n_logged = 1;
-  __syncthreads();
+  EHX_GSYNC();
   uint32_t scan_from = 0;  // every entry of R before this index is expanded
   uint32_t pf_node = kNoNode, pf_nb = kNoNode, pf_word = 0;
   unsigned long long n_pf_hit = 0;
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     EHX_PROF(0)
     const uint32_t c = (uint32_t)(kidx & 0xFFFFFFFFull) >> 1;
     const uint32_t c2 = idx2 != kNoNode ? (uint32_t)(kidx2 & 0xFFFFFFFFull) >> 1 : kNoNode;
-    __syncthreads();
+    EHX_GSYNC();
     if (lane == 0) R[idx] |= 1ull;
     n_hops0 += 1;
     // neighbours (stored order) and their visited words
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
       if (n_logged + slot < a.vislog_cap) vlog[n_logged + slot] = nb;
     }
     n_logged += nfresh;
-    __syncthreads();
+    EHX_GSYNC();
     n_dist += nfresh;
     EHX_PROF(1)
     // distances: lane p (< nfresh) owns fresh neighbour p
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     uint32_t rank = 0;
     if (do_merge) {
       batch[lane] = mykey;
-      __syncthreads();
+      EHX_GSYNC();
       // sixteen keys per trip, all LDS reads issued before the first compare (a one-key-per-trip loop
       // pays the LDS latency nfresh times); batch[nfresh..64) = +inf never counts
       for (uint32_t j = 0; j < nfresh; j += 16) {
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
         for (int u = 0; u < 16; ++u) rank += kb[u] < mykey ? 1u : 0u;
       }
       const uint64_t first = __ballot((uint32_t)lane < nfresh && rank == 0);
-      minkey = __shfl(mykey, (int)__builtin_ctzll(first), 64);
+      minkey = readlane64(mykey, (int)__builtin_ctzll(first));
     }
     EHX_PROF(3)
     // The node expanded next is known NOW, before the merge: the closer of the closest fresh neighbour
@@ -366,14 +378,16 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     EHX_PROF(4)
     if (do_merge) {
       if ((uint32_t)lane < nfresh) S[rank] = mykey;
-      __syncthreads();
+      EHX_GSYNC();
       uint64_t skey = kKeyInf;
       uint32_t ps = kNoNode;
       if ((uint32_t)lane < nfresh) {
         skey = S[lane];  // the lane-th smallest fresh key
         ps = lower_bound_lds(R, nR, skey);
       }
-      const uint32_t p0 = __shfl(ps, 0, 64);  // insertion point of the smallest fresh key
+      // insertion point of the smallest fresh key (lane 0).  readfirstlane, not a shuffle: the value is wave-uniform
+      // and everything derived from it (nR, the scan positions, the loop bounds) then lives in scalar registers
+      const uint32_t p0 = EHX_UNIFORM(ps);
       EHX_PROF(5)
       if (p0 < ef) {
         // Merge in place, driven by the DESTINATION: fresh key i lands at fpos = ps_i + i (distinct,
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
         const uint32_t fpos = ps + (uint32_t)lane;
         const bool lands = (uint32_t)lane < nfresh && fpos < ef;
         if (lands) F[fpos] = 1;
-        __syncthreads();
+        EHX_GSYNC();
         for (uint32_t dhi = new_nR; dhi > p0;) {
           const uint32_t dlo = dhi - p0 > 64 ? dhi - 64 : p0;
           const uint32_t dpos = dlo + (uint32_t)lane;
@@ -397,16 +411,16 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
           const bool mv = in && !taken;
           uint64_t kj = 0;
           if (mv) kj = R[dpos - cnt];
-          __syncthreads();
+          EHX_GSYNC();
           if (mv) R[dpos] = kj;
-          __syncthreads();
+          EHX_GSYNC();
           dhi = dlo;
         }
         if (lands) {
           R[fpos] = skey;
           F[fpos] = 0;
         }
-        __syncthreads();
+        EHX_GSYNC();
         nR = new_nR;
         if (p0 < scan_from) scan_from = p0;
       }
@@ -421,6 +435,7 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   }
 
   // ---- leave the visited bitmap all-zero: clear the words of the logged rows (or everything, if the log overflowed)
+  __syncthreads();  // the log was written by other lanes, through global memory: a real fence, once per query
   if (a.vislog_cap == 0) {
     // (A/B mode: the host clears the bitmaps with a memset before every launch)
   } else if (n_logged <= a.vislog_cap) {

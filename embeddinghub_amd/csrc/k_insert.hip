@@ -28,6 +28,15 @@
 
 namespace ehx {
 
+#ifndef EHX_I_WSYNC
+#define EHX_I_WSYNC 1  // every kernel here runs one wave per workgroup: wave_lds_sync() instead of a barrier
+#endif
+#if EHX_I_WSYNC
+#define EHX_ISYNC() wave_lds_sync()
+#else
+#define EHX_ISYNC() __syncthreads()
+#endif
+
 namespace {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -128,7 +137,7 @@ __device__ __forceinline__ uint32_t select_heuristic(const InsertArgs& a, const 
   const bool scale = a.metric == 2;
   if (nc < Msel) {
     for (uint32_t i = lane; i < nc; i += 64) kept[i] = cand[i];
-    __syncthreads();
+    EHX_ISYNC();
     return nc;
   }
   uint32_t nk = 0;
@@ -147,7 +156,7 @@ __device__ __forceinline__ uint32_t select_heuristic(const InsertArgs& a, const 
       if (lane == 0) kept[nk] = ck;
       nk += 1;
     }
-    __syncthreads();
+    EHX_ISYNC();
   }
   return nk;
 }
@@ -185,25 +194,14 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
 #endif
     }
   }
-  __syncthreads();
+  EHX_ISYNC();
 
 #if EHX_INSERT_COOP
   // canonical distances of rows ids_l[0..count) to the new row: 16 rows per pass, one 4-lane group per row
   // reading the search copy in coalesced 64-byte pieces (canon_dist_group_t, as k_graph.hip); lane p gets row p
   auto lane_dist = [&](uint32_t count) -> float {
-    float mine = __builtin_inff();
-    for (uint32_t base = 0; base < count; base += 16) {
-      const uint32_t r = base + ((uint32_t)lane >> 2);
-      float res = __builtin_inff();
-      if (r < count) {
-        const float* row = a.Xs + (size_t)ids_l[r] * a.ld;
-        res = metric01 == 0 ? canon_dist_group_t<0>(qs, row, lane & 3, a.dims)
-                            : canon_dist_group_t<1>(qs, row, lane & 3, a.dims);
-      }
-      const float got = __shfl(res, (lane & 15) << 2, 64);
-      if (((uint32_t)lane & ~15u) == base && (uint32_t)lane < count) mine = got;
-    }
-    return mine;
+    return metric01 == 0 ? wave_group_dists<0>(qs, a.Xs, a.ld, a.dims, ids_l, count, lane)
+                         : wave_group_dists<1>(qs, a.Xs, a.ld, a.dims, ids_l, count, lane);
   };
 #else
   auto lane_dist = [&](uint32_t count) -> float {
@@ -224,14 +222,15 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
 
   uint32_t* out = a.sel + (size_t)p * (a.max_sel_levels * (1 + a.M));
   for (uint32_t i = lane; i < a.max_sel_levels * (1 + a.M); i += 64) out[i] = (i % (1 + a.M)) == 0 ? 0u : kNone;
+  __syncthreads();  // (global memory handed between lanes — here: rewritten by other lanes later — keeps the real fence)
 
   // ---- greedy descent through the levels above the node's level (hnswlib addPoint) ----
   uint32_t cur = a.entry_point;
   if (lane == 0) ids_l[0] = cur;
-  __syncthreads();
+  EHX_ISYNC();
   float curdist = 0.0f;
   if (my_level < a.max_level) {
-    curdist = __shfl(lane_dist(1), 0, 64);
+    curdist = wave_uniform(lane_dist(1));
     for (int level = a.max_level; level > my_level; --level) {
       bool changed = true;
       while (changed) {
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
         if (lane < (int)width) nb = lst[lane];
         const uint32_t cnt = __builtin_popcountll(__ballot(nb != kNone));
         if (lane < (int)cnt) ids_l[lane] = nb;
-        __syncthreads();
+        EHX_ISYNC();
         float m = lane_dist(cnt);
         uint32_t mi = (uint32_t)lane;
 #pragma unroll
@@ -254,12 +253,14 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
             mi = oi;
           }
         }
+        m = wave_uniform(m);  // (the butterfly leaves the minimum in every lane)
+        mi = wave_uniform(mi);
         if (m < curdist) {
           curdist = m;
-          cur = ids_l[mi];
+          cur = wave_uniform(ids_l[mi]);
           changed = true;
         }
-        __syncthreads();
+        EHX_ISYNC();
       }
     }
   }
@@ -270,8 +271,8 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
   for (int level = top_level; level >= 0; --level) {
     uint32_t nlog = 0;
     if (lane == 0) ids_l[0] = cur;
-    __syncthreads();
-    const float d0 = __shfl(lane_dist(1), 0, 64);
+    EHX_ISYNC();
+    const float d0 = wave_uniform(lane_dist(1));
     uint32_t nR = 1;
     if (lane == 0) {
       R[0] = ((uint64_t)f32_to_ordered(d0) << 32) | ((uint64_t)cur << 1);
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
       vlog[0] = cur;
     }
     nlog = 1;
-    __syncthreads();
+    EHX_ISYNC();
     for (;;) {
       uint32_t idx = kNone;
       for (uint32_t base = 0; base < nR && idx == kNone; base += 64) {
@@ -289,8 +290,8 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
         if (m) idx = base + (uint32_t)__builtin_ctzll(m);
       }
       if (idx == kNone) break;
-      const uint32_t c = (uint32_t)(R[idx] & 0xFFFFFFFFull) >> 1;
-      __syncthreads();
+      const uint32_t c = wave_uniform((uint32_t)(R[idx] & 0xFFFFFFFFull) >> 1);
+      EHX_ISYNC();
       if (lane == 0) R[idx] |= 1ull;
       uint32_t width;
       const uint32_t* lst = list_of(c, level, &width);
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
         if (nlog + slot < a.vislog_cap) vlog[nlog + slot] = nb;
       }
       nlog += nfresh;
-      __syncthreads();
+      EHX_ISYNC();
       if (nfresh == 0) continue;
       uint64_t mykey = kKeyInf;
       {
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
       }
       mykey = wsort64(mykey, lane);
       batch[lane] = mykey;
-      __syncthreads();
+      EHX_ISYNC();
       if ((uint32_t)lane < nfresh) {
         const uint32_t pos = lb_lds(R, nR, mykey) + lane;
         if (pos < ef) R2[pos] = mykey;
@@ -328,13 +329,14 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
         const uint32_t pos = j + lb_lds(batch, nfresh, kj);
         if (pos < ef) R2[pos] = kj;
       }
-      __syncthreads();
+      EHX_ISYNC();
       nR = nR + nfresh < ef ? nR + nfresh : ef;
       uint64_t* t = R;
       R = R2;
       R2 = t;
     }
     // reset the visited bits of this search (hnswlib takes a fresh visited tag per searchBaseLayer)
+    __syncthreads();  // the log was written by other lanes, through global memory
     if (nlog <= a.vislog_cap) {
       for (uint32_t i = lane; i < nlog; i += 64) {
         const uint32_t v = vlog[i];
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
     } else {
       for (uint32_t i = lane; i < a.vis_words; i += 64) vis[i] = 0u;
     }
-    __syncthreads();
+    EHX_ISYNC();
     if (a.exclude_self) {
       // repairConnectionsForUpdate: the node being updated is part of the graph and finds itself;
       // hnswlib filters it out of the results (and skips the level if nothing else is left)
@@ -355,9 +357,9 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
       }
       if (pos != kNone) {
         for (uint32_t i = lane; i < nR; i += 64) R2[i] = R[i];
-        __syncthreads();
+        EHX_ISYNC();
         for (uint32_t i = pos + lane; i + 1 < nR; i += 64) R[i] = R2[i + 1];
-        __syncthreads();
+        EHX_ISYNC();
         nR -= 1;
       }
       if (nR == 0) continue;  // level skipped: own list and entry for the next level unchanged
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
     if (lane == 0) o[0] = nk;
     if ((uint32_t)lane < nk) o[1 + lane] = (uint32_t)(kept[nk - 1 - lane] & 0xFFFFFFFFull) >> 1;
     cur = (uint32_t)(kept[0] & 0xFFFFFFFFull) >> 1;
-    __syncthreads();
+    EHX_ISYNC();
   }
 }
 
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(64) void update_neigh_kernel(const InsertArgs a, co
     }
     key = wsort64(key, lane);
     batch[lane] = key;
-    __syncthreads();
+    EHX_ISYNC();
     if ((uint32_t)lane < n_here) {
       const uint32_t pos = lb_lds(R, nR, key) + lane;
       if (pos < keep) R2[pos] = key;
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(64) void update_neigh_kernel(const InsertArgs a, co
       const uint32_t pos = j + lb_lds(batch, n_here, kj);
       if (pos < keep) R2[pos] = kj;
     }
-    __syncthreads();
+    EHX_ISYNC();
     nR = nR + n_here < keep ? nR + n_here : keep;
     uint64_t* t = R;
     R = R2;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# graph-path measurement suite (profiles/r01_p_graph_*): bench_graph on every dataset of DESIGN.md's table, the phase
+# graph-path measurement suite (profiles/r0N_*_graph_*): bench_graph on every dataset of DESIGN.md's table, the phase
 # timers (ablation build), a rocprofv3 kernel trace of one bench_graph run, an FETCH_SIZE pass of the same.
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
@@ -22,5 +22,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python scripts/rocpd_summary.py gpurun_out/prof/gpmc_$c > gpurun_out/prof/gpmc_${c}_summary.txt 2>&1; grep -h "graph_search" gpurun_out/prof/gpmc_${c}_summary.txt | cut -c1-170
 done
 find gpurun_out/prof -name "*.db" -size +20M -delete
+echo "== 6.25M x 128 (one of eight shards of configs[4])"
+timeout 400 python scripts/bench_graph.py --rows 6250000 --dims 128 --metric l2 --gpu-build --efs 50,200,800 --reps 5 > gpurun_out/graph_6250k128.jsonl 2> gpurun_out/g7.err; J gpurun_out/graph_6250k128.jsonl
 echo "== 10M x 768"
 timeout 500 python scripts/bench_graph.py --rows 10000000 --dims 768 --metric cosine --gpu-build --efs 100,400,1600 --reps 3 > gpurun_out/graph_10m768.jsonl 2> gpurun_out/g4.err; J gpurun_out/graph_10m768.jsonl

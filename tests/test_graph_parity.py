@@ -37,6 +37,9 @@ def _build(n, d, em, om, seed=0, M=16):
     (500, 19, 7, 3, (16,)),                 # residual distance path
     (4000, 64, 12, 100, (10, 300)),         # k > 48: searchKnn keeps max(ef, k) results (ef 10 -> 100)
     (2500, 32, 6, 300, (64,)),              # k spanning several 64-wide output passes
+    (3000, 96, 20, 10, (50,)),              # short rows: two rows per 4-lane group (wave_group_dists), every
+    (3000, 192, 20, 10, (50,)),             # paired row length once (32 and 64 above, 128 in the 10k case)
+    (3000, 256, 20, 10, (50,)),
 ])
 def test_strict_parity_on_oracle_graph(n, d, nq, k, efs, em, om):
     X, h, s, rng = _build(n, d, em, om, seed=n + d)
