@@ -106,6 +106,7 @@ struct ehx_space {
                                // the rows land beyond the published row count — and takes mu just to publish
   hipStream_t wstream = nullptr;  // the writers' stream (uploads, row statistics, derived copies)
   hipEvent_t wev = nullptr;       // blocking-sync event: a writer waiting for its stream sleeps instead of spinning
+  hipEvent_t sev[2] = {nullptr, nullptr};  // "upload out of staging half i has finished" (ping-pong staging)
                                   // inside the HIP runtime beside the threads that launch searches
   int device = 0;              // HIP device of this space's HBM state
   // Row sharding behind the C ABI (ehx_params.shards > 1): the PARENT keeps the key maps and no rows; global row g
@@ -323,6 +324,10 @@ struct ehx_space {
     wstream = nullptr;
     if (wev) (void)hipEventDestroy(wev);
     wev = nullptr;
+    for (auto& e : sev) {
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
     cap = 0;
     n = 0;
     g_n = 0;
@@ -585,7 +590,7 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
     HIP_TRY(hipMemcpyAsync(s->dInsLevels.p, h_lv.data(), P * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, P * vis_words * sizeof(uint32_t), st));
     InsertArgs a;
-    a.X = s->xf32();
+    a.X = s->x_half ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
     a.Xs = s->dXs;
     a.inv_norm = s->dInv;
     a.adj0 = s->dAdj0;
@@ -683,7 +688,7 @@ int graph_update(ehx_space* s, uint32_t id) {
   const int level = s->h_levels[id];
   int rc;
   InsertArgs a;
-  a.X = s->xf32();
+  a.X = s->x_half ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
   a.Xs = s->dXs;
   a.inv_norm = s->dInv;
   a.adj0 = s->dAdj0;
@@ -875,7 +880,7 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, q_rows, s->metric, s->dQ.p, st));
   GraphArgs a;
   a.Q = s->dQ.p;
-  a.X = s->xf32();
+  a.X = s->x_half ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
   a.Xs = s->dXs;
   a.inv_norm = s->dInv;
   a.adj0 = s->dAdj0;
@@ -1579,13 +1584,12 @@ void resolve_keys(ehx_space* s, size_t n, const char* const* keys, const size_t*
       (*ids)[i] = it->second;
       continue;
     }
-    auto f = fresh.find(k);
-    if (f != fresh.end()) {
-      (*ids)[i] = f->second;
+    auto f = fresh.try_emplace(k, next);  // (one hash for "seen in this batch?" and the insert)
+    if (!f.second) {
+      (*ids)[i] = f.first->second;
       continue;
     }
     (*ids)[i] = next;
-    fresh.emplace(k, next);
     new_keys->push_back(std::move(k));
     ++next;
   }
@@ -1859,6 +1863,7 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&s->wstream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&s->wev, hipEventBlockingSync | hipEventDisableTiming));
+  for (auto& e : s->sev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventBlockingSync | hipEventDisableTiming));
   if (!parent) {
     HIP_TRY(hipMalloc((void**)&s->dMaxSumsq, sizeof(float)));
     HIP_TRY(hipMemset(s->dMaxSumsq, 0, sizeof(float)));
@@ -1879,8 +1884,6 @@ int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metri
   if (dims == 0 || dims > (1u << 16)) return fail(EHX_EINVAL, "dims=%u out of range", dims);
   if (metric < EHX_METRIC_L2SQ || metric > EHX_METRIC_COSINE) return fail(EHX_EINVAL, "unknown metric %d", metric);
   if (dtype != EHX_DTYPE_F32 && dtype != EHX_DTYPE_F16) return fail(EHX_EUNSUPPORTED, "dtype %d not supported", dtype);
-  if (dtype == EHX_DTYPE_F16 && params && params->mode == EHX_MODE_GRAPH)
-    return fail(EHX_EUNSUPPORTED, "fp16 row storage is a flat-mode feature (graph mode stores fp32 rows)");
   for (size_t i = 0; i < name_len; ++i)
     if (name[i] == '\x01') return fail(EHX_EINVAL, "space names must not contain byte 0x01 (reserved for shards)");
   int rc = ehx_init(nullptr, 0);
@@ -2112,6 +2115,31 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
   return write(n, keys, klens, vecs);
 }
 
+// rows -> pinned staging (fp16 spaces: rounded to binary16, round-to-nearest-even, on the way); large slabs are split
+// over four threads
+static void stage_rows(char* dst, const float* src, size_t elems, bool half) {
+  auto work = [=](size_t e0, size_t e1) {
+    if (half) {
+      _Float16* h = (_Float16*)dst;
+      for (size_t e = e0; e < e1; ++e) h[e] = (_Float16)src[e];
+    } else {
+      memcpy(dst + e0 * sizeof(float), src + e0, (e1 - e0) * sizeof(float));
+    }
+  };
+  constexpr size_t kThreads = 4;
+  if (elems * sizeof(float) < (2u << 20)) {
+    work(0, elems);
+    return;
+  }
+  const size_t per = ((elems + kThreads - 1) / kThreads + 63) & ~(size_t)63;
+  std::thread th[kThreads - 1];
+  size_t started = 0;
+  for (size_t t = 1; t < kThreads && t * per < elems; ++t, ++started)
+    th[t - 1] = std::thread(work, t * per, std::min(elems, (t + 1) * per));
+  work(0, std::min(elems, per));
+  for (size_t t = 0; t < started; ++t) th[t].join();
+}
+
 // wait for a stream of the space: the writers' stream through the blocking event, any other by hipStreamSynchronize
 static int sync_stream(ehx_space* s, hipStream_t st) {
   if (st == s->wstream && s->wev) {
@@ -2128,7 +2156,7 @@ static int sync_stream(ehx_space* s, hipStream_t st) {
 static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n, hipStream_t st = nullptr) {
   if (!st) st = s->stream;
   if (s->dXs && n)
-    HIP_TRY(launch_make_search_copy(s->xf32(), s->dInv, row0, n, s->ld, s->metric, s->dXs, st));
+    HIP_TRY(launch_make_search_copy(s->dX, s->x_half, s->dInv, row0, n, s->ld, s->metric, s->dXs, st));
   if ((!s->has16 && !s->has8) || n == 0) return EHX_OK;  // (kept current whatever engine is selected right now)
   unsigned long long u = 0, u8 = 0;
   if (s->has16) {
@@ -2193,20 +2221,19 @@ static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>
   if (rc) return rc;
   // upload through pinned staging in slabs; rows may be non-contiguous (updates) so copy per row
   // (fp16 spaces: rows are rounded to binary16, round-to-nearest-even, while they are staged)
+  // Two staging halves, ping-pong: slab i is copied into its half (by up to four host threads — one core moves
+  // ~8 GB/s, a 25-MB chunk of copy.go's 8192 x 768 rows would spend 3 ms there) while slab i-1 is on the wire.
   const size_t row_bytes = (size_t)s->dims * s->esz;
   const size_t slab_rows = std::max<size_t>(1, std::min<size_t>(n, (8u << 20) / row_bytes));
-  if ((rc = ensure_stage(s, slab_rows * row_bytes))) return rc;
-  char* stage = (char*)s->hStage;
+  const size_t half_bytes = (slab_rows * row_bytes + 255) & ~(size_t)255;
+  if ((rc = ensure_stage(s, 2 * half_bytes))) return rc;
   uint64_t min_id = ~0ull, max_id = 0;
-  for (size_t i0 = 0; i0 < n; i0 += slab_rows) {
+  size_t slab = 0;
+  for (size_t i0 = 0; i0 < n; i0 += slab_rows, ++slab) {
     const size_t m = std::min(slab_rows, n - i0);
-    if (s->x_half) {
-      _Float16* h = (_Float16*)stage;
-      const float* src = vecs + i0 * s->dims;
-      for (size_t e = 0; e < m * s->dims; ++e) h[e] = (_Float16)src[e];
-    } else {
-      memcpy(stage, vecs + i0 * s->dims, m * row_bytes);
-    }
+    char* stage = (char*)s->hStage + (slab & 1) * half_bytes;
+    if (slab >= 2) HIP_TRY(hipEventSynchronize(s->sev[slab & 1]));  // the upload that last used this half
+    stage_rows(stage, vecs + i0 * s->dims, m * s->dims, s->x_half);
     // contiguous run of fresh ids -> one 2D copy; otherwise row by row
     bool contiguous = true;
     for (size_t i = 1; i < m; ++i)
@@ -2219,12 +2246,13 @@ static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>
         HIP_TRY(hipMemcpyAsync(s->xrow(ids[i0 + i]), stage + i * row_bytes, row_bytes,
                                hipMemcpyHostToDevice, ws));
     }
-    if ((rc = sync_stream(s, ws))) return rc;  // staging buffer is reused
+    HIP_TRY(hipEventRecord(s->sev[slab & 1], ws));
     for (size_t i = 0; i < m; ++i) {
       min_id = std::min(min_id, ids[i0 + i]);
       max_id = std::max(max_id, ids[i0 + i]);
     }
   }
+  // (the stream is waited for below, before the commit: both halves are free again when this call returns)
   // per-row statistics over the touched id range (idempotent for untouched rows in between)
   HIP_TRY(launch_row_stats(s->dX, s->x_half, min_id, max_id - min_id + 1, s->dims, s->ld, s->metric, s->dInv,
                            s->dRowp, s->dMaxSumsq, ws));

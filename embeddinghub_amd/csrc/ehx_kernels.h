@@ -681,8 +681,8 @@ hipError_t launch_row_stats(const void* X, int x_half, uint64_t row0, uint64_t n
 hipError_t launch_rowp_pad(float2* rowp, uint64_t row0, uint64_t n, hipStream_t st);
 // graph mode: rows [row0, row0+n) of the search copy (16-float blocks permuted for the four SSE partial
 // sums, cosine rows pre-normalised); must follow launch_row_stats (inv_norm)
-hipError_t launch_make_search_copy(const float* X, const float* inv_norm, uint64_t row0, uint64_t n, uint32_t ld,
-                                   int metric, float* Xs, hipStream_t st);
+hipError_t launch_make_search_copy(const void* X, bool x_half, const float* inv_norm, uint64_t row0, uint64_t n,
+                                   uint32_t ld, int metric, float* Xs, hipStream_t st);
 
 // fp16 storage: rows of an fp32 matrix (stride src_ld) rounded to nearest-even into rows ids[i] (or
 // row0+i when ids == nullptr) of the fp16 matrix, and one fp16 row widened back for Get

@@ -18,13 +18,9 @@
 // nodes of one batch do not see each other, the result depends on the batch size, and parity is
 // recall parity, not graph identity.
 //
-// All distances use the canonical (oracle-order) arithmetic; for cosine spaces rows are normalised on
-// the fly (x * inv_norm), i.e. exactly the vectors hnswlib would have stored.
+// All distances use the canonical (oracle-order) arithmetic and read the SEARCH COPY only (cosine rows normalised
+// there: exactly the vectors hnswlib would have stored) — the raw rows may be fp32 or binary16.
 #include "ehx_kernels.h"
-
-#ifndef EHX_INSERT_COOP
-#define EHX_INSERT_COOP 1  // construction searches read neighbour rows through the search copy (4-lane groups)
-#endif
 
 namespace ehx {
 
@@ -67,60 +63,71 @@ __device__ __forceinline__ uint32_t lb_lds(const uint64_t* a, uint32_t n, uint64
   return lo;
 }
 
-// canonical distance between two STORED rows (both normalised on the fly for cosine), one lane
-__device__ __forceinline__ float row_row_dist(int metric01, bool scale, const float* __restrict__ xa, float sa,
-                                              const float* __restrict__ xb, float sb, uint32_t dims) {
+// canonical distance between two STORED rows, one lane, both read from the SEARCH COPY (k_misc.hip: cosine rows
+// already normalised — the product hnswlib stores — and every 16-float block permuted so that piece j holds the four
+// inputs of SSE partial sum j in order).  Piece j of a block therefore feeds partial sum j with its four products one
+// after the other: the same additions in the same order as walking the raw rows 16 bytes at a time, and the kernels
+// here need neither the raw rows nor their norms (fp16 row storage: the search copy is made from the rounded rows).
+__device__ __forceinline__ float row_row_dist(int metric01, const float* __restrict__ xa, const float* __restrict__ xb,
+                                              uint32_t dims) {
   uint32_t body;
   if ((dims & 15u) == 0 || (dims & 3u) == 0) body = dims;
   else if (dims > 16) body = dims & ~15u;
   else if (dims > 4) body = dims & ~3u;
   else body = 0;
-  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
-  auto step = [&](float4 a, float4 b) {
-    if (scale) {
-      a.x = ex_mul(a.x, sa); a.y = ex_mul(a.y, sa); a.z = ex_mul(a.z, sa); a.w = ex_mul(a.w, sa);
-      b.x = ex_mul(b.x, sb); b.y = ex_mul(b.y, sb); b.z = ex_mul(b.z, sb); b.w = ex_mul(b.w, sb);
-    }
+  float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  auto step = [&](const float4 a, const float4 b, float& acc, int ncomp) {
     if (metric01 == 0) {
       const float d0 = ex_sub(a.x, b.x), d1 = ex_sub(a.y, b.y), d2 = ex_sub(a.z, b.z), d3 = ex_sub(a.w, b.w);
-      p0 = ex_add(p0, ex_mul(d0, d0)); p1 = ex_add(p1, ex_mul(d1, d1));
-      p2 = ex_add(p2, ex_mul(d2, d2)); p3 = ex_add(p3, ex_mul(d3, d3));
+      acc = ex_add(acc, ex_mul(d0, d0));
+      if (ncomp > 1) acc = ex_add(acc, ex_mul(d1, d1));
+      if (ncomp > 2) acc = ex_add(acc, ex_mul(d2, d2));
+      if (ncomp > 3) acc = ex_add(acc, ex_mul(d3, d3));
     } else {
-      p0 = ex_add(p0, ex_mul(a.x, b.x)); p1 = ex_add(p1, ex_mul(a.y, b.y));
-      p2 = ex_add(p2, ex_mul(a.z, b.z)); p3 = ex_add(p3, ex_mul(a.w, b.w));
+      acc = ex_add(acc, ex_mul(a.x, b.x));
+      if (ncomp > 1) acc = ex_add(acc, ex_mul(a.y, b.y));
+      if (ncomp > 2) acc = ex_add(acc, ex_mul(a.z, b.z));
+      if (ncomp > 3) acc = ex_add(acc, ex_mul(a.w, b.w));
     }
   };
-  // eight 16-byte pieces of both rows requested before the first is used (a one-piece-per-trip loop keeps
-  // ONE load in flight and pays the cache latency dims/4 times); same accumulation order
-  constexpr int RB = 8;
   const float4* a4 = (const float4*)xa;
   const float4* b4 = (const float4*)xb;
-  const uint32_t n4 = body / 4u;
-  uint32_t m = 0;
-  for (; m + RB <= n4; m += RB) {
-    float4 ra[RB], rb[RB];
+  const uint32_t n16 = body / 16u;
+  // two blocks (sixteen 16-byte pieces of both rows) requested before the first is used: a one-piece-per-trip
+  // loop keeps ONE load in flight and pays the cache latency dims/4 times
+  uint32_t t = 0;
+  for (; t + 2 <= n16; t += 2) {
+    float4 ra[8], rb[8];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      ra[i] = a4[m + i];
-      rb[i] = b4[m + i];
+    for (int i = 0; i < 8; ++i) {
+      ra[i] = a4[t * 4 + i];
+      rb[i] = b4[t * 4 + i];
     }
 #pragma unroll
-    for (int i = 0; i < RB; ++i) step(ra[i], rb[i]);
+    for (int i = 0; i < 8; ++i) step(ra[i], rb[i], p[i & 3], 4);
   }
-  for (; m < n4; ++m) step(a4[m], b4[m]);
-  float res = ex_add(ex_add(ex_add(p0, p1), p2), p3);
+  for (; t < n16; ++t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) step(a4[t * 4 + j], b4[t * 4 + j], p[j], 4);
+  }
+  const int rem4 = (int)((body & 15u) >> 2);  // 4-float pieces of a last, partial block: components 0..rem4-1
+  if (rem4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) step(a4[n16 * 4 + j], b4[n16 * 4 + j], p[j], rem4);
+  }
+  float res = ex_add(ex_add(ex_add(p[0], p[1]), p[2]), p[3]);
   if (body != dims) {
     float tail = 0.0f;
     for (uint32_t m = body; m < dims; ++m) {
-      const float a = scale ? ex_mul(xa[m], sa) : xa[m];
-      const float b = scale ? ex_mul(xb[m], sb) : xb[m];
+      const uint32_t pos = search_copy_pos(m);
       if (metric01 == 0) {
-        const float d = ex_sub(a, b);
+        const float d = ex_sub(xa[pos], xb[pos]);
         tail = ex_add(tail, ex_mul(d, d));
       } else {
-        tail = ex_add(tail, ex_mul(a, b));
+        tail = ex_add(tail, ex_mul(xa[pos], xb[pos]));
       }
     }
+    if (metric01 != 0 && body) return ex_sub(ex_add(ex_sub(1.0f, res), ex_sub(1.0f, tail)), 1.0f);  // see canon_dist
     res = body ? ex_add(res, tail) : tail;
   }
   if (metric01 != 0) res = ex_sub(1.0f, res);
@@ -134,7 +141,6 @@ __device__ __forceinline__ float row_row_dist(int metric01, bool scale, const fl
 __device__ __forceinline__ uint32_t select_heuristic(const InsertArgs& a, const uint64_t* cand, uint32_t nc,
                                                      uint32_t Msel, uint64_t* kept, int lane) {
   const int metric01 = a.metric == 0 ? 0 : 1;
-  const bool scale = a.metric == 2;
   if (nc < Msel) {
     for (uint32_t i = lane; i < nc; i += 64) kept[i] = cand[i];
     EHX_ISYNC();
@@ -148,8 +154,7 @@ __device__ __forceinline__ uint32_t select_heuristic(const InsertArgs& a, const 
     bool bad = false;
     if ((uint32_t)lane < nk) {
       const uint32_t rid = (uint32_t)(kept[lane] & 0xFFFFFFFFull) >> 1;
-      const float d = row_row_dist(metric01, scale, a.X + (size_t)rid * a.ld, scale ? a.inv_norm[rid] : 1.0f,
-                                   a.X + (size_t)cid * a.ld, scale ? a.inv_norm[cid] : 1.0f, a.dims);
+      const float d = row_row_dist(metric01, a.Xs + (size_t)rid * a.ld, a.Xs + (size_t)cid * a.ld, a.dims);
       bad = d < dq;
     }
     if (!__any(bad)) {
@@ -182,35 +187,17 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
   const uint32_t me = a.new_ids[p];
   const int my_level = a.new_levels[p];
   const int metric01 = a.metric == 0 ? 0 : 1;
-  const bool scale_x = a.metric == 2;
-  {  // the query is the new row itself, prepared the way hnswlib stores it
-    const float s = scale_x ? a.inv_norm[me] : 1.0f;
-    for (uint32_t i = lane; i < a.ld; i += 64) {
-      const float v = a.X[(size_t)me * a.ld + i];
-#if EHX_INSERT_COOP
-      qs[search_copy_pos(i)] = scale_x ? ex_mul(v, s) : v;  // permuted like the search copy
-#else
-      qs[i] = scale_x ? ex_mul(v, s) : v;
-#endif
-    }
-  }
+  // the query is the new row itself, prepared the way hnswlib stores it: its search-copy row (normalised for
+  // cosine, permuted like every row the distance passes read)
+  for (uint32_t i = lane; i < a.ld; i += 64) qs[i] = a.Xs[(size_t)me * a.ld + i];
   EHX_ISYNC();
 
-#if EHX_INSERT_COOP
-  // canonical distances of rows ids_l[0..count) to the new row: 16 rows per pass, one 4-lane group per row
-  // reading the search copy in coalesced 64-byte pieces (canon_dist_group_t, as k_graph.hip); lane p gets row p
+  // canonical distances of rows ids_l[0..count) to the new row: 4-lane groups reading the search copy in coalesced
+  // 64-byte pieces (wave_group_dists, as k_graph.hip); lane p gets row p
   auto lane_dist = [&](uint32_t count) -> float {
     return metric01 == 0 ? wave_group_dists<0>(qs, a.Xs, a.ld, a.dims, ids_l, count, lane)
                          : wave_group_dists<1>(qs, a.Xs, a.ld, a.dims, ids_l, count, lane);
   };
-#else
-  auto lane_dist = [&](uint32_t count) -> float {
-    if ((uint32_t)lane >= count) return __builtin_inff();
-    const uint32_t id = ids_l[lane];
-    const float xs = scale_x ? a.inv_norm[id] : 1.0f;
-    return canon_dist_lane(metric01, qs, a.X + (size_t)id * a.ld, xs, scale_x, a.dims);
-  };
-#endif
   auto list_of = [&](uint32_t node, int level, uint32_t* width) -> const uint32_t* {
     if (level == 0) {
       *width = a.M0;
@@ -411,8 +398,6 @@ __global__ __launch_bounds__(64) void insert_link_kernel(const InsertArgs a, con
     return;
   }
   const int metric01 = a.metric == 0 ? 0 : 1;
-  const bool scale = a.metric == 2;
-  const float ss = scale ? a.inv_norm[s] : 1.0f;
   for (uint32_t b = b0; b < b1; ++b) {
     const uint32_t nid = inc_ids[b];
     uint32_t nb = kNone;
@@ -426,8 +411,7 @@ __global__ __launch_bounds__(64) void insert_link_kernel(const InsertArgs a, con
     }
     // full: candidates = {new} u list with distances to s, heuristic with the level's max degree
     auto key_of = [&](uint32_t id) {
-      const float d = row_row_dist(metric01, scale, a.X + (size_t)id * a.ld, scale ? a.inv_norm[id] : 1.0f,
-                                   a.X + (size_t)s * a.ld, ss, a.dims);
+      const float d = row_row_dist(metric01, a.Xs + (size_t)id * a.ld, a.Xs + (size_t)s * a.ld, a.dims);
       return ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)id << 1);
     };
     if (cnt < 64) {
@@ -475,8 +459,6 @@ __global__ __launch_bounds__(64) void update_neigh_kernel(const InsertArgs a, co
   uint32_t* lst = level == 0 ? a.adj0 + (size_t)s * a.M0
                              : a.up_lists + ((size_t)a.up_start[s] + (uint32_t)(level - 1)) * a.M;
   const int metric01 = a.metric == 0 ? 0 : 1;
-  const bool scale = a.metric == 2;
-  const float ss = scale ? a.inv_norm[s] : 1.0f;
   const uint32_t keep = (c1 - c0) < a.ef ? (c1 - c0) : a.ef;
   uint32_t nR = 0;
   for (uint32_t base = c0; base < c1; base += 64) {
@@ -484,8 +466,7 @@ __global__ __launch_bounds__(64) void update_neigh_kernel(const InsertArgs a, co
     uint64_t key = kKeyInf;
     if ((uint32_t)lane < n_here) {
       const uint32_t id = cand_ids[base + lane];
-      const float d = row_row_dist(metric01, scale, a.X + (size_t)s * a.ld, ss, a.X + (size_t)id * a.ld,
-                                   scale ? a.inv_norm[id] : 1.0f, a.dims);
+      const float d = row_row_dist(metric01, a.Xs + (size_t)s * a.ld, a.Xs + (size_t)id * a.ld, a.dims);
       key = ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)id << 1);
     }
     key = wsort64(key, lane);

@@ -110,7 +110,8 @@ hipError_t launch_row_stats(const void* X, int x_half, uint64_t row0, uint64_t n
 // bytes, so a 4-lane group reads a block as ONE coalesced 64-byte piece and lane j gets exactly its
 // partial sum's inputs, in order.  Pad columns stay zero.
 namespace {
-__global__ __launch_bounds__(256) void make_search_copy_kernel(const float* __restrict__ X, const float* __restrict__ inv_norm,
+template <typename XT>
+__global__ __launch_bounds__(256) void make_search_copy_kernel(const XT* __restrict__ X, const float* __restrict__ inv_norm,
                                                                uint64_t row0, uint64_t n, uint32_t ld, int scale,
                                                                float* __restrict__ Xs) {
   const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // element index within the row range
@@ -118,18 +119,23 @@ __global__ __launch_bounds__(256) void make_search_copy_kernel(const float* __re
   const uint64_t r = row0 + e / ld;
   const uint32_t c = (uint32_t)(e % ld);                        // destination column
   const uint32_t blk = c & ~15u, j = (c >> 2) & 3u, i = c & 3u;
-  float v = X[r * ld + blk + 4 * i + j];
+  float v = (float)X[r * ld + blk + 4 * i + j];  // (binary16 rows: the rounded value, exactly)
   if (scale) v = ex_mul(v, inv_norm[r]);
   Xs[r * ld + c] = v;
 }
 }  // namespace
 
-hipError_t launch_make_search_copy(const float* X, const float* inv_norm, uint64_t row0, uint64_t n, uint32_t ld,
-                                   int metric, float* Xs, hipStream_t st) {
+hipError_t launch_make_search_copy(const void* X, bool x_half, const float* inv_norm, uint64_t row0, uint64_t n,
+                                   uint32_t ld, int metric, float* Xs, hipStream_t st) {
   if (n == 0) return hipSuccess;
   const uint64_t elems = n * ld;
-  hipLaunchKernelGGL(make_search_copy_kernel, dim3((uint32_t)((elems + 255) / 256)), dim3(256), 0, st, X, inv_norm, row0,
-                     n, ld, metric == 2 ? 1 : 0, Xs);
+  const dim3 grid((uint32_t)((elems + 255) / 256));
+  if (x_half)
+    hipLaunchKernelGGL(make_search_copy_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16*)X, inv_norm, row0, n,
+                       ld, metric == 2 ? 1 : 0, Xs);
+  else
+    hipLaunchKernelGGL(make_search_copy_kernel<float>, grid, dim3(256), 0, st, (const float*)X, inv_norm, row0, n, ld,
+                       metric == 2 ? 1 : 0, Xs);
   return hipGetLastError();
 }
 
