@@ -85,21 +85,22 @@ __device__ __forceinline__ float i8_score(const float4 P, const float4 qq, int v
   return __builtin_fmaf(P.x, t, K);
 }
 
-// Integer alarm level of a tile for one query: a lane's accumulator I can only belong to a row with
-// S_lower <= thr if  I >= level.  tp = (max|A|, max|C|, max|D|, min B) over the tile's rows (tile_params8):
-//   S_lower(r) >= Bmin*gamma - Dmax - Cmax*e_q - Amax*s_q*max(I, 0)
-// The level errs towards alarms (relative slack, one integer unit); INT_MIN = always alarm, INT_MAX = never.
-__device__ __forceinline__ int i8_alarm_level(const float4 tp, const float4 qq) {
+// Alarm threshold of a tile for one query, on the PRODUCT I * |A_r| (exact integer dot product times the row's own
+// step): an accumulator can only belong to a row with S_lower <= thr if  I * |A_r| >= K.  From
+//   S_lower(r) = B gamma + D + C e_q - |A_r| s_q I  >=  Bmin*gamma - Dmax - Cmax*e_q - |A_r| s_q I
+// with tp = (max|A|, max|C|, max|D|, min B) over the tile's rows (tile_params8):  K = (Bmin gamma - Dmax - Cmax e_q -
+// thr) / s_q.  The first version compared I against ONE integer per (tile, query), which has to assume the tile's
+// largest step: max|x/|x|| varies +-10 % between rows and the largest of 256 is 1.37 x the mean, so on 768-dim Gaussian
+// rows the level sat at 2.6 sigma instead of 3.6 and 99 % of the 32 x 32 blocks took the slow path for 0.14 candidates
+// per block (tests/test_i8_model.py reproduces the rates).  Per row the test costs a convert and a multiply per
+// accumulator and ~15 % of the blocks go on.  K errs towards alarms (relative slack); -inf = always, +inf = never.
+__device__ __forceinline__ float i8_alarm_k(const float4 tp, const float4 qq) {
   const float bg = tp.w * qq.z, ce = tp.y * qq.y;
   float num = bg - tp.z - ce - qq.w;
   num -= 1e-5f * (fabsf(bg) + tp.z + ce + fabsf(qq.w));
-  if (!(num > 0.0f)) return (int)0x80000000;                 // thr = +inf, NaN, or the bound is already below thr
-  const float den = tp.x * qq.x;
-  if (!(den > 0.0f)) return 0x7FFFFFFF;                      // no row of the tile depends on I: S_lower >= lo > thr
-  const float lev = num / den * (1.0f - 1e-5f) - 1.0f;
-  if (!(lev < 2.0e9f)) return 0x7FFFFFFF;
-  if (lev < -2.0e9f) return (int)0x80000000;
-  return (int)floorf(lev);
+  if (!(num > 0.0f)) return -__builtin_inff();              // thr = +inf, NaN, or the bound is already below thr
+  if (!(qq.x > 0.0f)) return __builtin_inff();              // the query's step is 0: S_lower does not depend on I
+  return num / qq.x * (1.0f - 1e-5f);
 }
 
 // What the flush path needs lives in LDS (written once per workgroup): the out-of-line flush takes no arguments.
@@ -300,26 +301,33 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       return;
     }
     const float4 tp = tp_cur;  // uniform: (max|A|, max|C|, max|D|, min B) of the tile's rows (loaded a tile ago)
-    const int lev0 = i8_alarm_level(tp, qq0), lev1 = i8_alarm_level(tp, qq1);
+    const float k0 = i8_alarm_k(tp, qq0), k1 = i8_alarm_k(tp, qq1);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
+      // |A_r| of this lane's 16 rows of the row block (the same rows for both query blocks)
+      const uint32_t rbase = (uint32_t)(wr * 128 + rb * 32) + 4u * h;
+      float aa[16];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) aa[reg] = fabsf(rp[rbase + (uint32_t)((reg & 3) + 8 * (reg >> 2))].x);
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        // ---- phase 1: the block's integer maximum per lane against the alarm level ----
+        // ---- phase 1: the largest I * |A_r| of the lane's 16 accumulators against the query's threshold ----
         const i32x16 c = acc[rb][cb];
-        const int m0 = max(max(c[0], c[1]), c[2]), m1 = max(max(c[3], c[4]), c[5]);
-        const int m2 = max(max(c[6], c[7]), c[8]), m3 = max(max(c[9], c[10]), c[11]);
-        const int m4 = max(max(c[12], c[13]), c[14]);
-        const int m = max(max(max(m0, m1), m2), max(max(m3, m4), c[15]));
-        const int lev = cb ? lev1 : lev0;
-        if (!__any(m >= lev)) continue;
-        // ---- phase 2: the accumulators at or above the alarm level, one per lane and trip ----
+        float p[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) p[reg] = (float)c[reg] * aa[reg];
+        const float m0 = fmaxf(fmaxf(p[0], p[1]), p[2]), m1 = fmaxf(fmaxf(p[3], p[4]), p[5]);
+        const float m2 = fmaxf(fmaxf(p[6], p[7]), p[8]), m3 = fmaxf(fmaxf(p[9], p[10]), p[11]);
+        const float m4 = fmaxf(fmaxf(p[12], p[13]), p[14]);
+        const float m = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), p[15]));
+        const float kq = cb ? k1 : k0;
+        if (!__any(m >= kq)) continue;
+        // ---- phase 2: the accumulators at or above the threshold, one per lane and trip ----
         const float4 qq = cb ? qq1 : qq0;
         const int ql = cb * 32 + i31;
-        const uint32_t rbase = (uint32_t)(wr * 128 + rb * 32) + 4u * h;
         uint32_t pend = 0u;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) pend |= (c[reg] >= lev) ? (1u << reg) : 0u;
+        for (int reg = 0; reg < 16; ++reg) pend |= (p[reg] >= kq) ? (1u << reg) : 0u;
         while (__any(pend != 0u)) {
           const bool hi = pend != 0u;
           int v = 0;

@@ -61,10 +61,11 @@ enum {
 };
 enum {
   EHX_DTYPE_F32 = 0, /* rows stored as given (the reference's std::vector<float>, index.h:14)                     */
-  EHX_DTYPE_F16 = 1  /* flat mode only: rows rounded to IEEE binary16 (nearest-even) when written and widened
-                        exactly to fp32 wherever they are read — results are those of an F32 space fed the
-                        rounded rows; halves the footprint of the stored rows (BASELINE.json configs[5]);
-                        the API still speaks fp32 (Get returns the widened stored values)                         */
+  EHX_DTYPE_F16 = 1  /* rows rounded to IEEE binary16 (nearest-even) when written and widened exactly to fp32
+                        wherever they are read — results are those of an F32 space fed the rounded rows; halves
+                        the footprint of the stored rows (BASELINE.json configs[5]); the API still speaks fp32
+                        (Get returns the widened stored values).  Graph mode: the fp32 search copy is made from
+                        the rounded rows (6 instead of 8 bytes per stored dimension)                              */
 };
 enum {
   EHX_MODE_FLAT = 0,  /* exhaustive scan on the matrix cores + canonical re-rank: exact kNN */

@@ -1,0 +1,20 @@
+#!/bin/bash
+# int8 scan with the alarm judged per row (I * |A_r|): parity tests, then A/B against the previous library
+# (embeddinghub_amd/lib/libehx_old.so, built from the parent commit)
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -q --timeout=300 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_gpu.log
+S="--graph-rows 0 --structured-rows 0 --no-cpu-baseline --no-f32-engine --check-queries 0"
+for v in "new:X=0:" "old:EHX_LIB=$PWD/embeddinghub_amd/lib/libehx_old.so:" "newb:X=0:" "oldb:EHX_LIB=$PWD/embeddinghub_amd/lib/libehx_old.so:" "m1new:X=0:--rows 1000000" "m1old:EHX_LIB=$PWD/embeddinghub_amd/lib/libehx_old.so:--rows 1000000"; do
+  name=${v%%:*}; rest=${v#*:}; envs=${rest%%:*}; args=${rest#*:}
+  env $envs timeout 300 python bench.py $S $args > gpurun_out/bench_$name.log 2>&1
+  tail -1 gpurun_out/bench_$name.log > gpurun_out/bench_$name.json
+  python - <<PY
+import json
+try:
+    r = json.loads(open("gpurun_out/bench_$name.json").read())
+    print("$name", "value", r["value"], "ms", r["ms_per_step"], "kernel_ms", r["roofline"]["kernel_ms"], "i8fb", r.get("i8_fallback_queries"), "host", r.get("host_pointer_path", {}).get("value"))
+except Exception as e:
+    print("$name parse failed", e); print(open("gpurun_out/bench_$name.log").read()[-1500:])
+PY
+done

@@ -272,3 +272,56 @@ def test_reference_update_test_in_graph_mode():  # index_test.cc:39-49 through t
     s.set("a", [0, -1, 0])
     assert s.knn_keys([0, 1, 0], 1) == [["b"]]
     s.drop()
+
+
+@pytest.mark.parametrize("em,om", METRICS)
+def test_fp16_row_storage_in_graph_mode(em, om):
+    """EHX_DTYPE_F16 graph spaces (BASELINE configs[5] rows behind a graph): rows are rounded to binary16 once, on Set;
+    the search copy is made from the rounded rows, so searching, building and Get behave exactly like an fp32 space
+    (and the oracle) fed the rounded rows."""
+    n, d, nq, k = 1800, 72, 24, 10
+    rng = np.random.default_rng(31)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Xh = X.astype(np.float16).astype(np.float32)
+    h = pyoracle.Hnsw(d, om, n)
+    h.add_rows(Xh)
+    # strict parity on the oracle's graph
+    s = ehx.Space.unique("gh", d, metric=em, mode=ehx.MODE_GRAPH, initial_capacity=n, build_batch=0xFFFFFFFF,
+                         dtype=ehx.DTYPE_F16)
+    s.set_batch(["k%d" % i for i in range(n)], X)
+    assert s.get("k7").tobytes() == Xh[7].tobytes()
+    l0, lv, upper = h.export_graph()
+    s.graph_import(l0, lv, upper, h.enterpoint, h.maxlevel)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    for ef in (10, 120):
+        h.set_ef(ef)
+        s.set_ef(ef)
+        labels, dists, counts, _, _ = h.search_batch(Q, k, threads=1)
+        ids, dist, cnt = s.knn(Q, k)
+        np.testing.assert_array_equal(cnt, counts)
+        np.testing.assert_array_equal(ids, labels)
+        assert dist.tobytes() == dists.tobytes()
+    s.drop()   # (the GPU build over fp16 rows: test_update_in_place_every_metric_and_row_type below)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("em,om", METRICS)
+def test_update_in_place_every_metric_and_row_type(em, om, dtype):
+    """updatePoint on cosine / inner-product spaces and on fp16 rows (the L2 / fp32 case has its own, longer test)"""
+    n, d = 700, 40
+    rng = np.random.default_rng(13)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    rnd = (lambda a: a.astype(np.float16).astype(np.float32)) if dtype == "f16" else (lambda a: a)
+    h = pyoracle.Hnsw(d, om, n)
+    h.add_rows(rnd(X))
+    b = ehx.Space.unique("gupd2", d, metric=em, mode=ehx.MODE_GRAPH, initial_capacity=n,
+                         dtype=ehx.DTYPE_F16 if dtype == "f16" else ehx.DTYPE_F32)
+    b.set_batch(["k%d" % i for i in range(n)], X)
+    _same_graph(b, h)
+    for i in (5, 300, h.enterpoint):
+        upd = rng.standard_normal(d).astype(np.float32)
+        b.set("k%d" % i, upd)
+        h.add(rnd(upd), i)   # addPoint with an existing label -> updatePoint
+        assert b.get("k%d" % i).tobytes() == rnd(upd).tobytes()
+        _same_graph(b, h)
+    b.drop()

@@ -1,9 +1,10 @@
 """CPU model of the int8 filter's score lower bound (host logic, no GPU, no oracle): the quantities make_scan8 /
-prep_queries8 (k_misc.hip) store and the expression i8_score / i8_alarm_level (k_flati8.hip) evaluate, restated in
+prep_queries8 (k_misc.hip) store and the expressions i8_score / i8_alarm_k (k_flati8.hip) evaluate, restated in
 numpy float32, checked against float64 distances on ordinary and adversarial data:
 
   * S_lower(r, q) mapped to a distance (D = u*S + v) never exceeds the true distance;
-  * the tile-level integer alarm level never hides a row whose S_lower is at or below the threshold.
+  * the alarm test (I * |A_r| against one threshold per tile and query) never hides a row whose S_lower is at or
+    below the threshold.
 
 The constants below are the kernels' (a change there must be mirrored here)."""
 import numpy as np
@@ -119,7 +120,8 @@ def test_lower_bound_never_exceeds_the_true_distance(d, metric):
 
 
 @pytest.mark.parametrize("metric", ["cosine", "ip", "l2"])
-def test_alarm_level_never_hides_a_hit(metric):
+def test_alarm_threshold_never_hides_a_hit(metric):
+    """i8_alarm_k: an accumulator belongs to a row with S_lower <= thr only if I * |A_r| >= K(tile, query)"""
     d = 256
     rng = np.random.default_rng(3)
     for name, X in _datasets(rng, d, n=256):            # one 256-row tile
@@ -131,20 +133,51 @@ def test_alarm_level_never_hides_a_hit(metric):
         t = (sq[None, :] * I.astype(f32)).astype(f32)
         K = (B[:, None] * g[None, :] + (C[:, None] * eq[None, :] + D[:, None]).astype(f32)).astype(f32)
         S = (A[:, None] * t + K).astype(f32)
-        Amax, Cmax, Dmax, Bmin = np.abs(A).max(), np.abs(C).max(), np.abs(D).max(), B.min()   # tile_params8
+        Cmax, Dmax, Bmin = np.abs(C).max(), np.abs(D).max(), B.min()                          # tile_params8
         for qj in range(Q.shape[0]):
             col = np.sort(S[:, qj])
             for thr in (col[0], col[5], col[40], col[-1], f32(np.inf), col[0] - f32(1.0)):
-                bg, ce = f32(Bmin * g[qj]), f32(Cmax * eq[qj])                                # i8_alarm_level
-                num = f32(f32(f32(bg - Dmax) - ce) - thr)
-                num = f32(num - f32(1e-5) * f32(abs(bg) + Dmax + ce + abs(thr))) if np.isfinite(thr) else f32(-np.inf)
-                den = f32(Amax * sq[qj])
-                if not (num > 0):
-                    level = -2 ** 31
-                elif not (den > 0):
-                    level = 2 ** 31 - 1
-                else:
-                    lev = f32(f32(num / den) * f32(1.0 - 1e-5) - f32(1.0))
-                    level = 2 ** 31 - 1 if not (lev < 2e9) else (-2 ** 31 if lev < -2e9 else int(np.floor(lev)))
+                kq = _alarm_k(Bmin, Cmax, Dmax, g[qj], eq[qj], sq[qj], thr)
+                prod = (I[:, qj].astype(f32) * np.abs(A)).astype(f32)                         # (float)I * |A_r|
                 hits = S[:, qj] <= thr
-                assert (I[hits, qj] >= level).all(), (name, metric, qj, float(thr))
+                assert (prod[hits] >= kq).all(), (name, metric, qj, float(thr))
+
+
+def _alarm_k(Bmin, Cmax, Dmax, g, eq, sq, thr):
+    bg, ce = f32(Bmin * g), f32(Cmax * eq)
+    num = f32(f32(f32(bg - Dmax) - ce) - thr)
+    num = f32(num - f32(1e-5) * f32(abs(bg) + Dmax + ce + abs(thr))) if np.isfinite(thr) else f32(-np.inf)
+    if not (num > 0):
+        return f32(-np.inf)
+    if not (sq > 0):
+        return f32(np.inf)
+    return f32(f32(num / sq) * f32(1.0 - 1e-5))
+
+
+def test_the_alarm_is_judged_per_row():
+    """Why the alarm compares I * |A_r| and not I against one integer per (tile, query): that integer has to assume the
+    tile's largest quantisation step.  768-dim Gaussian rows, threshold near the 256th best of 10 M rows: the
+    per-tile level sends nearly every 32 x 32 accumulator block down the slow path, the per-row product under a fifth
+    of them — for the same candidates."""
+    d, n = 768, 256 * 16
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((n, d)).astype(f32)
+    Q = rng.standard_normal((64, d)).astype(f32)
+    qi, sq, eq, g, u, v = _query_params(Q, "cosine", d)
+    xi, A, B, C, D = _row_params(X, "cosine", d)
+    thr = f32(1.0 - 0.1462)
+    I = xi @ qi.T
+    t = (sq[None, :] * I.astype(f32)).astype(f32)
+    S = (A[:, None] * t + (B[:, None] * g[None, :] + (C[:, None] * eq[None, :] + D[:, None]))).astype(f32)
+    per_tile = per_row = blocks = 0
+    for t0 in range(0, n, 256):
+        sl = slice(t0, t0 + 256)
+        Amax, Cmax, Dmax, Bmin = np.abs(A[sl]).max(), np.abs(C[sl]).max(), np.abs(D[sl]).max(), B[sl].min()
+        kq = np.array([_alarm_k(Bmin, Cmax, Dmax, g[j], eq[j], sq[j], thr) for j in range(Q.shape[0])], dtype=f32)
+        a_row = (I[sl].astype(f32) * np.abs(A[sl])[:, None]).astype(f32) >= kq[None, :]
+        a_tile = (I[sl].astype(f32) * Amax) >= kq[None, :]          # what one level per (tile, query) amounts to
+        assert (a_row | ~(S[sl] <= thr)).all()                      # every candidate raises the alarm
+        per_row += int(a_row.reshape(8, 32, 2, 32).any(axis=(1, 3)).sum())
+        per_tile += int(a_tile.reshape(8, 32, 2, 32).any(axis=(1, 3)).sum())
+        blocks += 16
+    assert per_tile / blocks > 0.9 and per_row / blocks < 0.25, (per_tile / blocks, per_row / blocks)
