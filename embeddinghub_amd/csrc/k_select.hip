@@ -300,11 +300,67 @@ __device__ __forceinline__ float rerank_floor(const Rerank256Args& a, uint32_t q
 }
 }  // namespace
 
-// fp32 rows: one wave per query, one candidate per lane — the lane walks its row with 16-byte loads through a
-// register ring (canon_dist_lane_t: 16-24 loads in flight per lane), the query sits in LDS
+// Canonical distances of 64 rows (one per lane: row `id`, garbage allowed when !valid) to the query q, for rows whose
+// length is a multiple of 32 floats.  The arithmetic is the lane-private walk's (canon_lane_step, piece after piece);
+// what changes is how the rows reach the lane.  A lane that loads its own row 16 bytes at a time makes every wave
+// load touch 64 different 128-byte lines, each needed eight times: with three ring blocks in flight per lane and four
+// waves on a CU that is 768 lines against a 256-line L1, and most of them are evicted before their eighth use
+// (measured: 0.41 ms for 1024 queries x 64 rows x 3 KB = 0.5 TB/s).  Here the wave loads the rows TOGETHER —
+// eight lanes per row take its next 128-byte line in one request, eight rows per load instruction — parks the
+// pieces in LDS and every lane then reads its own row's eight pieces back.  Piece p of row r sits at slot
+// p ^ ((r >> 1) & 7) of the row's line: the write is contiguous per instruction, the read conflict-free.  One chunk
+// (128 bytes of every row) is in flight while the previous one is accumulated.
+constexpr uint32_t kStageFloat4 = 64 * 8;  // 64 rows x 8 pieces (8 KB)
 template <int METRIC01, bool SCALE>
+__device__ __forceinline__ float wave_rows_dist_staged(const float* __restrict__ q_lds, const float* __restrict__ X,
+                                                       uint32_t ld, uint32_t dims, uint32_t id, bool valid, float xscale,
+                                                       float4* stage, int lane) {
+  const uint32_t n_chunks = dims / 32u;
+  const int sub = lane & 7, grp = lane >> 3;
+  const uint32_t my = valid ? id : 0u;
+  // the row this lane helps to load in instruction i is row i*8 + grp of the wave's 64
+#define EHX_SRC(i) \
+  ((const float4*)(X + (size_t)(uint32_t)__shfl((int)my, (i) * 8 + grp, 64) * ld) + (sub ^ ((((i) * 8 + grp) >> 1) & 7)))
+  const float4 *s0 = EHX_SRC(0), *s1 = EHX_SRC(1), *s2 = EHX_SRC(2), *s3 = EHX_SRC(3), *s4 = EHX_SRC(4),
+               *s5 = EHX_SRC(5), *s6 = EHX_SRC(6), *s7 = EHX_SRC(7);
+#undef EHX_SRC
+  const int key = (lane >> 1) & 7;
+  const float4* q4 = (const float4*)q_lds;
+  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+  float4 r0 = s0[0], r1 = s1[0], r2 = s2[0], r3 = s3[0], r4 = s4[0], r5 = s5[0], r6 = s6[0], r7 = s7[0];
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    // (one buffer is enough: the LDS executes a wave's accesses in order, so these writes land after the previous
+    // chunk's reads)
+    wave_lds_sync();
+    stage[0 * 64 + lane] = r0;
+    stage[1 * 64 + lane] = r1;
+    stage[2 * 64 + lane] = r2;
+    stage[3 * 64 + lane] = r3;
+    stage[4 * 64 + lane] = r4;
+    stage[5 * 64 + lane] = r5;
+    stage[6 * 64 + lane] = r6;
+    stage[7 * 64 + lane] = r7;
+    if (c + 1 < n_chunks) {  // the next 128 bytes of every row travel while this chunk is accumulated
+      const size_t o = (size_t)(c + 1) * 8;
+      r0 = s0[o], r1 = s1[o], r2 = s2[o], r3 = s3[o], r4 = s4[o], r5 = s5[o], r6 = s6[o], r7 = s7[o];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      canon_lane_step<METRIC01, SCALE>(stage[lane * 8 + (p ^ key)], q4[(size_t)c * 8 + p], xscale, p0, p1, p2, p3);
+  }
+  float res = ex_add(ex_add(ex_add(p0, p1), p2), p3);
+  if (METRIC01 != 0) res = ex_sub(1.0f, res);
+  return res;
+}
+
+// fp32 rows: one wave per query, one candidate per lane; rows of a multiple of 32 floats are loaded by the wave
+// together (wave_rows_dist_staged), others by the lane itself with 16-byte loads through a register ring
+// (canon_dist_lane_t); the query sits in LDS
+template <int METRIC01, bool SCALE, bool STAGED>
 __global__ __launch_bounds__(64) void rerank256_lane_kernel(const Rerank256Args a, uint32_t q_in_lds) {
   extern __shared__ __attribute__((aligned(16))) float qs[];
+  float4* stage = (float4*)(qs + (q_in_lds ? a.ld : 0u));  // [kStageFloat4] when `staged`
   const int lane = threadIdx.x;
   const uint32_t q = blockIdx.x;
   const float* qv = a.Q + (size_t)q * a.ld;
@@ -324,7 +380,10 @@ __global__ __launch_bounds__(64) void rerank256_lane_kernel(const Rerank256Args 
     const uint32_t id = (uint32_t)mk;
     const bool valid = mk != kKeyInf && id < a.n;
     float d = __builtin_inff();
-    if (valid) {
+    if (STAGED) {
+      const float xs = (SCALE && valid) ? a.inv_norm[id] : 1.0f;
+      d = wave_rows_dist_staged<METRIC01, SCALE>(qs, (const float*)a.X, a.ld, a.dims, id, valid, xs, stage, lane);
+    } else if (valid) {
       const float* xv = (const float*)a.X + (size_t)id * a.ld;
       const float xs = SCALE ? a.inv_norm[id] : 1.0f;
       d = q_in_lds ? canon_dist_lane_t<METRIC01, SCALE>(qs, xv, xs, a.dims)
@@ -385,11 +444,22 @@ hipError_t launch_rerank256(const Rerank256Args& a, hipStream_t st) {
     return hipGetLastError();
   }
   const size_t qbytes = (size_t)a.ld * sizeof(float);
-  const uint32_t in_lds = qbytes <= 48 * 1024 ? 1u : 0u;  // (very long rows: the query stays in global memory)
-  const size_t lds = in_lds ? qbytes : 0;
-  if (a.metric == 0) hipLaunchKernelGGL((rerank256_lane_kernel<0, false>), dim3(a.nq), dim3(64), lds, st, a, in_lds);
-  else if (a.metric == 1) hipLaunchKernelGGL((rerank256_lane_kernel<1, false>), dim3(a.nq), dim3(64), lds, st, a, in_lds);
-  else hipLaunchKernelGGL((rerank256_lane_kernel<1, true>), dim3(a.nq), dim3(64), lds, st, a, in_lds);
+  const uint32_t in_lds = qbytes <= 32 * 1024 ? 1u : 0u;  // (very long rows: the query stays in global memory)
+  static const bool allow_staged = [] {
+    const char* e = getenv("EHX_RERANK_STAGED");  // "0": every lane walks its own row (A/B runs)
+    return e ? atoi(e) != 0 : true;
+  }();
+  const uint32_t staged = (allow_staged && in_lds && (a.dims & 31u) == 0 && a.dims >= 32) ? 1u : 0u;
+  const size_t lds = (in_lds ? qbytes : 0) + (staged ? kStageFloat4 * sizeof(float4) : 0);
+#define EHX_RR(M, S)                                                                                              \
+  do {                                                                                                            \
+    if (staged) hipLaunchKernelGGL((rerank256_lane_kernel<M, S, true>), dim3(a.nq), dim3(64), lds, st, a, in_lds); \
+    else hipLaunchKernelGGL((rerank256_lane_kernel<M, S, false>), dim3(a.nq), dim3(64), lds, st, a, in_lds);       \
+  } while (0)
+  if (a.metric == 0) EHX_RR(0, false);
+  else if (a.metric == 1) EHX_RR(1, false);
+  else EHX_RR(1, true);
+#undef EHX_RR
   return hipGetLastError();
 }
 
