@@ -156,6 +156,8 @@ struct ehx_space {
   uint32_t g_entry = 0;
   int g_maxlevel = -1;
   DevBuf<uint32_t> dVisited;
+  bool vis_dirty = false;    // a search that clears its bitmaps with a memset BEFORE the kernel leaves them marked; the
+                             // visit-log mode needs them all-zero at launch
   // GPU-side insertion state
   uint64_t g_cap_rows = 0;       // rows the adjacency arrays are sized for
   uint64_t g_lists_cap = 0, g_lists_used = 0;  // upper-level lists (M ids each)
@@ -910,7 +912,11 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   HIP_TRY(hipEventRecord(s->ev[1], st));
   HIP_TRY(hipEventRecord(pr[0], st));
   // (inside the timed kernel region: clearing the bitmaps is part of what a batch costs, log or memset)
-  if (!log_now) HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, (size_t)nq * vis_words * sizeof(uint32_t), st));
+  if (log_now && s->vis_dirty)  // (the whole buffer: an earlier, larger batch may have marked words beyond this one's)
+    HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, s->dVisited.n * sizeof(uint32_t), st));
+  else if (!log_now)
+    HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, (size_t)nq * vis_words * sizeof(uint32_t), st));
+  s->vis_dirty = !log_now;
   HIP_TRY(launch_graph_search(a, st));
   HIP_TRY(hipEventRecord(pr[1], st));
   HIP_TRY(hipEventRecord(s->ev[2], st));
