@@ -92,5 +92,21 @@ class EmbeddingHubClient:
                                         embedding=None if embedding is None else pb.Embedding(values=embedding))
         return _finish(self._stub.NearestNeighbor.future(req), wait, lambda r: r.keys)
 
+    def multi_nearest_neighbor(self, space, num, embeddings=None, keys=None, vectors=None):
+        """The batched lookup of the reference's docs (`multi_nearest_neighbor(10, vectors=user_vecs)`,
+        docs/inference.md:17-22; never implemented there): one key list per embedding (or per key), in order, over
+        ONE MultiNearestNeighbor stream — the server answers what has accumulated as one device batch.  Needs this
+        package's server (the RPC is additive; the reference server answers UNIMPLEMENTED)."""
+        if vectors is not None and embeddings is None:
+            embeddings = vectors
+        if (embeddings is None) == (keys is None):
+            raise ValueError("exactly one of embeddings / keys")
+        if embeddings is not None:
+            reqs = (pb.NearestNeighborRequest(space=str(space), num=num, embedding=pb.Embedding(values=e))
+                    for e in embeddings)
+        else:
+            reqs = (pb.NearestNeighborRequest(space=str(space), num=num, key=str(k)) for k in keys)
+        return [list(r.keys) for r in self._stub.MultiNearestNeighbor(reqs)]
+
     def download(self, space):
         return ((r.key, r.embedding.values) for r in self._stub.Download(pb.DownloadRequest(space=str(space))))

@@ -53,6 +53,14 @@ METHODS = {
     "NearestNeighbor": ("NearestNeighborRequest", "NearestNeighborResponse", False, False),
     "Download": ("DownloadRequest", "DownloadResponse", False, True),
 }
+# Additive (NOT in the reference's proto): the batched lookup its docs promise (`multi_nearest_neighbor`,
+# embeddinghub/docs/inference.md:17-22) but the SDK and the server never got — a stream of NearestNeighbor requests
+# answered by a stream of responses in request order, built from the reference's own messages only.
+ADDITIVE_METHODS = {
+    "MultiNearestNeighbor": ("NearestNeighborRequest", "NearestNeighborResponse", True, True),
+}
+REFERENCE_METHODS = dict(METHODS)
+METHODS.update(ADDITIVE_METHODS)
 
 
 def _file_descriptor():

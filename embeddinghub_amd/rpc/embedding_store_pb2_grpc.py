@@ -21,7 +21,7 @@ class EmbeddingHubStub:
 
 
 class EmbeddingHubServicer:
-    """Subclass and implement the nine methods (server.h:24-59)."""
+    """Subclass and implement the nine methods (server.h:24-59) and the additive MultiNearestNeighbor."""
 
 
 def add_EmbeddingHubServicer_to_server(servicer, server):

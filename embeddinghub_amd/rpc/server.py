@@ -1,7 +1,8 @@
 """The embeddingstore gRPC service over the MI355X engine.
 
 Replaces embeddinghub/embeddingstore/server.cc:65-268 (EmbeddingHubService) — same nine RPCs, same
-status codes and messages — with the engine's spaces behind it instead of RocksDB + hnswlib:
+status codes and messages — with the engine's spaces behind it instead of RocksDB + hnswlib (plus ONE additive RPC,
+MultiNearestNeighbor: the batched lookup the reference documents, docs/inference.md:17-22, and never shipped):
 
   * unknown space -> NOT_FOUND "Not found" (server.cc:88, 103, 122, 140, 160, 178, 222);
   * NearestNeighbor: exactly one of key / embedding, else INVALID_ARGUMENT with the reference's texts
@@ -23,6 +24,7 @@ The servicer talks to a *store* (create_space / get_space / delete_space returni
 set / set_batch / get / freeze / len / key_of / nearest); `EngineStore` is the engine-backed one.
 """
 import argparse
+import queue
 import sys
 import threading
 from concurrent import futures
@@ -86,6 +88,10 @@ class EngineSpace:
         if code == 5:
             raise KeyNotFound()
         return keys
+
+    def nearest_many(self, num, embeddings):
+        """by-embedding lookups of one stream window as ONE engine call (n x dims matrix -> n key lists)"""
+        return self._s.knn_keys(np.asarray(embeddings, dtype=np.float32).reshape(-1, self.dims), num)
 
     def drop(self):
         self._s.drop()
@@ -207,6 +213,20 @@ class EmbeddingHubService(pb_grpc.EmbeddingHubServicer):
             yield pb.MultiGetResponse(embedding=pb.Embedding(values=[] if v is None else v.tolist()))
 
     def NearestNeighbor(self, request, context):
+        sp, has_key = self._nn_validate(request, context)
+        try:
+            if has_key:
+                keys = sp.nearest(request.num, key=request.key)
+            else:
+                keys = sp.nearest(request.num, embedding=self._checked(sp, request.embedding, context))
+        except KeyNotFound:
+            context.abort(grpc.StatusCode.NOT_FOUND, "Not found")
+        return pb.NearestNeighborResponse(keys=keys)
+
+    MULTI_NN_WINDOW = 1024  # requests of one stream answered by one engine call (the bench's batch size)
+
+    def _nn_validate(self, request, context):
+        """the checks of NearestNeighbor (server.cc:178-189), shared by the unary and the streamed form"""
         sp = self._space(request.space, context)
         has_key = request.key != ""
         has_vec = len(request.embedding.values) != 0
@@ -216,14 +236,63 @@ class EmbeddingHubService(pb_grpc.EmbeddingHubServicer):
             context.abort(grpc.StatusCode.INVALID_ARGUMENT, "Key or embedding must be set")
         if request.num < 0:
             context.abort(grpc.StatusCode.INVALID_ARGUMENT, "num must not be negative")
-        try:
-            if has_key:
-                keys = sp.nearest(request.num, key=request.key)
-            else:
-                keys = sp.nearest(request.num, embedding=self._checked(sp, request.embedding, context))
-        except KeyNotFound:
-            context.abort(grpc.StatusCode.NOT_FOUND, "Not found")
-        return pb.NearestNeighborResponse(keys=keys)
+        return sp, has_key
+
+    def MultiNearestNeighbor(self, request_iterator, context):
+        """Additive RPC (embedding_store_pb2.ADDITIVE_METHODS): NearestNeighbor over a stream, answers in request
+        order.  Requests are taken off the stream as they arrive — a reader thread feeds a queue, so a client that
+        waits for an answer before sending its next request is served at once — and whatever has accumulated (up to
+        MULTI_NN_WINDOW) is answered together: by-embedding requests of one (space, num) go to the engine as ONE batch
+        (`nearest_many`), by-key requests one by one.  Every request gets the unary RPC's checks; the first failing one
+        ends the stream with the unary RPC's status."""
+        inbox = queue.Queue(maxsize=4 * self.MULTI_NN_WINDOW)
+        end = object()
+
+        def reader():
+            try:
+                for req in request_iterator:
+                    inbox.put(req)
+            except Exception as exc:  # noqa: BLE001  (a cancelled stream: hand the error to the consumer)
+                inbox.put(exc)
+            inbox.put(end)
+        threading.Thread(target=reader, daemon=True).start()
+        done = False
+        while not done:
+            window = [inbox.get()]
+            while len(window) < self.MULTI_NN_WINDOW:
+                try:
+                    window.append(inbox.get_nowait())
+                except queue.Empty:
+                    break
+            if window[-1] is end:
+                done = True
+                window.pop()
+            for item in window:
+                if isinstance(item, Exception):
+                    context.abort(grpc.StatusCode.CANCELLED, "request stream failed: %r" % (item,))
+            answers = [None] * len(window)
+            groups = {}  # (space name, num) -> (space, [positions], [vectors])
+            for pos, req in enumerate(window):
+                sp, has_key = self._nn_validate(req, context)
+                if has_key:
+                    try:
+                        answers[pos] = sp.nearest(req.num, key=req.key)
+                    except KeyNotFound:
+                        context.abort(grpc.StatusCode.NOT_FOUND, "Not found")
+                else:
+                    g = groups.setdefault((req.space, req.num), (sp, [], []))
+                    g[1].append(pos)
+                    g[2].append(self._checked(sp, req.embedding, context))
+            for (_, num), (sp, positions, vecs) in groups.items():
+                many = getattr(sp, "nearest_many", None)
+                if many is not None and len(vecs) > 1:
+                    for pos, keys in zip(positions, many(num, np.stack(vecs))):
+                        answers[pos] = keys
+                else:
+                    for pos, v in zip(positions, vecs):
+                        answers[pos] = sp.nearest(num, embedding=v)
+            for keys in answers:
+                yield pb.NearestNeighborResponse(keys=keys)
 
     def Download(self, request, context):
         sp = self._space(request.space, context)

@@ -63,6 +63,10 @@ class OracleSpace:
             return got[:num]
         return self._idx.approx_nearest(np.asarray(embedding, dtype=np.float32), min(num, len(self._vals)))
 
+    def nearest_many(self, num, embeddings):  # the servicer's batched branch (EngineSpace: one ehx_knn_keys call)
+        self.batched_calls = getattr(self, "batched_calls", 0) + 1
+        return [self.nearest(num, embedding=e) for e in np.asarray(embeddings, dtype=np.float32)]
+
 
 class OracleStore:
     def __init__(self):
@@ -189,8 +193,56 @@ def check_nearest_neighbor(c):  # index_test.cc:17-49 data through the RPC; serv
     assert list(c.nearest_neighbor(space, 1, embedding=[0, 1, 0])) == ["b"]
 
 
+def check_multi_nearest_neighbor(c):  # docs/inference.md:17-22 (`multi_nearest_neighbor`): the additive stream RPC
+    a, b = uuid.uuid4(), uuid.uuid4()
+    rng = np.random.default_rng(4)
+    c.create_space(a, 6)
+    c.create_space(b, 3)
+    XA = rng.standard_normal((300, 6)).astype(np.float32)
+    c.multiset(a, (("a%d" % i, XA[i].tolist()) for i in range(300)))
+    c.multiset(b, {"a": [0, 1, 0], "b": [1, 1, 0], "c": [1, 0, 0]})
+    Q = rng.standard_normal((70, 6)).astype(np.float32)
+    want = [list(c.nearest_neighbor(a, 4, embedding=q.tolist())) for q in Q]
+    assert c.multi_nearest_neighbor(a, 4, embeddings=[q.tolist() for q in Q]) == want     # answers in request order
+    assert c.multi_nearest_neighbor(a, 4, vectors=[q.tolist() for q in Q[:3]]) == want[:3]  # the documented keyword
+    assert c.multi_nearest_neighbor(b, 2, keys=["a", "c"]) == [["b", "c"], ["b", "a"]]      # by key: itself removed
+    assert c.multi_nearest_neighbor(a, 0, embeddings=[Q[0].tolist()]) == [[]]
+    assert c.multi_nearest_neighbor(a, 3, embeddings=[]) == []
+    # one stream may mix spaces, by-key and by-embedding requests, and different num
+    mixed = [pb.NearestNeighborRequest(space=str(a), num=4, embedding=pb.Embedding(values=Q[0].tolist())),
+             pb.NearestNeighborRequest(space=str(b), num=1, key="c"),
+             pb.NearestNeighborRequest(space=str(a), num=2, embedding=pb.Embedding(values=Q[1].tolist())),
+             pb.NearestNeighborRequest(space=str(b), num=2, embedding=pb.Embedding(values=[0, 1, 0]))]
+    got = [list(r.keys) for r in c._stub.MultiNearestNeighbor(iter(mixed))]
+    assert got == [want[0], ["b"], want[1][:2], ["a", "b"]]
+    # a client that waits for each answer before sending the next request is served at once (no window to fill)
+    import queue as _q
+    outbox, answers = _q.Queue(), []
+
+    def requests():
+        while True:
+            r = outbox.get()
+            if r is None:
+                return
+            yield r
+    stream = c._stub.MultiNearestNeighbor(requests())
+    for i in range(5):
+        outbox.put(pb.NearestNeighborRequest(space=str(a), num=4, embedding=pb.Embedding(values=Q[i].tolist())))
+        answers.append(list(next(stream).keys))
+    outbox.put(None)
+    assert list(stream) == [] and answers == want[:5]
+    # the unary RPC's checks and status codes, per request
+    for bad, code in ((pb.NearestNeighborRequest(space=str(a), num=1), grpc.StatusCode.INVALID_ARGUMENT),
+                      (pb.NearestNeighborRequest(space="no such space", num=1, key="x"), grpc.StatusCode.NOT_FOUND),
+                      (pb.NearestNeighborRequest(space=str(a), num=1, embedding=pb.Embedding(values=[1.0])),
+                       grpc.StatusCode.INVALID_ARGUMENT)):
+        with pytest.raises(grpc.RpcError) as e:
+            list(c._stub.MultiNearestNeighbor(iter([mixed[0], bad])))
+        assert e.value.code() == code
+
+
 SUITE = [check_set_get, check_immutable_set, check_multiset_get_multiget_download, check_multi_space,
-         check_status_codes, check_nearest_neighbor]
+         check_status_codes, check_nearest_neighbor, check_multi_nearest_neighbor]
 
 
 @pytest.mark.parametrize("check", SUITE, ids=lambda f: f.__name__)
@@ -206,6 +258,11 @@ def test_wire_contract_matches_the_reference_proto():
     assert pb.Embedding(values=[1.5]).SerializeToString() == b"\x0a\x04" + np.float32(1.5).tobytes()  # packed
     assert pb.DESCRIPTOR.package == "featureform.embedding.proto"
     assert sorted(m.name for m in pb.DESCRIPTOR.services_by_name["EmbeddingHub"].methods) == sorted(pb.METHODS)
+    # the reference's nine RPCs (embedding_store.proto:9-19) plus ONE additive stream built from its own messages
+    assert sorted(pb.REFERENCE_METHODS) == ["CreateSpace", "DeleteSpace", "Download", "FreezeSpace", "Get", "MultiGet",
+                                            "MultiSet", "NearestNeighbor", "Set"]
+    assert pb.ADDITIVE_METHODS == {"MultiNearestNeighbor": ("NearestNeighborRequest", "NearestNeighborResponse",
+                                                            True, True)}
 
 
 @pytest.mark.gpu
