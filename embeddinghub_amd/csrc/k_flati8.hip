@@ -93,7 +93,8 @@ __device__ __forceinline__ float i8_score(const float4 P, const float4 qq, int v
 // largest step: max|x/|x|| varies +-10 % between rows and the largest of 256 is 1.37 x the mean, so on 768-dim Gaussian
 // rows the level sat at 2.6 sigma instead of 3.6 and 99 % of the 32 x 32 blocks took the slow path for 0.14 candidates
 // per block (tests/test_i8_model.py reproduces the rates).  Per row the test costs a convert and a multiply per
-// accumulator and 18-50 % of the blocks go on (scripts/studies/int8_alarm_rates.py).  K errs towards alarms (relative slack); -inf = always, +inf = never.
+// accumulator and 18-50 % of the blocks go on (scripts/studies/int8_alarm_rates.py).  K errs towards alarms
+// (relative slack); -inf = always, +inf = never.
 __device__ __forceinline__ float i8_alarm_k(const float4 tp, const float4 qq) {
   const float bg = tp.w * qq.z, ce = tp.y * qq.y;
   float num = bg - tp.z - ce - qq.w;
