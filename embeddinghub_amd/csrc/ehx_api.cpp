@@ -20,6 +20,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -2139,11 +2140,19 @@ static void stage_rows(char* dst, const float* src, size_t elems, bool half) {
   }
   const size_t per = ((elems + kThreads - 1) / kThreads + 63) & ~(size_t)63;
   std::thread th[kThreads - 1];
-  size_t started = 0;
-  for (size_t t = 1; t < kThreads && t * per < elems; ++t, ++started)
-    th[t - 1] = std::thread(work, t * per, std::min(elems, (t + 1) * per));
+  size_t started = 0, done_to = std::min(elems, per);  // [0, per) is this thread's share
+  for (size_t t = 1; t < kThreads && t * per < elems; ++t) {
+    try {
+      th[t - 1] = std::thread(work, t * per, std::min(elems, (t + 1) * per));
+      ++started;
+      done_to = std::min(elems, (t + 1) * per);
+    } catch (const std::system_error&) {
+      break;  // no thread to be had (a process at its thread limit): the caller's thread copies the rest
+    }
+  }
   work(0, std::min(elems, per));
   for (size_t t = 0; t < started; ++t) th[t].join();
+  if (done_to < elems) work(done_to, elems);
 }
 
 // wait for a stream of the space: the writers' stream through the blocking event, any other by hipStreamSynchronize
