@@ -1,0 +1,74 @@
+"""CPU tests of bench.py's host-side helpers (no GPU): the oracle-truth reducer with its time box, the prefix
+consistency check used when the host cannot scan every row in time, the CPU-baseline sample sizing, the single JSON
+emit.  (The oracle is the checker here, as in bench.py itself.)"""
+import importlib.util
+import io
+import os
+import types
+from contextlib import redirect_stdout
+
+import numpy as np
+
+from oracle import pyoracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(bench)
+
+
+def _args(**kw):
+    base = dict(rows=40_000, dims=32, k=10, time_budget=300.0, cpu_sample_rows=1_000_000, cpu_sample_queries=16,
+                cpu_hnsw_rows=0)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def test_oracle_truth_is_the_exhaustive_scan_and_can_be_time_boxed():
+    args = _args()
+    Q = pyoracle.gen_rows(20250212, 0, 6, args.dims, normalize=True)
+    ids, dist, covered = bench.oracle_truth(args, Q, 10, pyoracle.METRIC_COSINE, chunk=7_000)  # ragged last chunk
+    assert covered == args.rows
+    X = pyoracle.gen_rows(20250211, 0, args.rows, args.dims, normalize=True)
+    oids, odist, _ = pyoracle.exhaustive(X, Q, 10, pyoracle.METRIC_COSINE)
+    np.testing.assert_array_equal(ids, oids.astype(np.uint64))
+    assert dist.tobytes() == odist.tobytes()
+    # a spent time box stops after the first chunk and says how far it got
+    _, _, part = bench.oracle_truth(args, Q, 10, pyoracle.METRIC_COSINE, chunk=7_000, max_seconds=0.0)
+    assert part == 7_000
+
+
+def test_prefix_consistency_accepts_the_exact_answer_and_flags_wrong_ones():
+    args = _args()
+    Q = pyoracle.gen_rows(20250212, 0, 8, args.dims, normalize=True)
+    full_i, full_d, _ = bench.oracle_truth(args, Q, 10, pyoracle.METRIC_COSINE, chunk=10_000)
+    half_i, half_d, cov = bench.oracle_truth(args, Q, 10, pyoracle.METRIC_COSINE, rows=20_000, chunk=10_000)
+    ok, frac = bench.prefix_consistent(full_i, full_d, half_i, half_d, cov)
+    assert ok and frac == 1.0
+    # an engine that lost a prefix row which belongs to the global top-k
+    q, j = next((q, j) for q in range(8) for j in range(9) if full_i[q, j] < cov)
+    bad_i, bad_d = full_i.copy(), full_d.copy()
+    bad_i[q, j] = args.rows - 1 - q
+    ok, frac = bench.prefix_consistent(bad_i, bad_d, half_i, half_d, cov)
+    assert not ok and frac < 1.0
+    # an engine whose distance for a prefix row differs in the last bit
+    bad_i, bad_d = full_i.copy(), full_d.copy()
+    bad_d[q, j] = np.nextafter(bad_d[q, j], np.float32(0))
+    ok, _ = bench.prefix_consistent(bad_i, bad_d, half_i, half_d, cov)
+    assert not ok
+
+
+def test_cpu_baseline_sample_is_sized_and_reported():
+    out = bench.cpu_baseline(_args(rows=120_000, dims=16), pyoracle.METRIC_COSINE)
+    assert out["sample_rows"] == 120_000 and out["cores"] == bench.host_cores() >= 1
+    assert out["kind"] == "port" and out["value"] > 0 and "hnsw" not in out
+    assert abs(out["value"] - out["value_on_sample"]) < 0.02 * out["value"]   # the sample IS the whole index here
+
+
+def test_the_json_line_is_emitted_once():
+    bench._EMIT = __import__("threading").Lock()
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.emit({"a": 1})
+        bench.emit({"a": 2})     # a watchdog firing after the main thread printed: nothing more
+    assert buf.getvalue() == '{"a": 1}\n'
