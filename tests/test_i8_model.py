@@ -181,3 +181,37 @@ def test_the_alarm_is_judged_per_row():
         per_tile += int(a_tile.reshape(8, 32, 2, 32).any(axis=(1, 3)).sum())
         blocks += 16
     assert per_tile / blocks > 0.9 and per_row / blocks < 0.25, (per_tile / blocks, per_row / blocks)
+
+
+def test_block_integer_alarm_is_valid_and_pays_once_rows_are_ordered_by_step():
+    """Groundwork for the next step of the epilogue (DESIGN.md open item 1): ONE integer level per (32-row block, query),
+    level = floor(K / max|A| of the block) - 1, is valid for any row order (no candidate below the level) and — once the
+    rows of a tile are ordered by their step — alarms about as rarely as the per-row product does, at a third of the
+    instructions.  In id order it is nearly as bad as the per-tile level."""
+    d, n = 768, 256 * 8
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((n, d)).astype(f32)
+    Q = rng.standard_normal((64, d)).astype(f32)
+    qi, sq, eq, g, u, v = _query_params(Q, "cosine", d)
+    xi, A, B, C, D = _row_params(X, "cosine", d)
+    thr = f32(1.0 - 0.1462)
+    I = xi @ qi.T
+    t = (sq[None, :] * I.astype(f32)).astype(f32)
+    S = (A[:, None] * t + (B[:, None] * g[None, :] + (C[:, None] * eq[None, :] + D[:, None]))).astype(f32)
+    rates = {}
+    for ordered in (False, True):
+        alarms = blocks = 0
+        for t0 in range(0, n, 256):
+            idx = np.arange(t0, t0 + 256)
+            if ordered:
+                idx = idx[np.argsort(np.abs(A[idx]), kind="stable")]   # the per-tile permutation
+            Cmax, Dmax, Bmin = np.abs(C[idx]).max(), np.abs(D[idx]).max(), B[idx].min()
+            kq = np.array([_alarm_k(Bmin, Cmax, Dmax, g[j], eq[j], sq[j], thr) for j in range(64)], dtype=np.float64)
+            Ablk = np.abs(A[idx]).reshape(8, 32).max(axis=1).astype(np.float64)
+            level = np.floor(kq[None, :] / Ablk[:, None]) - 1.0            # integer level per (block, query)
+            al = I[idx].reshape(8, 32, 64) >= level[:, None, :]
+            assert (al.reshape(256, 64) | ~(S[idx] <= thr)).all()           # valid in any order
+            alarms += int(al.reshape(8, 32, 2, 32).any(axis=(1, 3)).sum())
+            blocks += 16
+        rates[ordered] = alarms / blocks
+    assert rates[False] > 0.8 and rates[True] < 0.35, rates
