@@ -72,3 +72,26 @@ def test_the_json_line_is_emitted_once():
         bench.emit({"a": 1})
         bench.emit({"a": 2})     # a watchdog firing after the main thread printed: nothing more
     assert buf.getvalue() == '{"a": 1}\n'
+
+
+def test_engine_agreement_helpers_over_ten_batches():
+    import torch
+    assert bench.check_batches(2, 12, 10) == list(range(2, 12))
+    assert bench.check_batches(5, 25, 10) == list(range(5, 15))
+    assert bench.check_batches(1, 3, 10) == [1, 2, 0]                 # fewer resident batches than wanted: each once
+    g = torch.Generator().manual_seed(0)
+    data = {b: (torch.randint(0, 1000, (8, 10), generator=g), torch.rand((8, 10), generator=g),
+                torch.full((8,), 10, dtype=torch.int32)) for b in range(12)}
+    buf = [None]
+
+    def step(b):  # one reused output buffer, as the searcher has
+        buf[0] = tuple(t.clone() for t in data[b])
+        return buf[0]
+    kept = bench.keep_results(step, bench.check_batches(2, 12, 10), lambda: None)
+    assert sorted(kept) == list(range(2, 12))
+    assert bench.first_disagreement(step, kept, torch, lambda: None) is None
+    ids, dst, cnt = data[7]
+    dst2 = dst.clone()
+    dst2[3, 4] = torch.nextafter(dst2[3, 4], torch.tensor(2.0))       # one distance off by one ulp
+    data[7] = (ids, dst2, cnt)
+    assert bench.first_disagreement(step, kept, torch, lambda: None) == 7
