@@ -96,3 +96,33 @@ def test_cosine_rows_are_stored_normalised_like_hnswlib_python():
     want = f32(pyoracle.dist(pyoracle.METRIC_IP, q, xn))
     got = group_distance(pyoracle.METRIC_IP, make_search_copy(q, ld), make_search_copy(xn, ld), dims)
     assert got.tobytes() == want.tobytes()
+
+
+def test_staged_rerank_slots_are_consistent_and_conflict_free():
+    """wave_rows_dist_staged (k_select.hip): the wave loads 64 rows x 128 bytes together — instruction i, lane l takes
+    row i*8 + l//8, physical piece l%8, which holds logical piece (l%8) ^ ((row >> 1) & 7) — parks them at
+    stage[i*64 + l] and lane r reads logical piece p of its own row back from stage[r*8 + (p ^ ((r >> 1) & 7))].
+    Host-side restatement of that index arithmetic: every (row, piece) comes back from where it was put, and inside
+    each ds_read_b128 lane group (MI355X_MICROARCH.md, LDS table) the 16 reads touch 64 distinct banks."""
+    stage = {}
+    for i in range(8):
+        for l in range(64):
+            row, sub = i * 8 + l // 8, l % 8
+            stage[i * 64 + l] = (row, sub ^ ((row >> 1) & 7))          # (row, logical piece) stored in this slot
+    for r in range(64):
+        for p in range(8):
+            assert stage[r * 8 + (p ^ ((r >> 1) & 7))] == (r, p)
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
+              list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+              list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)),
+              list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+    for p in range(8):
+        for g in groups:
+            banks = set()
+            for lane in g:
+                addr = (lane * 8 + (p ^ ((lane >> 1) & 7))) * 16     # byte address of the 16-byte read
+                for b in range(4):
+                    bank = (addr // 4 + b) % 64
+                    assert bank not in banks, (p, lane)
+                    banks.add(bank)
+            assert len(banks) == 64
