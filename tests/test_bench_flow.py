@@ -215,3 +215,25 @@ def test_a_stuck_optional_leg_is_abandoned_by_the_watchdog(bench_on_stand_ins, m
     assert exits == [0]
     assert "graph_path" not in r and "watchdog" in r["optional_legs_skipped"]["graph_path"]
     assert r["exactness"]["recall_at_10"] == 1.0 and r["value"] > 0       # the headline part is all there
+
+
+def test_multi_rank_flow_rank0_prints_the_line(bench_on_stand_ins, monkeypatch):
+    """the path torchrun drives (WORLD_SIZE > 1): barriers, MAX-reduced time, no single-GPU legs — collectives stubbed"""
+    import torch.distributed as dist
+    calls = []
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setattr(dist, "init_process_group", lambda *a, **kw: calls.append("init"))
+    monkeypatch.setattr(dist, "barrier", lambda *a, **kw: calls.append("barrier"))
+    monkeypatch.setattr(dist, "all_reduce", lambda t, op=None: calls.append("all_reduce"))
+    monkeypatch.setattr(dist, "destroy_process_group", lambda *a, **kw: calls.append("destroy"))
+    real_tensor, real_device = torch.tensor, torch.device
+    monkeypatch.setattr(torch, "tensor", lambda *a, **kw: real_tensor(*a, **{k: v for k, v in kw.items() if k != "device"}))
+    monkeypatch.setattr(torch, "device", lambda *a, **kw: real_device("cpu"))
+    # the stand-in shard holds every row (shard_range stub), so the merged answer is the exact one
+    r = bench_on_stand_ins(SMALL + ["--gpus", "2"])
+    assert r["n_gpus"] == 2 and "row-shard x2" in r["config"]["parallelism"]
+    assert "graph_path" not in r and "cpu_baseline" not in r          # N = 1 legs
+    assert r["exactness"]["recall_at_10"] == 1.0
+    assert calls[0] == "init" and calls[-1] == "destroy" and "all_reduce" in calls and calls.count("barrier") >= 3
