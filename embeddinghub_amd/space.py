@@ -78,12 +78,11 @@ class Space:
     def set_batch(self, keys, vecs):
         v, pv = _f32(vecs)
         v = v.reshape(-1, self.dims)
-        ks = [k.encode() if isinstance(k, str) else bytes(k) for k in keys]
-        if len(ks) != v.shape[0]:
+        n, arr, lens, keep = marshal_keys(keys)
+        if n != v.shape[0]:
             raise ValueError("keys/vecs length mismatch")
-        arr = (C.c_char_p * len(ks))(*ks)
-        lens = (C.c_size_t * len(ks))(*[len(k) for k in ks])
-        check(self._L.ehx_set_batch(self._h, len(ks), arr, lens, pv))
+        check(self._L.ehx_set_batch(self._h, n, arr, lens, pv))
+        del keep
 
     def prepare_batch(self, keys, vecs):
         """Marshal a batch once (key arrays, contiguous fp32 rows) so that set_prepared() is ONE C call with no Python
@@ -91,12 +90,10 @@ class Space:
         where a Python writer thread would otherwise hold the GIL for milliseconds per chunk."""
         v, pv = _f32(vecs)
         v = v.reshape(-1, self.dims)
-        ks = [k.encode() if isinstance(k, str) else bytes(k) for k in keys]
-        if len(ks) != v.shape[0]:
+        n, arr, lens, keep = marshal_keys(keys)
+        if n != v.shape[0]:
             raise ValueError("keys/vecs length mismatch")
-        arr = (C.c_char_p * len(ks))(*ks)
-        lens = (C.c_size_t * len(ks))(*[len(k) for k in ks])
-        return (len(ks), arr, lens, pv, v, ks)
+        return (n, arr, lens, pv, v, keep)
 
     def set_prepared(self, prep):
         check(self._L.ehx_set_batch(self._h, prep[0], prep[1], prep[2], prep[3]))
@@ -249,6 +246,23 @@ class Space:
         out = (C.c_uint64 * 12)()
         check(self._L.ehx_graph_counters(self._h, out, 12))
         return tuple(int(v) for v in out)  # [4:] phase timers of -DEHX_GRAPH_PROFILE builds, else zeros
+
+
+def marshal_keys(keys):
+    """keys (str or bytes) -> (n, `const char* const*`, `const size_t*`, keep-alive) for ehx_set_batch: ONE joined
+    byte buffer and two numpy arrays (pointers = buffer address + running offsets, lengths) instead of a ctypes object
+    per key — 1.1 ms instead of 4.2 ms per 8192 keys, which is as long as the engine itself takes for such a chunk.
+    The returned keep-alive tuple owns the memory the pointers refer to: hold it until the call has returned."""
+    ks = [k.encode() if isinstance(k, str) else bytes(k) for k in keys]
+    n = len(ks)
+    lens = np.fromiter(map(len, ks), dtype=np.uint64, count=n)
+    blob = b"".join(ks)
+    buf = C.create_string_buffer(blob, len(blob) + 1)
+    ptrs = np.zeros(n, dtype=np.uint64)
+    if n:
+        np.cumsum(lens[:-1], out=ptrs[1:])
+        ptrs += np.uint64(C.addressof(buf))
+    return (n, ptrs.ctypes.data_as(C.POINTER(C.c_char_p)), lens.ctypes.data_as(C.POINTER(C.c_size_t)), (buf, ptrs, lens))
 
 
 def nearest_neighbor_rpc(space, num, key="", embedding=None):
