@@ -262,7 +262,8 @@ def marshal_keys(keys):
     if n:
         np.cumsum(lens[:-1], out=ptrs[1:])
         ptrs += np.uint64(C.addressof(buf))
-    return (n, ptrs.ctypes.data_as(C.POINTER(C.c_char_p)), lens.ctypes.data_as(C.POINTER(C.c_size_t)), (buf, ptrs, lens))
+    return (n, ptrs.ctypes.data_as(C.POINTER(C.c_char_p)), lens.ctypes.data_as(C.POINTER(C.c_size_t)),
+            (buf, ptrs, lens))
 
 
 def nearest_neighbor_rpc(space, num, key="", embedding=None):
