@@ -33,7 +33,33 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [HIPCC] + FLAGS + os.environ.get("EHX_DEFS", "").split() + ["-x", "hip"] + srcs + ["-o", LIB]
+    defs = os.environ.get("EHX_DEFS", "").split()
+    obj_dir = os.path.join(LIB_DIR, "obj%s" % os.environ.get("EHX_LIB_SUFFIX", ""))
+    os.makedirs(obj_dir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
+        os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    stamp = os.path.join(obj_dir, "defs.txt")  # objects built with other -D flags are not reused
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(defs):
+        force = True
+    compile_flags = [f for f in FLAGS if f != "-shared"]
+
+    def compile_one(src):
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+            return obj
+        cmd = [HIPCC] + compile_flags + defs + ["-x", "hip", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        return obj
+    # one hipcc per translation unit, side by side (the kernels are independent files; -fno-gpu-rdc)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    with open(stamp, "w") as f:
+        f.write(" ".join(defs))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

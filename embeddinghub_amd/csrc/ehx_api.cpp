@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <map>
 #include <random>
@@ -167,6 +168,8 @@ struct ehx_space {
   bool level_rng_seeded = false;
   uint64_t g_stale_updates = 0;  // rows overwritten in place after their insertion (no graph repair)
   DevBuf<uint32_t> dInsIds, dInsSel, dInsVislog, dItemTgt, dItemKind, dItemOff, dItemIds;
+  DevBuf<uint32_t> dLinkHead, dLinkNext, dLinkCount;  // bulk build: device-side link work items (k_insert.hip)
+  DevBuf<uint64_t> dLinkTouched;
   DevBuf<int32_t> dInsLevels, dItemLevel;
   unsigned long long* dGraphCounters = nullptr;  // n_dist, n_hops0, n_hops_up, n_prefetch_hit, [4..11] profile builds
 
@@ -299,6 +302,10 @@ struct ehx_space {
     dItemIds.release();
     dInsLevels.release();
     dItemLevel.release();
+    dLinkHead.release();
+    dLinkNext.release();
+    dLinkCount.release();
+    dLinkTouched.release();
     dQraw.release();
     dQ.release();
     dCand.release();
@@ -520,6 +527,13 @@ int graph_ensure_lists(ehx_space* s, uint64_t lists) {
   return EHX_OK;
 }
 
+// hnswlib addPoint for rows [id0, id0 + count), already in HBM.  Rounds of P rows (P = 1: hnswlib's sequential
+// insertion, the oracle's graph; P > 1: the analogue of its multi-threaded add_items) — and NO host work between a
+// round's kernels: the levels of all rows are drawn up front (the generator's sequence does not depend on the graph),
+// so the entry point and top level of every round are known to the host in advance; the search kernel writes the new
+// nodes' own lists and registers the reverse links per adjacency list on the device, the link kernel applies them.
+// The whole build is enqueued on the space's stream and waited for once.  (Round 2 paid three stream synchronisations,
+// a std::map regrouping on the host, five small uploads and a 5-GB bitmap memset per round.)
 int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
   if (count == 0) return EHX_OK;
   if (id0 != s->g_n)
@@ -537,146 +551,127 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
   }
   const double mult = 1.0 / log(1.0 * M);
   hipStream_t st = s->stream;
+  const uint64_t end = id0 + count;
+  // ---- levels of every new row (getRandomLevel: -log(U(0,1)) * mult, a fresh distribution object per draw) ----
+  std::vector<int32_t> h_lv(count);
+  std::vector<uint32_t> h_upstart(count);
+  uint64_t new_lists = 0;
+  int top = s->g_n ? s->g_maxlevel : 0;
+  for (uint64_t i = 0; i < count; ++i) {
+    std::uniform_real_distribution<double> distribution(0.0, 1.0);
+    const int level = (int)(-log(distribution(s->level_rng)) * mult);
+    h_lv[i] = level;
+    h_upstart[i] = level > 0 ? (uint32_t)(s->g_lists_used + new_lists) : 0xFFFFFFFFu;
+    new_lists += (uint64_t)level;
+    if (level > top) top = level;
+  }
+  if ((rc = graph_ensure_lists(s, s->g_lists_used + new_lists))) return rc;
+  s->g_lists_used += new_lists;
+  s->h_levels.insert(s->h_levels.end(), h_lv.begin(), h_lv.end());
+  // the new nodes' up_start entries and levels (their adjacency rows are still all-0xFF; nothing reaches a node
+  // before the round that links it)
+  if ((rc = s->dInsLevels.ensure(count))) return rc;
+  HIP_TRY(hipMemcpyAsync(s->dUpStart + id0, h_upstart.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(s->dInsLevels.p, h_lv.data(), count * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  // ---- round schedule ----
+  const uint64_t round_cap = batch > 1 ? batch : 4096;
+  auto round_size = [&](uint64_t g_n, uint64_t left) {
+    uint64_t P = 1;
+    if (batch != 1 && g_n >= 64) {
+      P = g_n / 16;
+      if (P > round_cap) P = round_cap;
+    }
+    return P > left ? left : P;
+  };
+  uint64_t n_rounds = 0, max_P = 1;
+  for (uint64_t g = s->g_n, pos = id0; pos < end; ++n_rounds) {
+    const uint64_t P = g ? round_size(g, end - pos) : 1;
+    if (P > max_P) max_P = P;
+    g += P;
+    pos += P;
+  }
   const uint32_t vis_words = (uint32_t)((s->cap + 31) / 32);
   const uint32_t vislog_cap = 32768;
-  uint64_t pos = id0;
-  const uint64_t end = id0 + count;
-  std::vector<uint32_t> h_ids, h_sel, h_tgt, h_kind, h_off, h_inc, h_upstart;
-  std::vector<int32_t> h_lv, h_tlevel;
+  const uint64_t max_pairs = max_P * (uint64_t)(top + 1) * M;
+  if (max_pairs >= 0xFFFFFFFFull) return fail(EHX_EUNSUPPORTED, "graph build: round too large");
+  // (the bitmaps are zero when allocated and every search clears the bits it set: no per-round memset)
+  if ((rc = s->dVisited.ensure(max_P * vis_words, true))) return rc;
+  if (s->vis_dirty) {  // a search that clears its bitmaps before its kernel left them marked
+    HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, s->dVisited.n * sizeof(uint32_t), st));
+    s->vis_dirty = false;
+  }
+  if ((rc = s->dInsVislog.ensure(max_P * (uint64_t)vislog_cap))) return rc;
+  if ((rc = s->dLinkHead.ensure(s->cap + s->g_lists_cap, true))) return rc;  // all zero between rounds
+  if ((rc = s->dLinkNext.ensure(max_pairs))) return rc;
+  if ((rc = s->dLinkTouched.ensure(max_pairs))) return rc;
+  if ((rc = s->dLinkCount.ensure(n_rounds))) return rc;
+  HIP_TRY(hipMemsetAsync(s->dLinkCount.p, 0, n_rounds * sizeof(uint32_t), st));
+  InsertArgs a;
+  a.X = s->x_half ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
+  a.Xs = s->dXs;
+  a.inv_norm = s->dInv;
+  a.adj0 = s->dAdj0;
+  a.up_start = s->dUpStart;
+  a.up_lists = s->dUpLists;
+  a.visited = s->dVisited.p;
+  a.vislog = s->dInsVislog.p;
+  a.new_ids = nullptr;
+  a.sel = nullptr;
+  a.ef = efc;
+  a.dims = s->dims;
+  a.ld = s->ld;
+  a.M = M;
+  a.M0 = M0;
+  a.vis_words = vis_words;
+  a.vislog_cap = vislog_cap;
+  a.metric = s->metric;
+  a.exclude_self = 0;
+  a.head_rows = (uint32_t)s->cap;
+  a.link_head = s->dLinkHead.p;
+  a.link_next = s->dLinkNext.p;
+  a.link_touched = (uint2*)s->dLinkTouched.p;
+  // EHX_BUILD_TRACE=1: progress to stderr (costs a stream synchronisation every 128 rounds)
+  const bool trace = getenv("EHX_BUILD_TRACE") != nullptr;
+  const auto t_build0 = std::chrono::steady_clock::now();
+  uint64_t pos = id0, round = 0;
   while (pos < end) {
-    // round size
-    uint64_t P = 1;
-    if (batch != 1 && s->g_n >= 64) {
-      P = s->g_n / 16;
-      const uint64_t cap = batch > 1 ? batch : 4096;
-      if (P > cap) P = cap;
-      if (P < 1) P = 1;
-    }
-    if (P > end - pos) P = end - pos;
-    // levels (getRandomLevel: -log(U(0,1)) * mult, a fresh distribution object per draw)
-    h_ids.resize(P);
-    h_lv.resize(P);
-    h_upstart.resize(P);
-    uint64_t new_lists = 0;
-    for (uint64_t i = 0; i < P; ++i) {
-      std::uniform_real_distribution<double> distribution(0.0, 1.0);
-      const int level = (int)(-log(distribution(s->level_rng)) * mult);
-      h_ids[i] = (uint32_t)(pos + i);
-      h_lv[i] = level;
-      h_upstart[i] = level > 0 ? (uint32_t)(s->g_lists_used + new_lists) : 0xFFFFFFFFu;
-      new_lists += (uint64_t)level;
-    }
-    if ((rc = graph_ensure_lists(s, s->g_lists_used + new_lists))) return rc;
-    s->g_lists_used += new_lists;
-    // the new nodes' own up_start entries (their adjacency rows are still all-0xFF)
-    HIP_TRY(hipMemcpyAsync(s->dUpStart + pos, h_upstart.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (uint64_t i = 0; i < P; ++i) s->h_levels.push_back(h_lv[i]);
     if (s->g_n == 0) {  // very first node: becomes the entry point, nothing to link
-      s->g_entry = h_ids[0];
+      s->g_entry = (uint32_t)pos;
       s->g_maxlevel = h_lv[0];
       s->g_n = 1;
       pos += 1;
-      if (P > 1) {  // keep the remaining draws: re-run them as their own round
-        // (P is 1 whenever the graph is empty, see the round-size rule above)
-      }
+      round += 1;
       continue;
     }
-    // ---- search + select on the device ----
-    const uint32_t max_sel_levels = (uint32_t)s->g_maxlevel + 1;
-    if ((rc = s->dInsIds.ensure(P))) return rc;
-    if ((rc = s->dInsLevels.ensure(P))) return rc;
-    if ((rc = s->dInsSel.ensure(P * max_sel_levels * (1 + M)))) return rc;
-    if ((rc = s->dVisited.ensure(P * vis_words, true))) return rc;
-    if ((rc = s->dInsVislog.ensure(P * (uint64_t)vislog_cap))) return rc;
-    HIP_TRY(hipMemcpyAsync(s->dInsIds.p, h_ids.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->dInsLevels.p, h_lv.data(), P * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, P * vis_words * sizeof(uint32_t), st));
-    InsertArgs a;
-    a.X = s->x_half ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
-    a.Xs = s->dXs;
-    a.inv_norm = s->dInv;
-    a.adj0 = s->dAdj0;
-    a.up_start = s->dUpStart;
-    a.up_lists = s->dUpLists;
-    a.visited = s->dVisited.p;
-    a.vislog = s->dInsVislog.p;
-    a.new_ids = s->dInsIds.p;
-    a.new_levels = s->dInsLevels.p;
-    a.sel = s->dInsSel.p;
-    a.ef = efc;
-    a.dims = s->dims;
-    a.ld = s->ld;
-    a.M = M;
-    a.M0 = M0;
-    a.vis_words = vis_words;
-    a.vislog_cap = vislog_cap;
-    a.max_sel_levels = max_sel_levels;
+    const uint64_t P = round_size(s->g_n, end - pos);
+    a.id0 = (uint32_t)pos;
+    a.new_levels = s->dInsLevels.p + (pos - id0);
+    a.max_sel_levels = (uint32_t)s->g_maxlevel + 1;
     a.entry_point = s->g_entry;
     a.max_level = s->g_maxlevel;
-    a.metric = s->metric;
-    a.exclude_self = 0;
+    a.link_count = s->dLinkCount.p + round;
     HIP_TRY(launch_insert_search(a, (uint32_t)P, st));
-    h_sel.resize(P * max_sel_levels * (1 + M));
-    HIP_TRY(hipMemcpyAsync(h_sel.data(), s->dInsSel.p, h_sel.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    // ---- work items for the link kernel (pure index shuffling) ----
-    h_tgt.clear();
-    h_tlevel.clear();
-    h_kind.clear();
-    h_off.clear();
-    h_inc.clear();
-    std::map<std::pair<int, uint32_t>, std::vector<uint32_t>> rev;  // (level, target) -> new ids in insertion order
-    for (uint64_t i = 0; i < P; ++i) {
-      const int top = std::min(h_lv[i], s->g_maxlevel);
-      for (int l = 0; l <= top; ++l) {
-        const uint32_t* o = &h_sel[(i * max_sel_levels + (uint32_t)l) * (1 + M)];
-        const uint32_t c = o[0];
-        h_tgt.push_back(h_ids[i]);
-        h_tlevel.push_back(l);
-        h_kind.push_back(1u);
-        h_off.push_back((uint32_t)h_inc.size());
-        for (uint32_t j = 0; j < c; ++j) {
-          h_inc.push_back(o[1 + j]);
-          rev[{l, o[1 + j]}].push_back(h_ids[i]);
-        }
-      }
-    }
-    for (auto& kv : rev) {
-      h_tgt.push_back(kv.first.second);
-      h_tlevel.push_back(kv.first.first);
-      h_kind.push_back(0u);
-      h_off.push_back((uint32_t)h_inc.size());
-      for (uint32_t v : kv.second) h_inc.push_back(v);
-    }
-    h_off.push_back((uint32_t)h_inc.size());
-    const uint32_t n_items = (uint32_t)h_tgt.size();
-    if (n_items) {
-      if ((rc = s->dItemTgt.ensure(n_items))) return rc;
-      if ((rc = s->dItemLevel.ensure(n_items))) return rc;
-      if ((rc = s->dItemKind.ensure(n_items))) return rc;
-      if ((rc = s->dItemOff.ensure(n_items + 1))) return rc;
-      if ((rc = s->dItemIds.ensure(h_inc.size() ? h_inc.size() : 1))) return rc;
-      HIP_TRY(hipMemcpyAsync(s->dItemTgt.p, h_tgt.data(), n_items * 4, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(s->dItemLevel.p, h_tlevel.data(), n_items * 4, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(s->dItemKind.p, h_kind.data(), n_items * 4, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(s->dItemOff.p, h_off.data(), (n_items + 1) * 4, hipMemcpyHostToDevice, st));
-      if (!h_inc.empty())
-        HIP_TRY(hipMemcpyAsync(s->dItemIds.p, h_inc.data(), h_inc.size() * 4, hipMemcpyHostToDevice, st));
-      HIP_TRY(launch_insert_link(a, n_items, s->dItemTgt.p, s->dItemLevel.p, s->dItemKind.p, s->dItemOff.p,
-                                 s->dItemIds.p, st));
-      HIP_TRY(hipStreamSynchronize(st));
-    }
+    const uint64_t pairs = P * a.max_sel_levels * M;
+    HIP_TRY(launch_insert_link_dev(a, (uint32_t)std::min<uint64_t>(pairs, 32768), st));
     // entry point / top level (hnswlib: a node with a higher level becomes the entry point)
     for (uint64_t i = 0; i < P; ++i) {
-      if (h_lv[i] > s->g_maxlevel) {
-        s->g_entry = h_ids[i];
-        s->g_maxlevel = h_lv[i];
+      const int lv = h_lv[pos - id0 + i];
+      if (lv > s->g_maxlevel) {
+        s->g_entry = (uint32_t)(pos + i);
+        s->g_maxlevel = lv;
       }
     }
     s->g_n += P;
     pos += P;
+    round += 1;
+    if (trace && ((round & 127) == 0 || pos >= end)) {
+      HIP_TRY(hipStreamSynchronize(st));
+      fprintf(stderr, "[ehx build] round %llu of %llu, rows %llu, %.1f s\n", (unsigned long long)round,
+              (unsigned long long)n_rounds, (unsigned long long)s->g_n,
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build0).count());
+    }
   }
+  HIP_TRY(hipStreamSynchronize(st));
   return EHX_OK;
 }
 

@@ -733,6 +733,14 @@ struct InsertArgs {
   uint32_t ef, dims, ld, M, M0, vis_words, vislog_cap, max_sel_levels, entry_point;
   int max_level, metric;
   uint32_t exclude_self;   // 1: repairConnectionsForUpdate (drop the node itself from the search results)
+  // ---- bulk build: the link work items are made on the device (no host between the search and the link kernel) ----
+  uint32_t id0;            // new_ids == nullptr: wave p inserts row id0 + p
+  uint32_t head_rows;      // list id of (node t, level l): l == 0 ? t : head_rows + up_start[t] + l - 1
+  uint32_t* link_head;     // [head_rows + upper lists], 0 = no incoming link this round; otherwise 1 + the pair
+                           // (wave p, level, slot) = (p * max_sel_levels + level) * M + slot registered last on the list
+  uint32_t* link_next;     // [P * max_sel_levels * M]: the pair registered before this one on the same list (same code)
+  uint2* link_touched;     // (target, level) of every list that received a pair, in arrival order
+  uint32_t* link_count;    // how many
 };
 size_t insert_lds_bytes(uint32_t ld, uint32_t ef);
 hipError_t launch_insert_search(const InsertArgs& a, uint32_t n_new, hipStream_t st);
@@ -740,6 +748,7 @@ hipError_t launch_update_neigh(const InsertArgs& a, uint32_t n_items, const uint
                                const uint32_t* cand_off, const uint32_t* cand_ids, hipStream_t st);
 hipError_t launch_insert_link(const InsertArgs& a, uint32_t n_items, const uint32_t* tgt, const int32_t* tlevel,
                               const uint32_t* kind, const uint32_t* inc_off, const uint32_t* inc_ids, hipStream_t st);
+hipError_t launch_insert_link_dev(const InsertArgs& a, uint32_t n_waves, hipStream_t st);
 
 // k-way merge of per-shard (dist, id) result lists [n_lists][nq][k] -> [nq][k]; an id of list l enters as
 // id * id_mul + l * id_step (row-sharded spaces: local row -> global row = local * G + shard)

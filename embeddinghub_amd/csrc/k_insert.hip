@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
   uint32_t* vis = a.visited + (size_t)p * a.vis_words;
   uint32_t* vlog = a.vislog + (size_t)p * a.vislog_cap;
 
-  const uint32_t me = a.new_ids[p];
+  const uint32_t me = a.new_ids ? a.new_ids[p] : a.id0 + p;
   const int my_level = a.new_levels[p];
   const int metric01 = a.metric == 0 ? 0 : 1;
   // the query is the new row itself, prepared the way hnswlib stores it: its search-copy row (normalised for
@@ -207,9 +207,11 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
     return a.up_lists + ((size_t)a.up_start[node] + (uint32_t)(level - 1)) * a.M;
   };
 
-  uint32_t* out = a.sel + (size_t)p * (a.max_sel_levels * (1 + a.M));
-  for (uint32_t i = lane; i < a.max_sel_levels * (1 + a.M); i += 64) out[i] = (i % (1 + a.M)) == 0 ? 0u : kNone;
-  __syncthreads();  // (global memory handed between lanes — here: rewritten by other lanes later — keeps the real fence)
+  uint32_t* out = a.sel ? a.sel + (size_t)p * (a.max_sel_levels * (1 + a.M)) : nullptr;
+  if (out) {
+    for (uint32_t i = lane; i < a.max_sel_levels * (1 + a.M); i += 64) out[i] = (i % (1 + a.M)) == 0 ? 0u : kNone;
+    __syncthreads();  // (global memory handed between lanes — here: rewritten by other lanes later — keeps the real fence)
+  }
 
   // ---- greedy descent through the levels above the node's level (hnswlib addPoint) ----
   uint32_t cur = a.entry_point;
@@ -354,9 +356,28 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
     // heuristic over the (sorted) results; selection is always with M, even at level 0
     const uint32_t nk = select_heuristic(a, R, nR, a.M, kept, lane);
     // own list: farthest first (hnswlib pops the max-heap); next entry = the closest selected
-    uint32_t* o = out + (size_t)level * (1 + a.M);
-    if (lane == 0) o[0] = nk;
-    if ((uint32_t)lane < nk) o[1 + lane] = (uint32_t)(kept[nk - 1 - lane] & 0xFFFFFFFFull) >> 1;
+    if (out) {
+      uint32_t* o = out + (size_t)level * (1 + a.M);
+      if (lane == 0) o[0] = nk;
+      if ((uint32_t)lane < nk) o[1 + lane] = (uint32_t)(kept[nk - 1 - lane] & 0xFFFFFFFFull) >> 1;
+    }
+    if (a.link_head) {
+      // bulk build: the node writes its own list here (nothing reaches a node of this round before the link kernel
+      // has run: the graph the searches walk is the graph before the round) and registers one (list, new node) pair
+      // per selected neighbour — a linked list per adjacency list, heads in link_head, so the link kernel needs no
+      // host-side regrouping.  The order pairs arrive in is arbitrary; the link kernel applies them by ascending id.
+      uint32_t width;
+      uint32_t* own = const_cast<uint32_t*>(list_of(me, level, &width));
+      const uint32_t t = (uint32_t)lane < nk ? (uint32_t)(kept[nk - 1 - lane] & 0xFFFFFFFFull) >> 1 : kNone;
+      if ((uint32_t)lane < width) own[lane] = t;
+      if (t != kNone) {
+        const uint32_t lid = level == 0 ? t : a.head_rows + a.up_start[t] + (uint32_t)(level - 1);
+        const uint32_t pair = (p * a.max_sel_levels + (uint32_t)level) * a.M + (uint32_t)lane;
+        const uint32_t old = atomicExch(&a.link_head[lid], pair + 1u);
+        a.link_next[pair] = old;
+        if (old == 0u) a.link_touched[atomicAdd(a.link_count, 1u)] = make_uint2(t, (uint32_t)level);
+      }
+    }
     cur = (uint32_t)(kept[0] & 0xFFFFFFFFull) >> 1;
     EHX_ISYNC();
   }
@@ -375,9 +396,54 @@ hipError_t launch_insert_search(const InsertArgs& a, uint32_t n_new, hipStream_t
   return hipGetLastError();
 }
 
+// mutuallyConnectNewElement for ONE incoming id on one wave: the list `lst` (width entries, kNone-padded) of node s
+// receives nid — appended while there is room, otherwise re-selected with the heuristic over {nid} u list.
+// is_update: hnswlib's isUpdate branch (a link that already exists is left alone).
+__device__ __forceinline__ void link_incoming(const InsertArgs& a, uint32_t* lst, uint32_t width, uint32_t s,
+                                              uint32_t nid, bool is_update, uint64_t* cand, uint64_t* kept, int lane,
+                                              int metric01) {
+  uint32_t nb = kNone;
+  if ((uint32_t)lane < width) nb = lst[lane];
+  const uint32_t cnt = __builtin_popcountll(__ballot(nb != kNone));
+  if (is_update && __any(nb == nid)) return;  // isUpdate: the link already exists
+  if (cnt < width) {
+    if (lane == 0) lst[cnt] = nid;
+    __syncthreads();
+    return;
+  }
+  // full: candidates = {new} u list with distances to s, heuristic with the level's max degree
+  auto key_of = [&](uint32_t id) {
+    const float d = row_row_dist(metric01, a.Xs + (size_t)id * a.ld, a.Xs + (size_t)s * a.ld, a.dims);
+    return ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)id << 1);
+  };
+  if (cnt < 64) {
+    const uint32_t id = (uint32_t)lane < cnt ? nb : ((uint32_t)lane == cnt ? nid : kNone);
+    uint64_t key = kKeyInf;
+    if (id != kNone) key = key_of(id);
+    key = wsort64(key, lane);
+    cand[lane] = key;
+  } else {
+    // 64 list entries fill the wave: sort them, then slot the incoming key in at its rank (keys are distinct:
+    // the id is part of the key and the incoming id is not in the list)
+    uint64_t nkey = 0;
+    if (lane == 0) nkey = key_of(nid);
+    nkey = ((uint64_t)__shfl((int)(nkey >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)nkey, 0, 64);
+    const uint64_t key = wsort64(key_of(nb), lane);
+    const uint32_t rank = __builtin_popcountll(__ballot(key < nkey));
+    cand[(uint32_t)lane + ((uint32_t)lane >= rank ? 1u : 0u)] = key;
+    if (lane == 0) cand[rank] = nkey;
+  }
+  __syncthreads();
+  const uint32_t nk = select_heuristic(a, cand, cnt + 1, width, kept, lane);
+  // rewrite farthest first
+  if ((uint32_t)lane < width) lst[lane] = (uint32_t)lane < nk ? (uint32_t)(kept[nk - 1 - lane] & 0xFFFFFFFFull) >> 1 : kNone;
+  __syncthreads();
+}
+
 // One wave per work item w: target node tgt[w] at level tlevel[w] receives the new ids
 // inc_ids[inc_off[w] .. inc_off[w+1]) in that order.  kind[w] == 1: the target IS a new node and the
-// ids are its own selected list (already farthest first) — plain overwrite.
+// ids are its own selected list (already farthest first) — plain overwrite.  (Host-built items: single-row
+// Sets of an existing key, graph_update.)
 __global__ __launch_bounds__(64) void insert_link_kernel(const InsertArgs a, const uint32_t* __restrict__ tgt,
                                                          const int32_t* __restrict__ tlevel,
                                                          const uint32_t* __restrict__ kind,
@@ -398,43 +464,67 @@ __global__ __launch_bounds__(64) void insert_link_kernel(const InsertArgs a, con
     return;
   }
   const int metric01 = a.metric == 0 ? 0 : 1;
-  for (uint32_t b = b0; b < b1; ++b) {
-    const uint32_t nid = inc_ids[b];
-    uint32_t nb = kNone;
-    if ((uint32_t)lane < width) nb = lst[lane];
-    const uint32_t cnt = __builtin_popcountll(__ballot(nb != kNone));
-    if (kind[w] == 2 && __any(nb == nid)) continue;  // isUpdate: the link already exists
-    if (cnt < width) {
-      if (lane == 0) lst[cnt] = nid;
-      __syncthreads();
-      continue;
-    }
-    // full: candidates = {new} u list with distances to s, heuristic with the level's max degree
-    auto key_of = [&](uint32_t id) {
-      const float d = row_row_dist(metric01, a.Xs + (size_t)id * a.ld, a.Xs + (size_t)s * a.ld, a.dims);
-      return ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)id << 1);
-    };
-    if (cnt < 64) {
-      const uint32_t id = (uint32_t)lane < cnt ? nb : ((uint32_t)lane == cnt ? nid : kNone);
-      uint64_t key = kKeyInf;
-      if (id != kNone) key = key_of(id);
-      key = wsort64(key, lane);
-      cand[lane] = key;
-    } else {
-      // 64 list entries fill the wave: sort them, then slot the incoming key in at its rank (keys are distinct:
-      // the id is part of the key and the incoming id is not in the list)
-      uint64_t nkey = 0;
-      if (lane == 0) nkey = key_of(nid);
-      nkey = ((uint64_t)__shfl((int)(nkey >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)nkey, 0, 64);
-      const uint64_t key = wsort64(key_of(nb), lane);
-      const uint32_t rank = __builtin_popcountll(__ballot(key < nkey));
-      cand[(uint32_t)lane + ((uint32_t)lane >= rank ? 1u : 0u)] = key;
-      if (lane == 0) cand[rank] = nkey;
+  for (uint32_t b = b0; b < b1; ++b) link_incoming(a, lst, width, s, inc_ids[b], kind[w] == 2, cand, kept, lane, metric01);
+}
+
+// Bulk build: the link work items come from the search kernel's registrations.  Waves stride over the touched lists;
+// a wave gathers the list's chain of pairs (new node = id0 + pair / (max_sel_levels * M)), clears the head for the
+// next round, and applies the new ids in ASCENDING id order — the order of insertion, whatever order the pairs were
+// registered in: the graph after the round is a function of the searches' results only.
+constexpr uint32_t kIncCap = 1024;  // incoming ids of one list kept in LDS; a longer chain is re-walked per id
+__global__ __launch_bounds__(64) void insert_link_dev_kernel(const InsertArgs a) {
+  __shared__ uint64_t cand[65];
+  __shared__ uint64_t kept[64];
+  __shared__ uint32_t inc[kIncCap];
+  __shared__ uint32_t chain_len;
+  const int lane = threadIdx.x;
+  const int metric01 = a.metric == 0 ? 0 : 1;
+  const uint32_t n_items = *(volatile const uint32_t*)a.link_count;
+  const uint32_t per_node = a.max_sel_levels * a.M;
+  for (uint32_t w = blockIdx.x; w < n_items; w += gridDim.x) {
+    const uint2 tl = a.link_touched[w];
+    const uint32_t s = tl.x;
+    const int level = (int)tl.y;
+    const uint32_t width = level == 0 ? a.M0 : a.M;
+    uint32_t* lst = level == 0 ? a.adj0 + (size_t)s * a.M0
+                               : a.up_lists + ((size_t)a.up_start[s] + (uint32_t)(level - 1)) * a.M;
+    const uint32_t lid = level == 0 ? s : a.head_rows + a.up_start[s] + (uint32_t)(level - 1);
+    const uint32_t h0 = a.link_head[lid];
+    if (lane == 0) {
+      uint32_t n = 0;
+      for (uint32_t pr = h0; pr != 0u; pr = a.link_next[pr - 1u]) {
+        if (n < kIncCap) inc[n] = a.id0 + (pr - 1u) / per_node;
+        n += 1;
+      }
+      chain_len = n;
+      a.link_head[lid] = 0u;
     }
     __syncthreads();
-    const uint32_t nk = select_heuristic(a, cand, cnt + 1, width, kept, lane);
-    // rewrite farthest first
-    if ((uint32_t)lane < width) lst[lane] = (uint32_t)lane < nk ? (uint32_t)(kept[nk - 1 - lane] & 0xFFFFFFFFull) >> 1 : kNone;
+    const uint32_t c = chain_len;
+    uint32_t prev = 0;
+    for (uint32_t b = 0; b < c; ++b) {
+      // the smallest incoming id above the last one applied
+      uint32_t m = kNone;
+      if (c <= kIncCap) {
+        for (uint32_t i = lane; i < c; i += 64) {
+          const uint32_t v = inc[i];
+          if ((b == 0 || v > prev) && v < m) m = v;
+        }
+      } else if (lane == 0) {
+        for (uint32_t pr = h0; pr != 0u; pr = a.link_next[pr - 1u]) {
+          const uint32_t v = a.id0 + (pr - 1u) / per_node;
+          if ((b == 0 || v > prev) && v < m) m = v;
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)m, o, 64);
+        m = other < m ? other : m;
+      }
+      m = wave_uniform(m);
+      prev = m;
+      link_incoming(a, lst, width, s, m, false, cand, kept, lane, metric01);
+    }
     __syncthreads();
   }
 }
@@ -503,6 +593,12 @@ hipError_t launch_insert_link(const InsertArgs& a, uint32_t n_items, const uint3
                               const uint32_t* kind, const uint32_t* inc_off, const uint32_t* inc_ids, hipStream_t st) {
   if (n_items == 0) return hipSuccess;
   hipLaunchKernelGGL(insert_link_kernel, dim3(n_items), dim3(64), 0, st, a, tgt, tlevel, kind, inc_off, inc_ids);
+  return hipGetLastError();
+}
+
+hipError_t launch_insert_link_dev(const InsertArgs& a, uint32_t n_waves, hipStream_t st) {
+  if (n_waves == 0) return hipSuccess;
+  hipLaunchKernelGGL(insert_link_dev_kernel, dim3(n_waves), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 

@@ -9,6 +9,9 @@
 
 namespace ehx {
 
+// work-items per dispatch (a grid dimension holds fewer than 2^32): launches that scale with the row count go in chunks
+constexpr uint64_t kMaxWorkItems = 1ull << 31;
+
 namespace {
 // one thread walks one row sequentially: the summation ORDER is the contract here
 template <typename XT>
@@ -128,14 +131,20 @@ __global__ __launch_bounds__(256) void make_search_copy_kernel(const XT* __restr
 hipError_t launch_make_search_copy(const void* X, bool x_half, const float* inv_norm, uint64_t row0, uint64_t n,
                                    uint32_t ld, int metric, float* Xs, hipStream_t st) {
   if (n == 0) return hipSuccess;
-  const uint64_t elems = n * ld;
-  const dim3 grid((uint32_t)((elems + 255) / 256));
-  if (x_half)
-    hipLaunchKernelGGL(make_search_copy_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16*)X, inv_norm, row0, n,
-                       ld, metric == 2 ? 1 : 0, Xs);
-  else
-    hipLaunchKernelGGL(make_search_copy_kernel<float>, grid, dim3(256), 0, st, (const float*)X, inv_norm, row0, n, ld,
-                       metric == 2 ? 1 : 0, Xs);
+  // A dispatch holds fewer than 2^32 work-items per grid dimension: one thread per element of a 10 M x 768 fill is
+  // 7.7 * 10^9 — launched in one go (round 2 did) only the first (n * ld) mod 2^32 elements, 4.4 M rows, were written
+  // and the rest of the search copy was whatever the allocation held.  Row chunks of at most 2^31 elements each.
+  const uint64_t max_rows = kMaxWorkItems / ld;
+  for (uint64_t r0 = 0; r0 < n; r0 += max_rows) {
+    const uint64_t m = n - r0 < max_rows ? n - r0 : max_rows;
+    const dim3 grid((uint32_t)((m * ld + 255) / 256));
+    if (x_half)
+      hipLaunchKernelGGL(make_search_copy_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16*)X, inv_norm,
+                         row0 + r0, m, ld, metric == 2 ? 1 : 0, Xs);
+    else
+      hipLaunchKernelGGL(make_search_copy_kernel<float>, grid, dim3(256), 0, st, (const float*)X, inv_norm, row0 + r0, m,
+                         ld, metric == 2 ? 1 : 0, Xs);
+  }
   return hipGetLastError();
 }
 
@@ -189,13 +198,17 @@ hipError_t launch_make_scan16(const void* X, int x_half, uint64_t row0, uint64_t
                               uint32_t ld16, int metric, __half* X16, float2* rowp16, unsigned long long* n_unsafe,
                               hipStream_t st) {
   if (n == 0) return hipSuccess;
-  const dim3 grid((uint32_t)((n + 3) / 4));
-  if (x_half)
-    hipLaunchKernelGGL(make_scan16_kernel<__half>, grid, dim3(256), 0, st, (const __half*)X, row0, n, dims, ld, ld16,
-                       metric, X16, rowp16, n_unsafe);
-  else
-    hipLaunchKernelGGL(make_scan16_kernel<float>, grid, dim3(256), 0, st, (const float*)X, row0, n, dims, ld, ld16,
-                       metric, X16, rowp16, n_unsafe);
+  const uint64_t max_rows = kMaxWorkItems / 64;  // one wave per row; a dispatch holds < 2^32 work-items
+  for (uint64_t r0 = 0; r0 < n; r0 += max_rows) {
+    const uint64_t m = n - r0 < max_rows ? n - r0 : max_rows;
+    const dim3 grid((uint32_t)((m + 3) / 4));
+    if (x_half)
+      hipLaunchKernelGGL(make_scan16_kernel<__half>, grid, dim3(256), 0, st, (const __half*)X, row0 + r0, m, dims, ld,
+                         ld16, metric, X16, rowp16, n_unsafe);
+    else
+      hipLaunchKernelGGL(make_scan16_kernel<float>, grid, dim3(256), 0, st, (const float*)X, row0 + r0, m, dims, ld,
+                         ld16, metric, X16, rowp16, n_unsafe);
+  }
   return hipGetLastError();
 }
 
@@ -348,13 +361,17 @@ hipError_t launch_make_scan8(const void* X, int x_half, uint64_t row0, uint64_t 
                              uint32_t ld8, int metric, int8_t* X8, float4* rowp8, float4* tilep8,
                              unsigned long long* n_unsafe, hipStream_t st) {
   if (n == 0) return hipSuccess;
-  const dim3 grid((uint32_t)((n + 3) / 4));
-  if (x_half)
-    hipLaunchKernelGGL(make_scan8_kernel<__half>, grid, dim3(256), 0, st, (const __half*)X, row0, n, dims, ld, ld8,
-                       metric, X8, rowp8, n_unsafe);
-  else
-    hipLaunchKernelGGL(make_scan8_kernel<float>, grid, dim3(256), 0, st, (const float*)X, row0, n, dims, ld, ld8,
-                       metric, X8, rowp8, n_unsafe);
+  const uint64_t max_rows = kMaxWorkItems / 64;  // one wave per row; a dispatch holds < 2^32 work-items
+  for (uint64_t r0 = 0; r0 < n; r0 += max_rows) {
+    const uint64_t m = n - r0 < max_rows ? n - r0 : max_rows;
+    const dim3 grid((uint32_t)((m + 3) / 4));
+    if (x_half)
+      hipLaunchKernelGGL(make_scan8_kernel<__half>, grid, dim3(256), 0, st, (const __half*)X, row0 + r0, m, dims, ld,
+                         ld8, metric, X8, rowp8, n_unsafe);
+    else
+      hipLaunchKernelGGL(make_scan8_kernel<float>, grid, dim3(256), 0, st, (const float*)X, row0 + r0, m, dims, ld, ld8,
+                         metric, X8, rowp8, n_unsafe);
+  }
   const uint64_t t0 = row0 >> 8, t1 = (row0 + n + 255) >> 8;
   hipLaunchKernelGGL(tile_params8_kernel, dim3((uint32_t)(t1 - t0)), dim3(64), 0, st, rowp8, t0, tilep8);
   return hipGetLastError();

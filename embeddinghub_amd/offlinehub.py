@@ -21,6 +21,7 @@ from .space import Space
 class Index:
     def __init__(self, key_emb_iter, dims):
         self._data = {}
+        self._orig = {}  # str(key) -> the caller's key object (keys travel through the C ABI as strings)
         self._dims = dims
         self._space = Space.unique("offline-index", dims, metric=_lib.METRIC_L2SQ,
                                    initial_capacity=1024)  # offlinehub.py:34-35 (cap 1024)
@@ -31,6 +32,7 @@ class Index:
         if key not in self._data:
             self._size += 1
         self._data[key] = embedding
+        self._orig[str(key)] = key
         self._space.set(str(key), embedding)
 
     def get(self, key):
@@ -46,10 +48,10 @@ class Index:
             if key not in self._data:
                 self._size += 1
             self._data[key] = embedding
+            self._orig[str(key)] = key
         if not keys:
             return
         self._space.set_batch(keys, np.asarray(embs, dtype=np.float32).reshape(len(keys), self._dims))
-        self._keymap = None
 
     def multiget(self, keys):
         return [self._data[key] for key in keys]
@@ -62,13 +64,9 @@ class Index:
         return [self._orig_key(k) for k in keys]
 
     def _orig_key(self, skey):
-        # keys travel as strings through the C ABI; hand back the caller's original key object
-        if skey in self._data:
-            return skey
-        for k in self._data:
-            if str(k) == skey:
-                return k
-        return skey
+        # hand back the caller's original key object: one dict lookup per neighbour (it was a scan over every key
+        # of the index for non-string keys — the reference's own tests use integer keys, offlinehub_test.py:68-86)
+        return self._orig.get(skey, skey)
 
     def size(self):
         return self._size

@@ -149,9 +149,13 @@ class DurableSpace:
                 raise
 
     def freeze(self):
-        with self._mu:
-            self._inner.freeze()
-            self._owner._catalog(_FREEZE, self._name, self.dims)
+        # lock order everywhere: the store's lock BEFORE a space's (delete_space holds the store's lock and then takes
+        # the space's; taking them the other way round here deadlocked a concurrent FreezeSpace / DeleteSpace)
+        with self._owner._mu:
+            with self._mu:
+                self._inner.freeze()
+                if self._owner._spaces.get(self._name) is self:  # (a stale handle of a deleted space records nothing)
+                    self._owner._catalog(_FREEZE, self._name, self.dims)
 
     def __getattr__(self, name):  # get / nearest / keys_sorted / __len__ ... : straight through
         return getattr(self._inner, name)

@@ -244,55 +244,88 @@ class EmbeddingHubService(pb_grpc.EmbeddingHubServicer):
         waits for an answer before sending its next request is served at once — and whatever has accumulated (up to
         MULTI_NN_WINDOW) is answered together: by-embedding requests of one (space, num) go to the engine as ONE batch
         (`nearest_many`), by-key requests one by one.  Every request gets the unary RPC's checks; the first failing one
-        ends the stream with the unary RPC's status."""
+        ends the stream with the unary RPC's status, after the requests before it have been answered.  The reader
+        thread ends with the handler (abort, cancelled client, normal end): it never blocks on a queue nobody drains."""
         inbox = queue.Queue(maxsize=4 * self.MULTI_NN_WINDOW)
         end = object()
+        stop = threading.Event()  # set when the handler is done (normally, by an abort, or by a cancelled client)
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    inbox.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    if not context.is_active():
+                        return False
+            return False
 
         def reader():
             try:
                 for req in request_iterator:
-                    inbox.put(req)
+                    if not put(req):
+                        return  # nobody drains the queue any more: do not pile requests up, do not block for ever
             except Exception as exc:  # noqa: BLE001  (a cancelled stream: hand the error to the consumer)
-                inbox.put(exc)
-            inbox.put(end)
+                put(exc)
+            put(end)
         threading.Thread(target=reader, daemon=True).start()
-        done = False
-        while not done:
-            window = [inbox.get()]
-            while len(window) < self.MULTI_NN_WINDOW:
-                try:
-                    window.append(inbox.get_nowait())
-                except queue.Empty:
-                    break
-            if window[-1] is end:
-                done = True
-                window.pop()
-            for item in window:
-                if isinstance(item, Exception):
-                    context.abort(grpc.StatusCode.CANCELLED, "request stream failed: %r" % (item,))
-            answers = [None] * len(window)
-            groups = {}  # (space name, num) -> (space, [positions], [vectors])
-            for pos, req in enumerate(window):
-                sp, has_key = self._nn_validate(req, context)
-                if has_key:
+
+        class _Failed(Exception):
+            def __init__(self, code, text):
+                self.code, self.text = code, text
+
+        class _Deferring:  # the unary checks, with the abort handed back instead of raised through the window
+            @staticmethod
+            def abort(code, text):
+                raise _Failed(code, text)
+        try:
+            done = False
+            while not done:
+                window = [inbox.get()]
+                while len(window) < self.MULTI_NN_WINDOW:
                     try:
-                        answers[pos] = sp.nearest(req.num, key=req.key)
-                    except KeyNotFound:
-                        context.abort(grpc.StatusCode.NOT_FOUND, "Not found")
-                else:
-                    g = groups.setdefault((req.space, req.num), (sp, [], []))
-                    g[1].append(pos)
-                    g[2].append(self._checked(sp, req.embedding, context))
-            for (_, num), (sp, positions, vecs) in groups.items():
-                many = getattr(sp, "nearest_many", None)
-                if many is not None and len(vecs) > 1:
-                    for pos, keys in zip(positions, many(num, np.stack(vecs))):
-                        answers[pos] = keys
-                else:
-                    for pos, v in zip(positions, vecs):
-                        answers[pos] = sp.nearest(num, embedding=v)
-            for keys in answers:
-                yield pb.NearestNeighborResponse(keys=keys)
+                        window.append(inbox.get_nowait())
+                    except queue.Empty:
+                        break
+                if window[-1] is end:
+                    done = True
+                    window.pop()
+                failed = None
+                answers = []
+                groups = {}  # (space name, num) -> (space, [positions], [vectors])
+                for pos, req in enumerate(window):
+                    try:
+                        if isinstance(req, Exception):
+                            raise _Failed(grpc.StatusCode.CANCELLED, "request stream failed: %r" % (req,))
+                        sp, has_key = self._nn_validate(req, _Deferring)
+                        if has_key:
+                            try:
+                                answers.append(sp.nearest(req.num, key=req.key))
+                            except KeyNotFound:
+                                raise _Failed(grpc.StatusCode.NOT_FOUND, "Not found")
+                        else:
+                            v = self._checked(sp, req.embedding, _Deferring)
+                            g = groups.setdefault((req.space, req.num), (sp, [], []))
+                            g[1].append(pos)
+                            g[2].append(v)
+                            answers.append(None)
+                    except _Failed as f:  # the requests before the failing one are still answered, then the stream ends
+                        failed = f
+                        break
+                for (_, num), (sp, positions, vecs) in groups.items():
+                    many = getattr(sp, "nearest_many", None)
+                    if many is not None and len(vecs) > 1:
+                        for pos, keys in zip(positions, many(num, np.stack(vecs))):
+                            answers[pos] = keys
+                    else:
+                        for pos, v in zip(positions, vecs):
+                            answers[pos] = sp.nearest(num, embedding=v)
+                for keys in answers:
+                    yield pb.NearestNeighborResponse(keys=keys)
+                if failed is not None:
+                    context.abort(failed.code, failed.text)
+        finally:
+            stop.set()
 
     def Download(self, request, context):
         sp = self._space(request.space, context)

@@ -3,13 +3,11 @@ replaced by small numpy / oracle stand-ins so that the WHOLE control flow runs â
 batches against the 'fp32 engine', the oracle check), CPU baseline, the optional legs under their time budget and
 watchdog, the one JSON line.  What this pins is bench.py itself (names, order, the JSON contract of the driver), not
 the engine: the stand-in answers every kNN with the oracle's exhaustive scan."""
-import ctypes as C
 import importlib.util
 import io
 import json
 import os
 import sys
-import types
 from contextlib import redirect_stdout
 
 import numpy as np
@@ -21,118 +19,14 @@ from oracle import pyoracle
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class FakeSpace:
-    spaces = {}
-
-    def __init__(self, name, dims, metric=0, mode=0, initial_capacity=0, shards=0, dtype=0, build_batch=0, **kw):
-        self.name, self.dims, self.metric, self.mode = name, dims, metric, mode
-        self.X = np.zeros((0, dims), dtype=np.float32)
-        self.ef, self._scan, self._st = 10, 0, self._zero()
-        FakeSpace.spaces[name] = self
-
-    @staticmethod
-    def _zero():
-        return {"scan_ms_mean": 1.0, "scan_launches": 0, "n_uncertified": 0, "n_i8_queries": 0, "n_i8_fallback": 0,
-                "n_filter_fallback": 0, "n_exhaustive": 0, "n_dist": 0, "n_hops": 0, "bytes_algorithmic": 0,
-                "n_queries": 0, "last_scan_ms": 1.0}
-
-    def _om(self):
-        return {0: pyoracle.METRIC_L2, 1: pyoracle.METRIC_IP, 2: pyoracle.METRIC_COSINE}[self.metric]
-
-    def fill_synthetic(self, seed, row0, n, normalize):
-        self.X = np.concatenate([self.X, pyoracle.gen_rows(seed, row0, n, self.dims, normalize=bool(normalize))])
-
-    def set_batch(self, keys, X):
-        self.X = np.concatenate([self.X, np.asarray(X, dtype=np.float32)])
-
-    def knn(self, Q, k):
-        Q = np.asarray(Q, dtype=np.float32).reshape(-1, self.dims)
-        ids, dist, cnt = pyoracle.exhaustive(self.X, Q, k, self._om())
-        self._st["scan_launches"] += 1
-        self._st["n_queries"] += Q.shape[0]
-        self._st["n_dist"] += 100 * Q.shape[0]
-        self._st["n_hops"] += 5 * Q.shape[0]
-        self._st["bytes_algorithmic"] += 100 * Q.shape[0] * self.dims * 4
-        self._st["n_i8_queries"] += Q.shape[0]
-        return ids, dist, cnt
-
-    def knn_device(self, q, k, ids, dst, cnt, stream=None):
-        i, d, c = self.knn(q.numpy(), k)
-        ids.copy_(torch.from_numpy(i.astype(np.int64)))
-        dst.copy_(torch.from_numpy(d))
-        cnt.copy_(torch.from_numpy(c.astype(np.int32)))
-
-    def set_scan(self, scan):
-        self._scan = scan
-
-    def scan_engine(self):
-        return "f32" if self._scan == 1 else "i8"
-
-    def set_ef(self, ef):
-        self.ef = ef
-
-    def stats(self):
-        return dict(self._st)
-
-    def stats_reset(self):
-        self._st = self._zero()
-
-    def drop(self):
-        FakeSpace.spaces.pop(self.name, None)
-
-    def __len__(self):
-        return self.X.shape[0]
-
-
-class FakeSearcher:
-    def __init__(self, row0, B, k, device, space=None, stream=None):
-        self.space, self.k = space, k
-        self.ids = torch.empty((B, k), dtype=torch.int64)
-        self.dst = torch.empty((B, k), dtype=torch.float32)
-        self.cnt = torch.empty((B,), dtype=torch.int32)
-
-    def knn(self, q):
-        self.space.knn_device(q, self.k, self.ids, self.dst, self.cnt)
-        return self.ids, self.dst, self.cnt
-
-
-class FakeLib:
-    @staticmethod
-    def ehx_init(dev, n):
-        return 0
-
-    @staticmethod
-    def ehx_gen_rows_device(stream, seed, row0, n, d, normalize, ptr):
-        rows = pyoracle.gen_rows(seed, row0, n, d, normalize=bool(normalize))
-        C.memmove(ptr.value, rows.ctypes.data, rows.nbytes)
-        return 0
+sys.path.insert(0, os.path.join(ROOT, "tests", "bench_stubs"))
+import standins  # noqa: E402  (tests/bench_stubs/standins.py: the engine / torch.cuda stand-ins)
+from standins import FakeSpace  # noqa: E402
 
 
 @pytest.fixture
 def bench_on_stand_ins(monkeypatch):
-    ehx = types.ModuleType("embeddinghub_amd")
-    for name, v in dict(METRIC_L2SQ=0, METRIC_IP=1, METRIC_COSINE=2, SCAN_AUTO=0, SCAN_F32=1, SCAN_F16=2, DTYPE_F32=0,
-                        DTYPE_F16=1, MODE_FLAT=0, MODE_GRAPH=1, SEED_CORPUS=20250211, SEED_QUERY=20250212).items():
-        setattr(ehx, name, v)
-    ehx.Space = FakeSpace
-    lib = types.ModuleType("embeddinghub_amd._lib")
-    lib.load = lambda: FakeLib
-    lib.check = lambda rc: None
-    ehx._lib = lib
-    sharded = types.ModuleType("embeddinghub_amd.sharded")
-    sharded.shard_range = lambda rows, G, rank: (0, rows)
-    sharded.ShardedSearcher = FakeSearcher
-    monkeypatch.setitem(sys.modules, "embeddinghub_amd", ehx)
-    monkeypatch.setitem(sys.modules, "embeddinghub_amd._lib", lib)
-    monkeypatch.setitem(sys.modules, "embeddinghub_amd.sharded", sharded)
-    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
-    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
-    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
-    monkeypatch.setattr(torch.cuda, "current_stream",
-                        lambda *a: types.SimpleNamespace(cuda_stream=0, synchronize=lambda: None))
-    real_empty = torch.empty
-    monkeypatch.setattr(torch, "empty", lambda *a, **kw: real_empty(*a, **{k: v for k, v in kw.items() if k != "device"}))
+    standins.install(monkeypatch)
     spec = importlib.util.spec_from_file_location("bench_flow_module", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
@@ -228,6 +122,7 @@ def test_multi_rank_flow_rank0_prints_the_line(bench_on_stand_ins, monkeypatch):
     monkeypatch.setattr(dist, "barrier", lambda *a, **kw: calls.append("barrier"))
     monkeypatch.setattr(dist, "all_reduce", lambda t, op=None: calls.append("all_reduce"))
     monkeypatch.setattr(dist, "destroy_process_group", lambda *a, **kw: calls.append("destroy"))
+    monkeypatch.setattr(dist, "get_world_size", lambda *a, **kw: 2)
     real_tensor, real_device = torch.tensor, torch.device
     monkeypatch.setattr(torch, "tensor", lambda *a, **kw: real_tensor(*a, **{k: v for k, v in kw.items() if k != "device"}))
     monkeypatch.setattr(torch, "device", lambda *a, **kw: real_device("cpu"))
@@ -237,3 +132,48 @@ def test_multi_rank_flow_rank0_prints_the_line(bench_on_stand_ins, monkeypatch):
     assert "graph_path" not in r and "cpu_baseline" not in r          # N = 1 legs
     assert r["exactness"]["recall_at_10"] == 1.0
     assert calls[0] == "init" and calls[-1] == "destroy" and "all_reduce" in calls and calls.count("barrier") >= 3
+
+
+def _run_bench_subprocess(argv, devices):
+    import subprocess
+    env = dict(os.environ, EHX_BENCH_STANDINS="1", EHX_STANDIN_DEVICES=str(devices),
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests", "bench_stubs"), ROOT,
+                                           os.environ.get("PYTHONPATH", "")]))
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(var, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True,
+                          text=True, timeout=600)
+
+
+def test_gpus_2_launches_two_real_ranks():
+    """`python bench.py --gpus 2` (no torchrun around it, WORLD_SIZE unset) must start the two ranks itself.
+    Here: the real launcher, two real processes under torch.distributed.run, a real process group (gloo instead of RCCL),
+    the product's own sharded.py (row partition, ONE packed all-gather per batch, merge) â€” only the engine and torch.cuda
+    are stand-ins (sitecustomize.py in tests/bench_stubs).  Each rank holds half of the rows; the merged answer is checked
+    against the oracle's exhaustive scan of ALL rows inside bench.py (exactness block), so a wrong partition, gather or
+    merge fails the run."""
+    r = _run_bench_subprocess(SMALL + ["--gpus", "2", "--rows", "3001"], devices=2)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2
+    assert out["config"]["rows_per_rank"] == [1500, 1501] and out["config"]["rows_per_gpu"] == 1500
+    assert out["scaling"] == "strong" and "row-shard x2" in out["config"]["parallelism"]
+    ex = out["exactness"]
+    assert ex["recall_at_10"] == 1.0 and ex["ids_identical_to_oracle"] and ex["dist_bytes_identical_to_oracle"]
+    assert ex["oracle_rows"] == 3001
+    assert "launching 2 ranks" in r.stderr
+
+
+def test_gpus_2_on_a_one_gpu_box_fails_loudly():
+    r = _run_bench_subprocess(SMALL + ["--gpus", "2"], devices=1)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "--gpus 2" in r.stderr and "1 GPU(s) visible" in r.stderr
+
+
+def test_world_size_that_contradicts_gpus_is_an_error(bench_on_stand_ins, monkeypatch):
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit) as e:
+        bench_on_stand_ins(SMALL + ["--gpus", "2"])
+    assert "WORLD_SIZE=4" in str(e.value)

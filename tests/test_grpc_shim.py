@@ -239,6 +239,22 @@ def check_multi_nearest_neighbor(c):  # docs/inference.md:17-22 (`multi_nearest_
         with pytest.raises(grpc.RpcError) as e:
             list(c._stub.MultiNearestNeighbor(iter([mixed[0], bad])))
         assert e.value.code() == code
+        # the requests before the failing one are answered before the stream ends with its status
+        got_before = []
+        with pytest.raises(grpc.RpcError) as e:
+            for r in c._stub.MultiNearestNeighbor(iter([mixed[0], mixed[2], bad, mixed[0]])):
+                got_before.append(list(r.keys))
+        assert e.value.code() == code and got_before == [want[0], want[1][:2]]
+    # a long stream that fails early must not leave its reader thread blocked on a full queue
+    before = threading.active_count()
+    many = [mixed[0]] * 6000
+    with pytest.raises(grpc.RpcError):
+        list(c._stub.MultiNearestNeighbor(iter([pb.NearestNeighborRequest(space=str(a), num=1)] + many)))
+    import time as _t
+    deadline = _t.time() + 10
+    while threading.active_count() > before and _t.time() < deadline:
+        _t.sleep(0.05)
+    assert threading.active_count() <= before, "a MultiNearestNeighbor reader thread outlived its failed stream"
 
 
 SUITE = [check_set_get, check_immutable_set, check_multiset_get_multiget_download, check_multi_space,
@@ -382,4 +398,34 @@ def test_durable_store_crash_consistency(tmp_path):
     st2 = DurableStore(OracleStore(), str(tmp_path))    # restart: only "z" comes back, neither x / y nor the refused w
     sp2 = st2.get_space("a")
     assert len(sp2) == 1 and sp2.keys_sorted() == ["z"]
+    st2.close()
+
+
+def test_durable_freeze_and_delete_do_not_deadlock(tmp_path):
+    """FreezeSpace (space lock, then the store's for the catalog record) against DeleteSpace (store lock,
+    then the space's) on the same space was a lock-order inversion; both now take the store's lock first.  A stale
+    handle's freeze after the delete records nothing, so a later space of the same name does not come back frozen."""
+    from embeddinghub_amd.rpc.durable import DurableStore
+    rng = np.random.default_rng(5)
+    st = DurableStore(OracleStore(), str(tmp_path))
+    for rnd in range(40):
+        sp = st.create_space("race", 8)
+        sp.set("k", rng.standard_normal(8).astype(np.float32))
+        ts = [threading.Thread(target=sp.freeze), threading.Thread(target=st.delete_space, args=("race",))]
+        for t in (ts if rnd % 2 else ts[::-1]):
+            t.start()
+        for t in ts:
+            t.join(timeout=20)
+            assert not t.is_alive(), "FreezeSpace / DeleteSpace deadlocked"
+    sp = st.create_space("race", 8)
+    stale = sp
+    st.delete_space("race")
+    stale.freeze()                               # a handle that outlived its space
+    sp = st.create_space("race", 8)
+    sp.set("fresh", rng.standard_normal(8).astype(np.float32))
+    st.close()
+    st2 = DurableStore(OracleStore(), str(tmp_path))
+    sp2 = st2.get_space("race")
+    sp2.set("still-writable", rng.standard_normal(8).astype(np.float32))   # not frozen by the stale handle's record
+    assert sp2.keys_sorted() == ["fresh", "still-writable"]
     st2.close()
