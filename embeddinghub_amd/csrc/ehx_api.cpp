@@ -9,6 +9,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <map>
 #include <random>
 #include <set>
@@ -92,6 +93,78 @@ struct DevBuf {
 
 }  // namespace
 
+// Persistent host threads of a sharded space: worker i drives shard i + 1 (the caller's thread drives shard 0).  Round 2
+// started G - 1 std::threads per CALL; these live as long as the space and sleep on a condition variable between jobs.
+struct ShardWorkers {
+  std::mutex run_mu;  // one job at a time
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  std::vector<std::thread> th;
+  const std::function<int(size_t)>* job = nullptr;
+  uint64_t gen = 0;
+  size_t pending = 0;
+  bool stop = false;
+  std::vector<int> rcs;
+  std::vector<std::string> errs;
+
+  explicit ShardWorkers(size_t G) : rcs(G, 0), errs(G) {
+    for (size_t i = 1; i < G; ++i) th.emplace_back([this, i] { loop(i); });
+  }
+  ~ShardWorkers() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_go.notify_all();
+    for (auto& t : th) t.join();
+  }
+  void loop(size_t i) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<int(size_t)>* f;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_go.wait(lk, [&] { return stop || gen != seen; });
+        if (stop) return;
+        seen = gen;
+        f = job;
+      }
+      const int rc = (*f)(i);
+      std::string err = rc ? g_err : "";
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        rcs[i] = rc;
+        errs[i] = std::move(err);
+        if (--pending == 0) cv_done.notify_all();
+      }
+    }
+  }
+
+  int run(const std::function<int(size_t)>& f) {
+    std::lock_guard<std::mutex> one(run_mu);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = &f;
+      pending = th.size();
+      ++gen;
+    }
+    cv_go.notify_all();
+    rcs[0] = f(0);
+    errs[0] = rcs[0] ? g_err : "";
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_done.wait(lk, [&] { return pending == 0; });
+      job = nullptr;
+    }
+    for (size_t i = 0; i < rcs.size(); ++i)
+      if (rcs[i]) {
+        snprintf(g_err, sizeof(g_err), "shard %zu: %s", i, errs[i].c_str());
+        return rcs[i];
+      }
+    return EHX_OK;
+  }
+};
+
 struct ehx_space {
   std::string name;
   uint32_t dims = 0, ld = 0;
@@ -116,9 +189,10 @@ struct ehx_space {
   // keyless spaces, one per device of ehx_init's list, searched concurrently and merged on shard 0's device.
   bool keyless = false;            // a shard: rows are addressed by local id only, hidden from ehx_space_open
   std::vector<ehx_space*> shards;  // parent only (the shards are owned by the registry under hidden names)
-  DevBuf<uint64_t> dGIds;          // parent scratch on shards[0]'s device: gathered [G][nq][k] ids,
-  DevBuf<float> dGDist;            //   distances,
-  DevBuf<uint32_t> dGCnt;          //   counts
+  std::unique_ptr<ShardWorkers> workers;  // parent only: one persistent host thread per shard beyond the first
+  hipEvent_t xev = nullptr;        // shard only: "my local top-k has reached the gather buffer" (the parent's stream waits)
+  DevBuf<unsigned char> dOutPack;  // shard only: ids | distances | counts of one batch, contiguous: ONE peer copy
+  DevBuf<unsigned char> dGPack;    // parent scratch on shards[0]'s device: the G packed results, one slot per shard
 
   // HBM-resident state
   void* dX = nullptr;        // [cap][ld] rows, fp32 or fp16 (x_half)
@@ -274,9 +348,10 @@ struct ehx_space {
     dPool.release();
     dMerged8.release();
     dI8Ctl.release();
-    dGIds.release();
-    dGDist.release();
-    dGCnt.release();
+    dGPack.release();
+    dOutPack.release();
+    if (xev) (void)hipEventDestroy(xev);
+    xev = nullptr;
     fr(dUncert16);
     fr(dAdj0);
     fr(dUpStart);
@@ -606,7 +681,7 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
   if ((rc = s->dLinkTouched.ensure(max_pairs))) return rc;
   if ((rc = s->dLinkCount.ensure(n_rounds))) return rc;
   HIP_TRY(hipMemsetAsync(s->dLinkCount.p, 0, n_rounds * sizeof(uint32_t), st));
-  InsertArgs a;
+  InsertArgs a{};  // (zeroed: a null link_head / sel switches those outputs off in the kernels)
   a.X = s->x_half ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
   a.Xs = s->dXs;
   a.inv_norm = s->dInv;
@@ -685,7 +760,7 @@ int graph_update(ehx_space* s, uint32_t id) {
   hipStream_t st = s->stream;
   const int level = s->h_levels[id];
   int rc;
-  InsertArgs a;
+  InsertArgs a{};  // (zeroed: a null link_head / sel switches those outputs off in the kernels)
   a.X = s->x_half ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
   a.Xs = s->dXs;
   a.inv_norm = s->dInv;
@@ -1608,28 +1683,15 @@ void resolve_keys(ehx_space* s, size_t n, const char* const* keys, const size_t*
 // =====================================================================================================
 inline bool is_parent(const ehx_space* s) { return !s->shards.empty(); }
 
-// f(i) for every shard, each on its own thread (shard 0 on the caller's); first failure wins
-template <class F>
-int for_each_shard(ehx_space* p, F f) {
-  const size_t G = p->shards.size();
-  std::vector<int> rcs(G, 0);
-  std::vector<std::string> errs(G);
-  std::vector<std::thread> th;
-  th.reserve(G);
-  for (size_t i = 1; i < G; ++i)
-    th.emplace_back([&, i] {
-      rcs[i] = f(i);
-      if (rcs[i]) errs[i] = g_err;
-    });
-  rcs[0] = f(0);
-  if (rcs[0]) errs[0] = g_err;
-  for (auto& t : th) t.join();
-  for (size_t i = 0; i < G; ++i)
-    if (rcs[i]) {
-      snprintf(g_err, sizeof(g_err), "shard %zu: %s", i, errs[i].c_str());
-      return rcs[i];
-    }
-  return EHX_OK;
+// f(i) for every shard, each on its own persistent thread (shard 0 on the caller's); first failure wins.  A shard that
+// was dropped meanwhile (ehx_space_drop marks the parent first, so this only guards a handle that outlived its space)
+// answers EHX_ENOTFOUND instead of touching released buffers.
+int for_each_shard(ehx_space* p, const std::function<int(size_t)>& f) {
+  if (!p->workers) return fail(EHX_EINTERNAL, "space '%s' has no shard workers", p->name.c_str());
+  return p->workers->run([&](size_t i) -> int {
+    if (p->shards[i]->dropped) return fail(EHX_ENOTFOUND, "Not found");
+    return f(i);
+  });
 }
 
 int write_rows_locked_fwd(ehx_space* s, size_t n, const std::vector<uint64_t>& ids, uint64_t next, const float* vecs);
@@ -1651,6 +1713,8 @@ int sharded_set_batch(ehx_space* p, size_t n, const char* const* keys, const siz
     lids[sh].push_back(ids[i] / G);
     rows[sh].insert(rows[sh].end(), vecs + i * p->dims, vecs + (i + 1) * p->dims);
   }
+  std::vector<uint64_t> before(G);
+  for (size_t i = 0; i < G; ++i) before[i] = p->shards[i]->n;
   int rc = for_each_shard(p, [&](size_t i) -> int {
     if (lids[i].empty()) return EHX_OK;
     ehx_space* c = p->shards[i];
@@ -1659,7 +1723,21 @@ int sharded_set_batch(ehx_space* p, size_t n, const char* const* keys, const siz
     const uint64_t next_local = (next + G - 1 - i) / G;  // globals below `next` that belong to shard i
     return write_rows_locked_fwd(c, lids[i].size(), lids[i], next_local, rows[i].data());
   });
-  if (rc) return rc;  // (a failing shard leaves the parent's key maps and row count untouched)
+  if (rc) {
+    // A failing shard (e.g. out of memory while growing) must not leave the others ahead of the parent: their published
+    // row counts go back to what they were, so no search returns a global id the parent has no key for.  (Rows of
+    // EXISTING keys that the batch rewrote on the shards that succeeded stay rewritten — a failed batch may have
+    // applied part of its updates, as a failed sequence of single Sets would; graph shards keep the nodes they linked.)
+    const std::string msg = g_err;
+    for (size_t i = 0; i < G; ++i) {
+      ehx_space* c = p->shards[i];
+      std::lock_guard<std::mutex> cg(c->wmu);
+      std::unique_lock<std::shared_mutex> wl(c->mu);
+      if (c->n > before[i] && c->params.mode != EHX_MODE_GRAPH) c->n = before[i];
+    }
+    snprintf(g_err, sizeof(g_err), "%s", msg.c_str());
+    return rc;
+  }
   const uint64_t old_n = p->n;
   {
     std::unique_lock<std::shared_mutex> kl(p->kmu);
@@ -1691,18 +1769,23 @@ int sharded_fill_synthetic(ehx_space* p, uint64_t seed, uint64_t row0, uint64_t 
 }
 
 // queries are on the host (d_queries == nullptr) or on device `qdev`; outputs likewise.  Parent locked shared.
+// Per batch and shard: the queries in, the shard's own pipeline, ONE peer copy of its packed local top-k
+// (ids | distances | counts: 12 k + 4 bytes per query) into its slot of the gather buffer on shard 0's device, and an
+// event; the parent's stream waits for the G events (no host synchronisation per shard), merges, and hands the result
+// over.  k up to 1024 like an unsharded space (every shard pages its own exhaustive pass beyond 48; the merge walks
+// the lists beyond 64).
 int sharded_knn(ehx_space* p, size_t nq, const float* h_queries, const float* d_queries, int qdev, uint32_t k,
                 uint64_t* out_ids, float* out_dist, uint32_t* out_count, bool out_on_device, hipStream_t caller_stream) {
   if (k == 0 || nq == 0) return EHX_OK;
-  if (k > 64) return fail(EHX_EUNSUPPORTED, "sharded spaces serve k <= 64 (k=%u)", k);
+  if (k > 1024) return fail(EHX_EUNSUPPORTED, "k=%u exceeds 1024", k);
   const size_t G = p->shards.size();
   const int home = p->shards[0]->device;
   std::lock_guard<std::mutex> sl(p->scratch_mu);
   int rc;
   HIP_TRY(hipSetDevice(home));
-  if ((rc = p->dGIds.ensure(G * nq * k))) return rc;
-  if ((rc = p->dGDist.ensure(G * nq * k))) return rc;
-  if ((rc = p->dGCnt.ensure(G * nq))) return rc;
+  const size_t o_dist = nq * k * sizeof(uint64_t), o_cnt = o_dist + nq * k * sizeof(float);
+  const size_t P = (o_cnt + nq * sizeof(uint32_t) + 15) / 16 * 16;  // one shard's packed result
+  if ((rc = p->dGPack.ensure(G * P))) return rc;
   if ((rc = p->dOutIds.ensure(nq * k))) return rc;
   if ((rc = p->dOutDist.ensure(nq * k))) return rc;
   if ((rc = p->dOutCount.ensure(nq))) return rc;
@@ -1718,24 +1801,26 @@ int sharded_knn(ehx_space* p, size_t nq, const float* h_queries, const float* d_
     HIP_TRY(hipSetDevice(c->device));
     int r;
     if ((r = c->dQraw.ensure(nq * c->dims))) return r;
-    if ((r = c->dOutIds.ensure(nq * k))) return r;
-    if ((r = c->dOutDist.ensure(nq * k))) return r;
-    if ((r = c->dOutCount.ensure(nq))) return r;
+    if ((r = c->dOutPack.ensure(P))) return r;
+    if (!c->xev) HIP_TRY(hipEventCreateWithFlags(&c->xev, hipEventDisableTiming));
     if (d_queries) HIP_TRY(hipMemcpyPeerAsync(c->dQraw.p, c->device, d_queries, qdev, qbytes, c->stream));
     else HIP_TRY(hipMemcpyAsync(c->dQraw.p, h_queries, qbytes, hipMemcpyHostToDevice, c->stream));
-    if ((r = knn_device_locked(c, c->stream, nq, c->dQraw.p, k, c->dOutIds.p, c->dOutDist.p, c->dOutCount.p))) return r;
-    // the one exchange step: this shard's local top-k into its slot of the gather buffer on shard 0's device
-    HIP_TRY(hipMemcpyPeerAsync(p->dGIds.p + i * nq * k, home, c->dOutIds.p, c->device, nq * k * sizeof(uint64_t), c->stream));
-    HIP_TRY(hipMemcpyPeerAsync(p->dGDist.p + i * nq * k, home, c->dOutDist.p, c->device, nq * k * sizeof(float), c->stream));
-    HIP_TRY(hipMemcpyPeerAsync(p->dGCnt.p + i * nq, home, c->dOutCount.p, c->device, nq * sizeof(uint32_t), c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned char* pk = c->dOutPack.p;
+    if ((r = knn_device_locked(c, c->stream, nq, c->dQraw.p, k, (uint64_t*)pk, (float*)(pk + o_dist),
+                               (uint32_t*)(pk + o_cnt))))
+      return r;
+    // the one exchange step
+    HIP_TRY(hipMemcpyPeerAsync(p->dGPack.p + i * P, home, pk, c->device, P, c->stream));
+    HIP_TRY(hipEventRecord(c->xev, c->stream));
     return EHX_OK;
   });
   if (rc) return rc;
   HIP_TRY(hipSetDevice(home));
-  HIP_TRY(launch_merge_lists(p->dGIds.p, p->dGDist.p, p->dGCnt.p, (uint32_t)nq, k, (uint32_t)G, p->dOutIds.p,
-                             p->dOutDist.p, p->dOutCount.p, p->stream, nq * k * sizeof(uint64_t),
-                             nq * k * sizeof(float), nq * sizeof(uint32_t), (uint64_t)G, 1));
+  for (size_t i = 0; i < G; ++i) HIP_TRY(hipStreamWaitEvent(p->stream, p->shards[i]->xev, 0));
+  const unsigned char* gp = p->dGPack.p;
+  HIP_TRY(launch_merge_lists((const uint64_t*)gp, (const float*)(gp + o_dist), (const uint32_t*)(gp + o_cnt),
+                             (uint32_t)nq, k, (uint32_t)G, p->dOutIds.p, p->dOutDist.p, p->dOutCount.p, p->stream, P, P,
+                             P, (uint64_t)G, 1));
   if (out_on_device) {
     HIP_TRY(hipMemcpyPeerAsync(out_ids, qdev, p->dOutIds.p, home, nq * k * sizeof(uint64_t), p->stream));
     HIP_TRY(hipMemcpyPeerAsync(out_dist, qdev, p->dOutDist.p, home, nq * k * sizeof(float), p->stream));
@@ -1745,7 +1830,7 @@ int sharded_knn(ehx_space* p, size_t nq, const float* h_queries, const float* d_
     HIP_TRY(hipMemcpyAsync(out_dist, p->dOutDist.p, nq * k * sizeof(float), hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipMemcpyAsync(out_count, p->dOutCount.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
   }
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));  // (the shards' scratch may be reused by the next call: all of it is done)
   p->n_queries += nq;
   return EHX_OK;
 }
@@ -1916,6 +2001,7 @@ int ehx_space_create(const char* name, size_t name_len, uint32_t dims, int metri
     }
     parent->shards.push_back(c);
   }
+  parent->workers = std::make_unique<ShardWorkers>(G);
   *out = parent;
   return EHX_OK;
 }
@@ -1933,14 +2019,20 @@ int ehx_space_open(const char* name, size_t name_len, ehx_space** out) {
 int ehx_space_drop(ehx_space* s) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   Engine& E = engine();
-  if (is_parent(s)) {  // the shards first (each leaves its own tombstone), then the parent itself below
+  if (is_parent(s)) {
+    // The PARENT is marked first, under its writer mutex and its lock held exclusively — every search or write that
+    // runs on the shards holds the parent's lock shared or exclusively, so none is in flight now and none starts
+    // later (they find `dropped`) — then the shards go (each leaves its own tombstone), then the parent itself below.
     std::vector<ehx_space*> kids;
     {
+      std::lock_guard<std::mutex> wg(s->wmu);
       std::unique_lock<std::shared_mutex> wl(s->mu);
       if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+      s->dropped = true;
       kids = s->shards;
     }
     for (ehx_space* c : kids) (void)ehx_space_drop(c);
+    s->workers.reset();  // (idle: nothing can reach for_each_shard any more)
   }
   std::unique_ptr<ehx_space> owned;
   {
@@ -2630,7 +2722,7 @@ int ehx_merge_topk_strided_device(void* stream, size_t n_queries, uint32_t k, ui
                                   size_t count_stride, uint64_t* d_out_ids, float* d_out_dist,
                                   uint32_t* d_out_count) {
   if (n_queries == 0 || k == 0) return EHX_OK;
-  if (k > 64) return fail(EHX_EUNSUPPORTED, "merge supports k <= 64");
+  if (k > 64 && n_lists > 64) return fail(EHX_EUNSUPPORTED, "merging k > 64 takes at most 64 lists (%u)", n_lists);
   if (!d_ids || !d_dist || !d_out_ids || !d_out_dist) return fail(EHX_EINVAL, "NULL device pointer");
   if (ids_stride % 8 || dist_stride % 4 || count_stride % 4) return fail(EHX_EINVAL, "misaligned list stride");
   int rc = ehx_init(nullptr, 0);

@@ -4,6 +4,7 @@
 
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 namespace ehx {
@@ -718,6 +719,29 @@ size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap);
 hipError_t launch_graph_search(const GraphArgs& a, hipStream_t st);
 
 // graph-mode insertion (k_insert.hip)
+// hipFuncAttributeMaxDynamicSharedMemorySize is set per function AND per device (every device has its own loaded code
+// object), and launches come from several host threads once a space is sharded over devices inside one process: the
+// largest size set so far is kept per device, atomically.  `fns`: the kernel's instantiations.
+struct DynLdsAttr {
+  std::atomic<size_t> set[64] = {};
+  hipError_t ensure(const void* const* fns, int n_fns, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;  // (within the default limit)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::atomic<size_t>& cur = set[dev & 63];
+    if (cur.load(std::memory_order_acquire) >= bytes) return hipSuccess;
+    for (int i = 0; i < n_fns; ++i) {
+      e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e != hipSuccess) return e;
+    }
+    size_t seen = cur.load(std::memory_order_relaxed);
+    while (seen < bytes && !cur.compare_exchange_weak(seen, bytes, std::memory_order_release)) {
+    }
+    return hipSuccess;
+  }
+};
+
 struct InsertArgs {
   const float* X;
   const float* Xs;         // search copy (launch_make_search_copy)

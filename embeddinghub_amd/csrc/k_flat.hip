@@ -364,10 +364,68 @@ __global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t* __restr
   if (lane == 0 && out_count) out_count[q] = cnt;
 }
 
+// the same merge for k > 64 (sharded spaces serve k up to 1024 like unsharded ones): lane l walks list l, every step
+// the wave takes the smallest head by (distance, id) and the lane that held it moves on — k steps of one load and a
+// six-stage minimum; n_lists <= 64
+__global__ __launch_bounds__(64) void merge_lists_walk_kernel(const uint64_t* __restrict__ ids,
+                                                              const float* __restrict__ dist,
+                                                              const uint32_t* __restrict__ count, uint32_t nq,
+                                                              uint32_t k, uint32_t n_lists, size_t ids_stride,
+                                                              size_t dist_stride, size_t count_stride,
+                                                              uint64_t id_mul, uint64_t id_step,
+                                                              uint64_t* __restrict__ out_ids,
+                                                              float* __restrict__ out_dist,
+                                                              uint32_t* __restrict__ out_count) {
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  const bool mine = (uint32_t)lane < n_lists;
+  const uint64_t* il = (const uint64_t*)((const char*)ids + (size_t)lane * ids_stride) + (size_t)q * k;
+  const float* dl = (const float*)((const char*)dist + (size_t)lane * dist_stride) + (size_t)q * k;
+  uint32_t c = 0;
+  if (mine) c = count ? ((const uint32_t*)((const char*)count + (size_t)lane * count_stride))[q] : k;
+  if (c > k) c = k;
+  uint32_t total = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) total += __shfl_xor(total, o, 64);
+  const uint32_t cnt = total < k ? total : k;
+  uint32_t pos = 0;
+  float hd = pos < c ? dl[pos] : __builtin_inff();
+  uint64_t hi = pos < c ? il[pos] * id_mul + (uint64_t)lane * id_step : ~0ull;
+  for (uint32_t j = 0; j < k; ++j) {
+    float md = hd;
+    uint64_t mi = hi;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float od = __shfl_xor(md, o, 64);
+      const uint64_t oi = __shfl_xor(mi, o, 64);
+      if (od < md || (od == md && oi < mi)) {
+        md = od;
+        mi = oi;
+      }
+    }
+    if (lane == 0) {
+      out_ids[(size_t)q * k + j] = j < cnt ? mi : ~0ull;
+      out_dist[(size_t)q * k + j] = j < cnt ? md : __builtin_inff();
+    }
+    if (hi == mi && hi != ~0ull) {  // (global ids are distinct: exactly one lane holds the winner)
+      pos += 1;
+      hd = pos < c ? dl[pos] : __builtin_inff();
+      hi = pos < c ? il[pos] * id_mul + (uint64_t)lane * id_step : ~0ull;
+    }
+  }
+  if (lane == 0 && out_count) out_count[q] = cnt;
+}
+
 hipError_t launch_merge_lists(const uint64_t* ids, const float* dist, const uint32_t* count, uint32_t nq,
                               uint32_t k, uint32_t n_lists, uint64_t* out_ids, float* out_dist,
                               uint32_t* out_count, hipStream_t st, size_t ids_stride, size_t dist_stride,
                               size_t count_stride, uint64_t id_mul, uint64_t id_step) {
+  if (k > 64) {
+    if (n_lists > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_lists_walk_kernel, dim3(nq), dim3(64), 0, st, ids, dist, count, nq, k, n_lists, ids_stride,
+                       dist_stride, count_stride, id_mul, id_step, out_ids, out_dist, out_count);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(merge_lists_kernel, dim3(nq), dim3(64), 0, st, ids, dist, count, nq, k, n_lists, ids_stride,
                      dist_stride, count_stride, id_mul, id_step, out_ids, out_dist, out_count);
   return hipGetLastError();

@@ -443,16 +443,10 @@ __global__ __launch_bounds__(kThreads16, 2) void flat_scan16_kernel(const ScanAr
 }
 
 hipError_t launch_flat_scan16(const ScanArgs16& a, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    const void* fns[3] = {(const void*)flat_scan16_kernel<false, false>, (const void*)flat_scan16_kernel<true, false>,
-                          (const void*)flat_scan16_kernel<false, true>};
-    for (const void* f : fns) {
-      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes16);
-      if (e != hipSuccess) return e;
-    }
-    attr_set = true;
-  }
+  static DynLdsAttr attr;
+  const void* fns[3] = {(const void*)flat_scan16_kernel<false, false>, (const void*)flat_scan16_kernel<true, false>,
+                        (const void*)flat_scan16_kernel<false, true>};
+  if (hipError_t e = attr.ensure(fns, 3, kLdsBytes16); e != hipSuccess) return e;
   const uint32_t grid = a.q_tiles * a.n_chunks;
   if (a.dump) hipLaunchKernelGGL((flat_scan16_kernel<false, true>), dim3(grid), dim3(kThreads16), kLdsBytes16, st, a);
   else if (a.cos) hipLaunchKernelGGL((flat_scan16_kernel<true, false>), dim3(grid), dim3(kThreads16), kLdsBytes16, st, a);

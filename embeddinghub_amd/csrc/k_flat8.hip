@@ -437,16 +437,9 @@ __global__ __launch_bounds__(kThreads8, 2) void flat_scan8_kernel(const ScanArgs
 }
 
 hipError_t launch_flat_scan8(const ScanArgs& a, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)flat_scan8_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes8);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)flat_scan8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kLdsBytes8);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static DynLdsAttr attr;
+  const void* fns[2] = {(const void*)flat_scan8_kernel<false>, (const void*)flat_scan8_kernel<true>};
+  if (hipError_t e = attr.ensure(fns, 2, kLdsBytes8); e != hipSuccess) return e;
   const uint32_t grid = a.q_tiles * a.n_chunks;
   if (a.x_half) hipLaunchKernelGGL(flat_scan8_kernel<true>, dim3(grid), dim3(kThreads8), kLdsBytes8, st, a);
   else hipLaunchKernelGGL(flat_scan8_kernel<false>, dim3(grid), dim3(kThreads8), kLdsBytes8, st, a);

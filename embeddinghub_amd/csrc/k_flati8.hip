@@ -479,15 +479,9 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 }
 
 hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    const void* fns[2] = {(const void*)flat_scan_i8_kernel<false>, (const void*)flat_scan_i8_kernel<true>};
-    for (const void* f : fns) {
-      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesI8);
-      if (e != hipSuccess) return e;
-    }
-    attr_set = true;
-  }
+  static DynLdsAttr attr;
+  const void* fns[2] = {(const void*)flat_scan_i8_kernel<false>, (const void*)flat_scan_i8_kernel<true>};
+  if (hipError_t e = attr.ensure(fns, 2, kLdsBytesI8); e != hipSuccess) return e;
   const uint32_t grid = a.q_tiles * a.n_chunks;
   if (a.dump) hipLaunchKernelGGL((flat_scan_i8_kernel<true>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
   else hipLaunchKernelGGL((flat_scan_i8_kernel<false>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);

@@ -464,16 +464,10 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
 
 hipError_t launch_graph_search(const GraphArgs& a, hipStream_t st) {
   const size_t lds = graph_lds_bytes(a.ld, a.ef_cap);
-  static size_t attr_set = 0;
-  if (lds > 64 * 1024 && lds > attr_set) {
-    const void* fns[3] = {(const void*)graph_search_kernel<0, false>, (const void*)graph_search_kernel<1, true>,
-                          (const void*)graph_search_kernel<1, false>};
-    for (const void* f : fns) {
-      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-    }
-    attr_set = lds;
-  }
+  static DynLdsAttr attr;
+  const void* fns[3] = {(const void*)graph_search_kernel<0, false>, (const void*)graph_search_kernel<1, true>,
+                        (const void*)graph_search_kernel<1, false>};
+  if (hipError_t e = attr.ensure(fns, 3, lds); e != hipSuccess) return e;
   if (a.metric == 0) hipLaunchKernelGGL((graph_search_kernel<0, false>), dim3(a.nq), dim3(64), lds, st, a);
   else if (a.metric == 2) hipLaunchKernelGGL((graph_search_kernel<1, true>), dim3(a.nq), dim3(64), lds, st, a);
   else hipLaunchKernelGGL((graph_search_kernel<1, false>), dim3(a.nq), dim3(64), lds, st, a);

@@ -385,13 +385,9 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
 
 hipError_t launch_insert_search(const InsertArgs& a, uint32_t n_new, hipStream_t st) {
   const size_t lds = insert_lds_bytes(a.ld, a.ef);
-  static size_t attr_set = 0;
-  if (lds > 64 * 1024 && lds > attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)insert_search_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = lds;
-  }
+  static DynLdsAttr attr;
+  const void* fns[1] = {(const void*)insert_search_kernel};
+  if (hipError_t e = attr.ensure(fns, 1, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(insert_search_kernel, dim3(n_new), dim3(64), lds, st, a);
   return hipGetLastError();
 }

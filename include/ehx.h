@@ -113,7 +113,7 @@ typedef struct ehx_params {
                                process — row g lives in shard g % G on device_ids[(g % G) % n_devices] of ehx_init;
                                ehx_set* route by row id, ehx_knn* search every shard concurrently, copy each local
                                top-k peer-to-peer (xGMI) to shard 0's device and merge there; ids stay the dense
-                               global row ids.  k <= 64; graph import / export are per-shard operations. */
+                               global row ids; k as for an unsharded space.  Graph import / export are per-shard operations.   */
   uint32_t reserved[5];
 } ehx_params;
 

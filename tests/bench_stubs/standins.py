@@ -39,6 +39,12 @@ class FakeSpace:
     def set_batch(self, keys, X):
         self.X = np.concatenate([self.X, np.asarray(X, dtype=np.float32)])
 
+    def prepare_batch(self, keys, X):
+        return keys, np.asarray(X, dtype=np.float32)
+
+    def set_prepared(self, prep):
+        self.set_batch(*prep)
+
     def knn(self, Q, k):
         Q = np.asarray(Q, dtype=np.float32).reshape(-1, self.dims)
         ids, dist, cnt = pyoracle.exhaustive(self.X, Q, k, self._om())

@@ -47,7 +47,7 @@ def bench_on_stand_ins(monkeypatch):
 
 SMALL = ["--rows", "3000", "--dims", "32", "--batch", "16", "--steps", "3", "--warmup", "1", "--check-queries", "8",
          "--cpu-sample-rows", "3000", "--cpu-sample-queries", "8", "--cpu-hnsw-rows", "500", "--graph-batches", "2",
-         "--graph-efs", "10,20"]
+         "--graph-efs", "10,20", "--set-concurrent", "0"]
 
 
 def test_default_flow_prints_one_json_line_with_the_contract_fields(bench_on_stand_ins):
@@ -68,11 +68,33 @@ def test_default_flow_prints_one_json_line_with_the_contract_fields(bench_on_sta
     assert "host_pointer_path" in r and "f32_scan_engine" in r
 
 
+def test_set_concurrent_is_a_default_leg(bench_on_stand_ins):
+    """streamed Set concurrent with search (BASELINE configs[4]) must be driver-visible: on by default"""
+    monkey_argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        assert bench_on_stand_ins.module.parse().set_concurrent > 0      # the default itself
+    finally:
+        sys.argv = monkey_argv
+    r = bench_on_stand_ins(SMALL[:-2] + ["--set-concurrent", "4096", "--graph-rows", "0", "--structured-rows", "0",
+                                         "--no-cpu-baseline"])
+    sc = r["set_concurrent"]
+    assert sc["rows_written_meanwhile"] == 4096 and sc["error"] is None
+    assert sc["search_batches_meanwhile"] >= 1 and sc["set_rows_per_s_meanwhile"] > 0
+    assert "set_concurrent" not in r["optional_legs_skipped"]
+
+
 def test_a_spent_time_budget_skips_the_optional_legs_and_says_so(bench_on_stand_ins):
     r = bench_on_stand_ins(SMALL + ["--graph-rows", "1000", "--structured-rows", "600", "--time-budget", "0"])
     assert "graph_path" not in r and "graph_path_structured" not in r
     assert set(r["optional_legs_skipped"]) == {"graph_path", "graph_path_structured"}
     assert "cpu_baseline" in r and r["exactness"]["recall_at_10"] == 1.0   # the required legs ran
+
+
+def test_a_spent_time_budget_skips_the_set_concurrent_leg_too(bench_on_stand_ins):
+    r = bench_on_stand_ins(SMALL[:-2] + ["--set-concurrent", "4096", "--graph-rows", "0", "--structured-rows", "0",
+                                         "--time-budget", "0", "--no-cpu-baseline"])
+    assert "set_concurrent" not in r and "set_concurrent" in r["optional_legs_skipped"]
 
 
 def test_a_slow_host_gets_the_prefix_check(bench_on_stand_ins, monkeypatch):

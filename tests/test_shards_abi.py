@@ -112,3 +112,58 @@ def test_shards_are_hidden_and_dropped_with_their_parent():
     t.set("b", np.ones(8, dtype=np.float32))
     assert t.knn_keys(np.ones(8, np.float32), 1) == [["b"]]
     t.drop()
+
+
+@pytest.mark.parametrize("k", [65, 100, 300])
+def test_sharded_space_serves_large_k_like_an_unsharded_one(k):
+    """sharded spaces capped k at 64 while unsharded ones serve 1024 — every shard pages its own exhaustive
+    pass beyond 48 results, and the merge walks the G lists (merge_lists_walk_kernel) beyond 64"""
+    rng = np.random.default_rng(k)
+    n, d, nq = 2600, 40, 9
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    X[1700] = X[3]                                    # a cross-shard exact tie: (distance, id) order decides
+    Q = np.concatenate([X[:3], rng.standard_normal((nq - 3, d)).astype(np.float32)])
+    s = ehx.Space.unique("shk", d, metric=ehx.METRIC_L2SQ, shards=3)
+    s.set_batch(_keys(n), X)
+    _check(s, X, Q, k, pyoracle.METRIC_L2)
+    s.drop()
+    tiny = ehx.Space.unique("shk2", d, metric=ehx.METRIC_COSINE, shards=4)   # fewer rows than k: count < k
+    tiny.set_batch(_keys(50), X[:50])
+    _check(tiny, X[:50], Q, k, pyoracle.METRIC_COSINE)
+    tiny.drop()
+
+
+def test_dropping_a_sharded_space_under_concurrent_searches():
+    """the parent is marked dropped (under its exclusive lock) BEFORE its shards are released, so a search
+    racing with the drop either completes on live shards or reports NOT_FOUND — never reads a released shard"""
+    import threading
+    rng = np.random.default_rng(12)
+    n, d = 4000, 32
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((16, d)).astype(np.float32)
+    oids, _, _ = pyoracle.exhaustive(X, Q, 5, pyoracle.METRIC_L2)
+    for rnd in range(3):
+        s = ehx.Space.unique("shdrop", d, metric=ehx.METRIC_L2SQ, shards=4)
+        s.set_batch(_keys(n), X)
+        outcomes, stop = [], threading.Event()
+
+        def searcher():
+            while not stop.is_set():
+                try:
+                    ids, _, _ = s.knn(Q, 5)
+                    outcomes.append("ok" if np.array_equal(ids, oids) else "WRONG")
+                except ehx.EhxError as e:
+                    outcomes.append("gone" if e.code == ehx._lib.ENOTFOUND else "ERR %d" % e.code)
+                    return
+        ts = [threading.Thread(target=searcher) for _ in range(4)]
+        for t in ts:
+            t.start()
+        import time
+        time.sleep(0.05 * (rnd + 1))
+        s.drop()
+        stop.set()
+        for t in ts:
+            t.join(timeout=30)
+            assert not t.is_alive()
+        assert set(outcomes) <= {"ok", "gone"}, set(outcomes)
+        assert "gone" in outcomes or all(o == "ok" for o in outcomes)
