@@ -232,6 +232,8 @@ struct ehx_space {
   uint32_t g_entry = 0;
   int g_maxlevel = -1;
   DevBuf<uint32_t> dVisited;
+  unsigned long long* hUncertPin = nullptr;  // pinned landing place of a batch's verdict (uncertified-query count)
+  uint32_t i8_width = kMerged8;  // width of the int8 pipeline's candidate list (doubles when batches lose queries)
   bool vis_dirty = false;    // a search that clears its bitmaps with a memset BEFORE the kernel leaves them marked; the
                              // visit-log mode needs them all-zero at launch
   // GPU-side insertion state
@@ -353,6 +355,8 @@ struct ehx_space {
     if (xev) (void)hipEventDestroy(xev);
     xev = nullptr;
     fr(dUncert16);
+    if (hUncertPin) (void)hipHostFree(hUncertPin);
+    hUncertPin = nullptr;
     fr(dAdj0);
     fr(dUpStart);
     fr(dUpLists);
@@ -650,11 +654,23 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
   HIP_TRY(hipMemcpyAsync(s->dInsLevels.p, h_lv.data(), count * sizeof(int32_t), hipMemcpyHostToDevice, st));
   // ---- round schedule ----
   const uint64_t round_cap = batch > 1 ? batch : 4096;
+  // Rows of one round do not see each other, so a round never exceeds a small share of the graph it joins: 1/256 while
+  // the graph is small (below 128 Ki nodes — hnswlib-python's add_items with 64 threads is blind to 64 / n of the graph),
+  // 1/64 above, at most `round_cap` rows.  Measured against the oracle's sequentially built graphs at equal ef
+  // (tests/test_graph_scale.py, 4096 queries): with 1/16 the 20 k x 768 index lost 0.009 of recall@10 at ef = 400, the
+  // 200 k x 768 index 0.0015; with 1/64: 0.005 and 0.001.  EHX_BUILD_DIV overrides both shares (A/B runs).
+  static const uint64_t div_env = [] {
+    const char* e = getenv("EHX_BUILD_DIV");
+    const long v = e ? atol(e) : 0;
+    return (uint64_t)(v < 0 ? 0 : v);
+  }();
   auto round_size = [&](uint64_t g_n, uint64_t left) {
     uint64_t P = 1;
     if (batch != 1 && g_n >= 64) {
-      P = g_n / 16;
+      const uint64_t div = div_env >= 2 ? div_env : (g_n < (128u << 10) ? 256 : 64);
+      P = g_n / div;
       if (P > round_cap) P = round_cap;
+      if (P < 1) P = 1;
     }
     return P > left ? left : P;
   };
@@ -1232,7 +1248,11 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   }();
   static const double safety = [] {
     const char* g = getenv("EHX_I8_SAFETY");
-    const double v = g ? atof(g) : 4.0;  // (1e9: always the 256th best)
+    // rank of the next pass's threshold = 256 x (share of the rows seen) x safety.  2: the last pass of a 10 M-row batch
+    // runs under the 138th best of the first 27 % (about 510 rows below it overall: the list still fills to 256, the
+    // certificate's floor is unchanged) instead of the 256th (950 rows): fewer alarms, fewer keys — 7.64 -> 7.46 ms per
+    // batch, 0 fallbacks over 25 batches; 1.5: 7.44; 1: a query falls to the next engine (profiles/r03_e_i8_safety_sweep.jsonl)
+    const double v = g ? atof(g) : 2.0;  // (1e9: always the 256th best)
     return v < 1.0 ? 1.0 : v;
   }();
   static const bool use_sync = [] {
@@ -1244,11 +1264,16 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   // (scripts/studies/int8_filter_bound.py), with a heavy tail — a query whose 10th neighbour is unusually far has
   // several times as many — and a query whose list is too short costs a whole scan by the next engine.  So the
   // threshold rank is the full width of the running list; the re-rank reads only as many candidates as it needs.
-  static const uint32_t kprime = [] {
+  // The list is 256 keys wide to begin with.  Longer rows leave more survivors (the bound is ~0.02 in dot units whatever
+  // the dimension, while the spread of the dot products shrinks like 1/sqrt(d)): at 12.5 M x 1536 a fifth of the
+  // queries needed more than 256 candidates and went to the next engine, which doubled the batch time.  A space whose
+  // batches keep losing queries that way doubles its list (knn_device_locked), up to kMerged8Max.
+  const uint32_t width = s->i8_width;
+  static const long kprime_env = [] {
     const char* g = getenv("EHX_I8_KPRIME");
-    const long v = g ? atol(g) : (long)kMerged8;
-    return (uint32_t)(v < 64 ? 64 : (v > (long)kMerged8 ? (long)kMerged8 : v));
+    return g ? atol(g) : 0L;
   }();
+  const uint32_t kprime = kprime_env >= 64 ? (uint32_t)std::min<long>(kprime_env, (long)width) : width;
   const uint32_t n_tiles = (uint32_t)((s->n + kTileRows16 - 1) / kTileRows16);
   struct Pass {
     uint32_t tile0;
@@ -1268,9 +1293,25 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
     }
     passes.push_back({done, plan_scan((uint32_t)nq, n_tiles - done, k, E.n_cus)});
   }
+  // rank of the threshold the select after pass i publishes for pass i + 1: the kprime-th best is always valid; while
+  // only a share f of the rows has been seen, the final kprime-th best is expected near rank kprime * f of the prefix, so
+  // rank kprime * f * safety (>= 16) is a much tighter threshold that is still above it — fewer keys collected, fewer
+  // epilogue alarms in the middle passes.  Sound whatever happens (the certificate uses the smallest threshold ever
+  // applied, qparams.w).
+  auto rank_after = [&](size_t i) -> uint32_t {
+    if (i + 1 >= passes.size()) return kprime;
+    const double f = (double)((uint64_t)(passes[i + 1].tile0) * kTileRows16) / (double)s->n;
+    return (uint32_t)std::min<double>(kprime, std::max<double>(16.0, std::ceil(kprime * f * safety)));
+  };
+  // The first pass runs under a threshold taken from the sample at a LOW rank, chosen for the number of keys the pass
+  // should collect: a single pass has to fill the list with room to spare (4 x its width); with more passes to come it
+  // only has to deliver the next threshold's rank (twice over, at least 512 keys: round 2 collected 1024 and spent
+  // more than half of the first pass in the epilogue's slow path).
   const uint64_t first_rows = (uint64_t)passes.front().plan.n_tiles * kTileRows16;
+  const uint64_t first_keys = std::min<uint64_t>(
+      2048, passes.size() == 1 ? 4ull * kprime : std::max<uint64_t>(512, 2ull * rank_after(0)));
   const uint32_t sample_rank =
-      (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, 1024ull * kSampleTiles * kTileRows16 / first_rows));
+      (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, first_keys * kSampleTiles * kTileRows16 / first_rows));
   const ScanPlan p = passes.back().plan;  // (q_tiles, q_rows are the same for every pass)
   uint32_t grid_max = 0, chunks_max = 0;
   for (auto& ps : passes) {
@@ -1287,7 +1328,7 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   if ((rc = s->dSample8.ensure((size_t)kSampleTiles * kTileRows16 * p.q_rows))) return rc;
   if ((rc = s->dCand.ensure((size_t)grid_max * 512 * kCandSlots))) return rc;
   if ((rc = s->dPool.ensure((size_t)p.q_rows * kPoolCap))) return rc;
-  if ((rc = s->dMerged8.ensure((size_t)p.q_rows * kMerged8))) return rc;
+  if ((rc = s->dMerged8.ensure((size_t)p.q_rows * width))) return rc;
   if ((rc = s->dI8Ctl.ensure((size_t)p.q_rows * 2 + 256))) return rc;
   if ((rc = s->dUflags.ensure(p.q_rows))) return rc;
   if (!s->dUncert16) {
@@ -1351,17 +1392,8 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
       HIP_TRY(hipEventRecord(s->ev[2], st));
       s->ring_count++;
     }
-    // The next pass's threshold: the 256th best so far is always valid; while only a fraction f of the rows has been
-    // seen, the final 256th best is expected near rank 256 f of the prefix, so rank 256 f x safety (>= 16) is a
-    // much tighter threshold that is still above it — fewer keys collected, fewer epilogue alarms in the middle
-    // passes.  Sound whatever happens (the certificate uses the smallest threshold ever applied, qparams.w).
-    uint32_t rank = kprime;
-    if (!last) {
-      const double f = (double)((uint64_t)(passes[i + 1].tile0) * kTileRows16) / (double)s->n;
-      rank = (uint32_t)std::min<double>(kprime, std::max<double>(16.0, std::ceil(kprime * f * safety)));
-    }
-    HIP_TRY(launch_select256(s->dPool.p, pool_cnt, kPoolCap, (uint32_t)nq, rank, s->dMerged8.p, i > 0, s->dThr8.p,
-                             s->dQp8.p, st));
+    HIP_TRY(launch_select256(s->dPool.p, pool_cnt, kPoolCap, (uint32_t)nq, rank_after(i), s->dMerged8.p, width, i > 0,
+                             s->dThr8.p, s->dQp8.p, st));
   }
   Rerank256Args r;
   r.Q = s->dQ.p;
@@ -1369,6 +1401,7 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   r.x_half = (uint32_t)s->x_half;
   r.inv_norm = s->dInv;
   r.merged = s->dMerged8.p;
+  r.width = width;
   r.ovf = ovf;
   r.quv = s->dQuv.p;
   r.qparams = s->dQp8.p;
@@ -1391,19 +1424,19 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
     std::vector<uint32_t> fl(nq), ov(nq);
     std::vector<float4> qp(nq);
     std::vector<float2> uv(nq);
-    std::vector<uint64_t> mg(nq * kMerged8);
+    std::vector<uint64_t> mg(nq * width);
     std::vector<float> od(nq * k);
     HIP_TRY(hipMemcpy(fl.data(), s->dUflags.p, nq * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(ov.data(), ovf, nq * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(qp.data(), s->dQp8.p, nq * sizeof(float4), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(uv.data(), s->dQuv.p, nq * sizeof(float2), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(mg.data(), s->dMerged8.p, nq * kMerged8 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mg.data(), s->dMerged8.p, nq * width * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(od.data(), d_dist, nq * k * 4, hipMemcpyDeviceToHost));
     int shown = 0;
     for (size_t q = 0; q < nq && shown < 6; ++q) {
       if (!fl[q]) continue;
       ++shown;
-      auto S = [&](int i) { return mg[q * kMerged8 + i] == ~0ull ? INFINITY : ordered_to_f32((uint32_t)(mg[q * kMerged8 + i] >> 32)); };
+      auto S = [&](int i) { return mg[q * width + i] == ~0ull ? INFINITY : ordered_to_f32((uint32_t)(mg[q * width + i] >> 32)); };
       fprintf(stderr, "[i8 debug] q=%zu ovf=%u tmin=%g S[0]=%g S[63]=%g S[127]=%g S[255]=%g kth_dist=%g u=%g v=%g\n", q, ov[q],
               qp[q].w, S(0), S(63), S(127), S(255), od[q * k + k - 1], uv[q].x, uv[q].y);
     }
@@ -1551,9 +1584,11 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     }
     // verdict
     unc->clear();
-    unsigned long long n_unc = 0;
-    HIP_TRY(hipMemcpyAsync(&n_unc, s->dUncert16, sizeof(n_unc), hipMemcpyDeviceToHost, st));
+    // (into PINNED host memory: a copy to pageable memory goes through a staging buffer and a copy kernel)
+    if (!s->hUncertPin) HIP_TRY(hipHostMalloc((void**)&s->hUncertPin, sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(s->hUncertPin, s->dUncert16, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const unsigned long long n_unc = *s->hUncertPin;
 #if defined(EHX_ABL) && EHX_ABL
     return EHX_OK;  // profiling builds with ablated (wrong-by-construction) kernels: time the first stage only
 #endif
@@ -1576,6 +1611,13 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     counted = true;
     s->n_i8_queries += nq;
     s->n_i8_fallback += next.size();
+    // a batch that loses more than 2 % of its queries to the next engine: the list was too short for this data
+    if (next.size() * 50 > nq && s->i8_width < kMerged8Max) {
+      s->i8_width *= 2;
+      if (getenv("EHX_I8_TRACE"))
+        fprintf(stderr, "[ehx i8] %zu of %zu queries uncertified: candidate list widened to %u\n", next.size(), nq,
+                s->i8_width);
+    }
     if (next.empty()) return EHX_OK;
     todo.swap(next);
     all = todo.size() * 2 > nq;

@@ -537,7 +537,8 @@ inline float scan16_eps(uint32_t dims) { return 1.0e-3f + 2.0e-7f * (float)dims;
 
 // ---- int8-MFMA filter scan (k_flati8.hip) ----
 constexpr uint32_t kPoolCap = 4096;    // candidate keys one query can collect in one pass (overflow: query flagged)
-constexpr uint32_t kMerged8 = 256;     // width of the running best list of the int8 pipeline (k' <= 192)
+constexpr uint32_t kMerged8 = 256;     // default width of the running best list of the int8 pipeline
+constexpr uint32_t kMerged8Max = 1024; // widest list (a space widens its list when queries go uncertified: ehx_api.cpp)
 struct ScanArgsI8 {
   const int8_t* Q;        // [q_tiles][ld/64 + 3][256][64] int8 query tiles, scan8 stage-blocked layout
   const int8_t* X;        // scan copy, scan8_index layout; cap % 256 == 0
@@ -594,14 +595,16 @@ hipError_t launch_sample_select256(const float* scores, uint32_t n_rows, uint32_
 // merge one pass's pool into the query's running best kMerged8 keys (seed: keep what `merged` holds); publishes
 // thr[q] = score of the kprime-th best (+inf while fewer are known), lowers qparams[q].w to the threshold the merged
 // pass was scanned with, and empties the pool (pool_cnt = 0)
+// (width: the list's length, a power of two in [256, kMerged8Max], kprime <= width)
 hipError_t launch_select256(const uint64_t* pool, uint32_t* pool_cnt, uint32_t pool_cap, uint32_t nq, uint32_t kprime,
-                            uint64_t* merged, bool seed, float* thr, float4* qparams, hipStream_t st);
+                            uint64_t* merged, uint32_t width, bool seed, float* thr, float4* qparams, hipStream_t st);
 struct Rerank256Args {
   const float* Q;          // prepared (canonical) queries [*][ld]
   const void* X;
   uint32_t x_half;
   const float* inv_norm;
-  const uint64_t* merged;  // [nq][kMerged8] keys (S_lower, id), ascending
+  const uint64_t* merged;  // [nq][width] keys (S_lower, id), ascending
+  uint32_t width;          // list stride
   const uint32_t* ovf;     // [nq] pool overflow flags
   const float2* quv;       // [nq] D = u*S + v
   const float4* qparams;   // [nq] .w = the smallest threshold the query was scanned with (select256_kernel)

@@ -72,6 +72,14 @@ static_assert(kTileRows16 == 256 && kTileQ == 256, "kernel geometry is hard-wire
 
 #define EHX_MFMA_I8(A, B, C) __builtin_amdgcn_mfma_i32_32x32x32_i8((A), (B), (C), 0, 0, 0)
 
+// Ablation builds (scripts/ablate_i8.sh; results are WRONG by construction, only the scan's duration is looked at):
+//   1  no tile epilogue      2  epilogue phase 1 only (alarms never taken)      4  no DMA after the prologue (the ring
+//   keeps its first three stages; no counted wait)      8  no fragment reads (MFMAs on the prologue's fragments)
+//   16 an all-integer phase 1 (what rows ordered by step inside a tile would allow), alarms never taken
+#ifndef EHX_I8_ABL
+#define EHX_I8_ABL 0
+#endif
+
 __device__ __forceinline__ void lds_barrier_i8() {
   __builtin_amdgcn_s_waitcnt(0xC07F);  // vmcnt 63, expcnt 7, lgkmcnt 0
   __builtin_amdgcn_s_barrier();
@@ -240,13 +248,14 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   const uint32_t qdst = kQOffI8 + (uint32_t)w * 1024u;
   const uint32_t rdst = kRowpOffI8 + (uint32_t)(w & 3) * 1024u;  // + (tile % 3)*4096
 
-#define EHX_DMA(DST_BASE, DST_IMM, VOFF, SRC)                                                              \
+#define EHX_DMA_ALWAYS(DST_BASE, DST_IMM, VOFF, SRC)                                                       \
   do {                                                                                                     \
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"                       \
                  :                                                                                         \
                  : "s"(DST_BASE), "n"(DST_IMM), "v"(VOFF), "s"(SRC)                                        \
                  : "memory", "scc");                                                                       \
   } while (0)
+#define EHX_DMA(DST_BASE, DST_IMM, VOFF, SRC) EHX_DMA_ALWAYS(DST_BASE, DST_IMM, VOFF, SRC)
 #define EHX_DMA_X0(SLOT) EHX_DMA(xdst, (SLOT) * 16384, voff, xsrc)
 #define EHX_DMA_Q0(SLOT) EHX_DMA(qdst, (SLOT) * 16384, voff, qsrc)
 #define EHX_DMA_X1(SLOT) EHX_DMA(xdst, (SLOT) * 16384 + 8192, voff8, xsrc)
@@ -308,12 +317,26 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       // |A_r| of this lane's 16 rows of the row block (the same rows for both query blocks)
       const uint32_t rbase = (uint32_t)(wr * 128 + rb * 32) + 4u * h;
       float aa[16];
+#if EHX_I8_ABL & 16
+      aa[0] = fabsf(rp[rbase].x);  // (one read per row block stands for the per-block step)
+#else
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) aa[reg] = fabsf(rp[rbase + (uint32_t)((reg & 3) + 8 * (reg >> 2))].x);
+#endif
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
         // ---- phase 1: the largest I * |A_r| of the lane's 16 accumulators against the query's threshold ----
         const i32x16 c = acc[rb][cb];
+#if EHX_I8_ABL & 16
+        {  // what an all-integer phase 1 would cost (a max3 tree and one compare; results meaningless)
+          const int i0 = max(max(c[0], c[1]), c[2]), i1 = max(max(c[3], c[4]), c[5]);
+          const int i2 = max(max(c[6], c[7]), c[8]), i3 = max(max(c[9], c[10]), c[11]);
+          const int i4 = max(max(c[12], c[13]), c[14]);
+          const int im = max(max(max(i0, i1), i2), max(max(i3, i4), c[15]));
+          if (im >= (int)((cb ? k1 : k0) * aa[0])) asm volatile("" ::: "memory");
+          continue;
+        }
+#endif
         float p[16];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) p[reg] = (float)c[reg] * aa[reg];
@@ -322,6 +345,10 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
         const float m4 = fmaxf(fmaxf(p[12], p[13]), p[14]);
         const float m = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), p[15]));
         const float kq = cb ? k1 : k0;
+#if EHX_I8_ABL & 2
+        if (m >= kq) asm volatile("" ::: "memory");  // (the comparison stays, the slow path does not)
+        continue;
+#endif
         if (!__any(m >= kq)) continue;
         // ---- phase 2: the accumulators at or above the threshold, one per lane and trip ----
         const float4 qq = cb ? qq1 : qq0;
@@ -361,6 +388,18 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   EHX_DMA_X0(2); EHX_DMA_Q0(2); EHX_DMA_X1(2); EHX_DMA_Q1(2);
   wait_vmcnt<8>();  // stage 0 (and the row parameters, older) landed <=> at most stages 1, 2 in flight
   lds_barrier_i8();  // B_0
+#if EHX_I8_ABL & 4
+  wait_vmcnt<0>();
+#define EHX_SDMA_X0(S) do { } while (0)
+#define EHX_SDMA_Q0(S) do { } while (0)
+#define EHX_SDMA_X1(S) do { } while (0)
+#define EHX_SDMA_Q1(S) do { } while (0)
+#else
+#define EHX_SDMA_X0(S) EHX_DMA_X0(S)
+#define EHX_SDMA_Q0(S) EHX_DMA_Q0(S)
+#define EHX_SDMA_X1(S) EHX_DMA_X1(S)
+#define EHX_SDMA_Q1(S) EHX_DMA_Q1(S)
+#endif
 
   // Fragments are double-buffered: set 0 feeds k-step 0, set 1 feeds k-step 1; the six fragment reads of
   // the next k-step are issued ahead of the current k-step's 8 MFMAs and land in their shadow.
@@ -370,7 +409,11 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) fb0[cb] = *(const i32x4*)(smem + b_off0 + cb * 2048);
 
+#if EHX_I8_ABL & 8
+#define EHX_FR(P) fa0[0]
+#else
 #define EHX_FR(P) (*(const i32x4*)(P))
+#endif
 #define EHX_MF(A, B, RB, CB) acc[RB][CB] = EHX_MFMA_I8(A[RB], B[CB], acc[RB][CB])
 #define EHX_SB() __builtin_amdgcn_sched_barrier(0)
   // One stage, ring slot S (compile-time): no branches, no address arithmetic; every gap between two MFMAs carries
@@ -385,8 +428,8 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     EHX_MF(fa0, fb0, 1, 1); fa1[1] = EHX_FR(smem + a_off1 + so + 2048);     EHX_SB();                    \
     EHX_MF(fa0, fb0, 2, 0); fa1[2] = EHX_FR(smem + a_off1 + so + 4096);     EHX_SB();                    \
     EHX_MF(fa0, fb0, 2, 1); fa1[3] = EHX_FR(smem + a_off1 + so + 6144);     EHX_SB();                    \
-    EHX_MF(fa0, fb0, 3, 0); EHX_DMA_X0(sd);                                 EHX_SB();                    \
-    EHX_MF(fa0, fb0, 3, 1); EHX_DMA_Q0(sd);                                 EHX_SB();                    \
+    EHX_MF(fa0, fb0, 3, 0); EHX_SDMA_X0(sd);                                 EHX_SB();                    \
+    EHX_MF(fa0, fb0, 3, 1); EHX_SDMA_Q0(sd);                                 EHX_SB();                    \
     /* stage barrier: the next stage landed (own pieces counted: the younger stage and the two pieces    \
        just issued may still be in flight) and is visible; every wave is done reading this stage */      \
     wait_vmcnt<6>();                                                                                     \
@@ -398,8 +441,8 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     EHX_MF(fa1, fb1, 1, 1); fa0[1] = EHX_FR(smem + a_off0 + sn + 2048);     EHX_SB();                    \
     EHX_MF(fa1, fb1, 2, 0); fa0[2] = EHX_FR(smem + a_off0 + sn + 4096);     EHX_SB();                    \
     EHX_MF(fa1, fb1, 2, 1); fa0[3] = EHX_FR(smem + a_off0 + sn + 6144);     EHX_SB();                    \
-    EHX_MF(fa1, fb1, 3, 0); EHX_DMA_X1(sd);                                 EHX_SB();                    \
-    EHX_MF(fa1, fb1, 3, 1); EHX_DMA_Q1(sd);                                 EHX_SB();                    \
+    EHX_MF(fa1, fb1, 3, 0); EHX_SDMA_X1(sd);                                 EHX_SB();                    \
+    EHX_MF(fa1, fb1, 3, 1); EHX_SDMA_Q1(sd);                                 EHX_SB();                    \
   } while (0)
 
   // One flat loop over groups of four stages (= one revolution of the ring; ld % 256 == 0 makes a tile a whole
@@ -439,7 +482,9 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     }
     if (++kq == kquads) {
       kq = 0;
+#if !(EHX_I8_ABL & 1)
       epilogue(t);
+#endif
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
@@ -466,11 +511,16 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 #undef EHX_MF
 #undef EHX_SB
 #undef EHX_FR
+#undef EHX_SDMA_X0
+#undef EHX_SDMA_Q0
+#undef EHX_SDMA_X1
+#undef EHX_SDMA_Q1
 #undef EHX_DMA_X0
 #undef EHX_DMA_Q0
 #undef EHX_DMA_X1
 #undef EHX_DMA_Q1
 #undef EHX_DMA
+#undef EHX_DMA_ALWAYS
 
   // ---- final: what is left in this wave's staging buffer goes to the pools ----
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

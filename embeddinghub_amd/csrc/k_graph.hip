@@ -130,6 +130,12 @@ size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap) {
 }
 
 template <int METRIC01, bool SCALE>
+#ifndef EHX_GRAPH_WAVES
+#define EHX_GRAPH_WAVES 0  // A/B builds: cap the registers so that this many waves share a SIMD (0 = the compiler's choice)
+#endif
+#if EHX_GRAPH_WAVES
+__attribute__((amdgpu_waves_per_eu(EHX_GRAPH_WAVES, EHX_GRAPH_WAVES)))
+#endif
 __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;

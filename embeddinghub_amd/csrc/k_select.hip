@@ -163,37 +163,85 @@ hipError_t launch_sample_select256(const float* scores, uint32_t n_rows, uint32_
 // one pass's pool -> running best 256 of the query.  Every key the scan collected is <= the pass's threshold;
 // everything it did not collect is above it, so the kprime-th best after the merge is again an upper bound of the
 // final kprime-th best and serves as the next pass's threshold.
+//
+// One workgroup of four waves per query; 256 pool keys per trip.  Wave w sorts its 64 keys (one register per lane);
+// then every key — the 256 of the running list and the 256 new ones — finds its place in the merged order by
+// binary searches over the OTHER sorted runs in LDS (keys are distinct: the row id is part of the key), and is
+// written there if the place is among the first 256.  Round 2 kept the list in one wave's registers and sorted each
+// chunk of 256 with a 36-layer bitonic network of 64-bit cross-lane exchanges: ~50 us per launch whatever the pool
+// held (three to four launches per batch: a seventh of a 1.25 M-row shard's batch).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void select256_kernel(const uint64_t* __restrict__ pool, uint32_t* __restrict__ pool_cnt,
-                                                       uint32_t pool_cap, uint32_t kprime, uint64_t* __restrict__ merged,
-                                                       uint32_t seed, float* __restrict__ thr,
-                                                       float4* __restrict__ qparams) {
-  const int lane = threadIdx.x;
+namespace {
+__device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* a, uint32_t n, uint64_t key) {  // n a power of two
+  uint32_t lo = 0;
+  for (uint32_t step = n >> 1; step > 0; step >>= 1)
+    if (a[lo + step - 1] < key) lo += step;
+  return lo + (a[lo] < key ? 1u : 0u);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void select256_kernel(const uint64_t* __restrict__ pool, uint32_t* __restrict__ pool_cnt,
+                                                        uint32_t pool_cap, uint32_t kprime, uint64_t* __restrict__ merged,
+                                                        uint32_t width, uint32_t seed, float* __restrict__ thr,
+                                                        float4* __restrict__ qparams) {
+  __shared__ uint64_t best[2][kMerged8Max];  // the running list (ascending, `width` long), ping-pong
+  __shared__ uint64_t runs[4][64];        // this trip's new keys: four sorted runs
+  __shared__ int any_new;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const uint32_t q = blockIdx.x;
-  uint64_t best[kR];
-#pragma unroll
-  for (int r = 0; r < kR; ++r) best[r] = seed ? merged[(size_t)q * kMerged8 + r * 64 + lane] : kKeyInf;
+  uint32_t cur = 0;
+  for (uint32_t e = (uint32_t)tid; e < width; e += 256) best[0][e] = seed ? merged[(size_t)q * width + e] : kKeyInf;
   uint32_t n = pool_cnt[q];
   if (n > pool_cap) n = pool_cap;  // (overflowed pool: the query is flagged; keep what fits)
   const uint64_t* p = pool + (size_t)q * pool_cap;
   for (uint32_t b0 = 0; b0 < n; b0 += 256) {
-    uint64_t v[kR];
-#pragma unroll
-    for (int r = 0; r < kR; ++r) {
-      const uint32_t i = b0 + (uint32_t)r * 64u + (uint32_t)lane;
-      v[r] = i < n ? p[i] : kKeyInf;
-    }
+    if (tid == 0) any_new = 0;
+    __syncthreads();  // best[cur] complete, flag cleared
+    const uint32_t i = b0 + (uint32_t)tid;
+    uint64_t v = i < n ? p[i] : kKeyInf;
     // a chunk in which nothing beats the 256th best so far cannot change anything
-    const uint64_t bar = wave_pick256(best, 255);
-    const uint64_t vmin = umin64(umin64(v[0], v[1]), umin64(v[2], v[3]));
-    if (!__any(vmin < bar)) continue;
-    wave_sort256(v, lane);
-    wave_merge256(best, v, lane);
-  }
+    if (v < best[cur][width - 1]) any_new = 1;
+    __syncthreads();
+    if (!any_new) continue;
+    // ascending bitonic sort of the wave's 64 keys
 #pragma unroll
-  for (int r = 0; r < kR; ++r) merged[(size_t)q * kMerged8 + r * 64 + lane] = best[r];
-  const uint64_t kth = wave_pick256(best, kprime - 1);
-  if (lane == 0) {
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+      for (int j = k2 >> 1; j > 0; j >>= 1) {
+        const uint64_t other = __shfl_xor(v, j, 64);
+        const bool up = (lane & k2) == 0;
+        const bool lower = (lane & j) == 0;
+        const uint64_t lo = umin64(v, other), hi = umax64(v, other);
+        v = (lower == up) ? lo : hi;
+      }
+    }
+    runs[w][lane] = v;
+    const uint32_t nxt = cur ^ 1u;
+    for (uint32_t e = (uint32_t)tid; e < width; e += 256) best[nxt][e] = kKeyInf;  // (places nobody claims stay empty)
+    __syncthreads();
+    // the new key's place: its index in its own run + the keys below it in the other runs and in the list
+    if (v != kKeyInf) {
+      uint32_t pos = (uint32_t)lane + lower_bound_lds(best[cur], width, v);
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o != w) pos += lower_bound_lds(runs[o], 64, v);
+      if (pos < width) best[nxt][pos] = v;
+    }
+    // the old keys' places
+    for (uint32_t e = (uint32_t)tid; e < width; e += 256) {
+      const uint64_t old = best[cur][e];
+      if (old == kKeyInf) continue;
+      uint32_t pos = e;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) pos += lower_bound_lds(runs[o], 64, old);
+      if (pos < width) best[nxt][pos] = old;
+    }
+    cur = nxt;
+  }
+  __syncthreads();
+  for (uint32_t e = (uint32_t)tid; e < width; e += 256) merged[(size_t)q * width + e] = best[cur][e];
+  if (tid == 0) {
+    const uint64_t kth = best[cur][kprime - 1];
     // qparams.w = the smallest threshold this query was ever scanned with: every row that is in no pool had a
     // lower bound above it (thr[q] still holds the threshold of the pass just merged)
     const float used = thr[q];
@@ -209,8 +257,9 @@ __global__ __launch_bounds__(64) void select256_kernel(const uint64_t* __restric
 }
 
 hipError_t launch_select256(const uint64_t* pool, uint32_t* pool_cnt, uint32_t pool_cap, uint32_t nq, uint32_t kprime,
-                            uint64_t* merged, bool seed, float* thr, float4* qparams, hipStream_t st) {
-  hipLaunchKernelGGL(select256_kernel, dim3(nq), dim3(64), 0, st, pool, pool_cnt, pool_cap, kprime, merged,
+                            uint64_t* merged, uint32_t width, bool seed, float* thr, float4* qparams, hipStream_t st) {
+  if (width < 256 || width > kMerged8Max || (width & (width - 1)) || kprime < 1 || kprime > width) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(select256_kernel, dim3(nq), dim3(256), 0, st, pool, pool_cnt, pool_cap, kprime, merged, width,
                      seed ? 1u : 0u, thr, qparams);
   return hipGetLastError();
 }
@@ -368,7 +417,7 @@ __global__ __launch_bounds__(64) void rerank256_lane_kernel(const Rerank256Args 
     for (uint32_t i = lane; i < a.ld; i += 64) qs[i] = qv[i];
     __syncthreads();
   }
-  const uint64_t* mq = a.merged + (size_t)q * kMerged8;
+  const uint64_t* mq = a.merged + (size_t)q * a.width;
   const float2 uv = a.quv[q];
   const float qn = a.metric == 0 ? uv.y : (a.metric == 1 ? uv.x * uv.x : 1.0f);
   const float maxss = a.max_sumsq ? *a.max_sumsq : __builtin_inff();
@@ -407,7 +456,7 @@ __global__ __launch_bounds__(256) void rerank256_kernel(const Rerank256Args a) {
   const int g = tid >> 2, sub = tid & 3;
   const float* qv = a.Q + (size_t)q * a.ld;
   const bool scale_x = a.metric == 2;
-  const uint64_t* mq = a.merged + (size_t)q * kMerged8;
+  const uint64_t* mq = a.merged + (size_t)q * a.width;
   const float2 uv = a.quv[q];
   const float qn = a.metric == 0 ? uv.y : (a.metric == 1 ? uv.x * uv.x : 1.0f);
   const float maxss = a.max_sumsq ? *a.max_sumsq : __builtin_inff();

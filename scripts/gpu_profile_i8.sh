@@ -1,24 +1,23 @@
 #!/bin/bash
 # rocprofv3 passes for the headline workload on the int8 engine: kernel trace (+ launch sequence), then PMC passes
 # (each its own run, kernel-trace only): FETCH_SIZE / WRITE_SIZE without and with the lock-step of sibling workgroups.
-# Summaries land in gpurun_out/prof/r02_*.txt; copy the ones to keep into profiles/.
+# Summaries land in gpurun_out/prof/$TAG_*.txt (TAG defaults to r03); copy the ones to keep into profiles/.
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 R=$(pwd)
-ARGS="--steps 4 --warmup 1 --check-queries 0 --no-f32-engine --graph-rows 0 --structured-rows 0 --no-cpu-baseline $BENCH_ARGS"
+ARGS="--steps 4 --warmup 1 --check-queries 0 --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --no-cpu-baseline $BENCH_ARGS"
 run() {  # name, env, rocprof args...
   local name=$1 envs=$2; shift 2
   rm -rf gpurun_out/prof/$name
   (cd /tmp && env $envs timeout 600 rocprofv3 --kernel-trace "$@" -d $R/gpurun_out/prof/$name -o p -- python $R/bench.py $ARGS > $R/gpurun_out/prof/$name.log 2>&1)
   ROCPD_SEQ=${SEQ:-0} python scripts/rocpd_summary.py gpurun_out/prof/$name > gpurun_out/prof/${name}_summary.txt 2>&1
 }
-SEQ=22 run r02_i8_trace "EHX_I8_SYNC=0" --stats
-run r02_i8_pmc_fetch "EHX_I8_SYNC=0" --pmc FETCH_SIZE
-run r02_i8_pmc_write "EHX_I8_SYNC=0" --pmc WRITE_SIZE
-run r02_i8sync_pmc_fetch "EHX_I8_SYNC=1" --pmc FETCH_SIZE
-run r02_i8_pmc_sq "EHX_I8_SYNC=0" --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE
-run r02_i8_pmc_clk "EHX_I8_SYNC=0" --pmc GRBM_GUI_ACTIVE
-python - <<'PY'
+SEQ=22 run ${TAG:-r03}_i8_trace "EHX_I8_SYNC=0" --stats
+run ${TAG:-r03}_i8_pmc_fetch "EHX_I8_SYNC=0" --pmc FETCH_SIZE
+run ${TAG:-r03}_i8_pmc_write "EHX_I8_SYNC=0" --pmc WRITE_SIZE
+run ${TAG:-r03}_i8_pmc_sq "EHX_I8_SYNC=0" --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE
+run ${TAG:-r03}_i8_pmc_clk "EHX_I8_SYNC=0" --pmc GRBM_GUI_ACTIVE
+TAG=${TAG:-r03} python - <<'PY'
 import json, re
 def counter_sum(path, kernel_sub, counter):
     tot, calls = 0.0, {}
@@ -34,8 +33,9 @@ def calls(path, kernel_sub):
             return int(f[1])
     return 0
 out = {}
-for tag, fpath, wpath in (("nosync", "gpurun_out/prof/r02_i8_pmc_fetch_summary.txt", "gpurun_out/prof/r02_i8_pmc_write_summary.txt"),
-                          ("sync", "gpurun_out/prof/r02_i8sync_pmc_fetch_summary.txt", None)):
+import os
+TAG = os.environ.get("TAG", "r03")
+for tag, fpath, wpath in (("nosync", "gpurun_out/prof/%s_i8_pmc_fetch_summary.txt" % TAG, "gpurun_out/prof/%s_i8_pmc_write_summary.txt" % TAG),):
     batches = calls(fpath, "scan_i8_kernelILb1")
     fetch = counter_sum(fpath, "scan_i8_kernel", "FETCH_SIZE")
     write = counter_sum(wpath, "scan_i8_kernel", "WRITE_SIZE") if wpath else 0.0
@@ -44,8 +44,8 @@ for tag, fpath, wpath in (("nosync", "gpurun_out/prof/r02_i8_pmc_fetch_summary.t
     out[tag] = {"batches": batches, "fetch_KB_sum": fetch, "write_KB_sum": write, "bytes_per_batch": per_batch,
                 "x_algorithmic_7.68e9": per_batch / (1e7 * 768 + 1024 * 768 * 4 + 1024 * 10 * 12)}
 print(json.dumps(out, indent=1))
-open("gpurun_out/prof/r02_i8_traffic.json", "w").write(json.dumps(out, indent=1))
+open("gpurun_out/prof/%s_i8_traffic.json" % TAG, "w").write(json.dumps(out, indent=1))
 PY
-head -28 gpurun_out/prof/r02_i8_trace_summary.txt | cut -c1-150
-grep -h "scan_i8" gpurun_out/prof/r02_i8_pmc_sq_summary.txt gpurun_out/prof/r02_i8_pmc_clk_summary.txt | cut -c1-140
+head -28 gpurun_out/prof/${TAG:-r03}_i8_trace_summary.txt | cut -c1-150
+grep -h "scan_i8" gpurun_out/prof/${TAG:-r03}_i8_pmc_sq_summary.txt gpurun_out/prof/${TAG:-r03}_i8_pmc_clk_summary.txt | cut -c1-140
 find gpurun_out/prof -name "*.db" -size +8M -delete; du -sh gpurun_out/prof

@@ -76,7 +76,9 @@ def test_oracle_graph_at_scale_imported_and_gpu_built(name):
     flat.drop()
     g = ehx.Space.unique("scale-gpu", d, metric=em, mode=ehx.MODE_GRAPH, initial_capacity=n, build_batch=4096)
     g.fill_synthetic(ehx.SEED_CORPUS, 0, n, norm)
-    report = {"name": name, "differing_queries_imported": differing, "recall": {}}
+    report = {"name": name, "build_div": os.environ.get("EHX_BUILD_DIV", "default"),
+              "differing_queries_imported": differing, "recall": {}}
+    worst = 0.0
     for ef in meta["efs"]:
         s.set_ef(ef)
         g.set_ef(ef)
@@ -84,7 +86,7 @@ def test_oracle_graph_at_scale_imported_and_gpu_built(name):
         r_gpu = _recall(g.knn(Q2, k)[0], truth)
         report["recall"][ef] = {"oracle_built": round(r_oracle, 4), "gpu_built_rounds_of_4096": round(r_gpu, 4),
                                 "oracle_stored_256q": meta["search"][str(ef)]["recall_at_10"]}
-        assert abs(r_gpu - r_oracle) <= 0.005, (name, ef, r_gpu, r_oracle)
+        worst = max(worst, abs(r_gpu - r_oracle))
     print(json.dumps(report))
     out = os.environ.get("EHX_SCALE_REPORT")
     if out:
@@ -92,6 +94,7 @@ def test_oracle_graph_at_scale_imported_and_gpu_built(name):
             f.write(json.dumps(report) + "\n")
     s.drop()
     g.drop()
+    assert worst <= 0.005, report
 
 
 def test_exact_distance_ties_engine_order_vs_heap_order():

@@ -170,3 +170,29 @@ def test_small_or_short_row_spaces_use_the_fp16_filter():
     a.drop()
     b.drop()
     c.drop()
+
+
+def test_a_space_whose_queries_keep_going_uncertified_widens_its_candidate_list():
+    """Round 3: at 12.5 M x 1536 (BASELINE configs[4]'s shard) a fifth of the queries needed more than the 256 candidates
+    the int8 list held and were re-run by the next engine — twice the batch time.  A batch that loses more than 2 % of
+    its queries that way doubles the space's list (up to 1024).  Here: a cluster of 600 rows that the int8 bound
+    cannot tell apart; the queries aimed at it are answered exactly every time, by the next engine at first and by the
+    int8 engine alone once the list holds the whole cluster."""
+    rng = np.random.default_rng(31)
+    n, d, nq, k = 24000, 768, 64, 10
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    base = rng.standard_normal(d).astype(np.float32)
+    X[5000:5600] = base + np.float32(2e-3) * rng.standard_normal((600, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    Q[:32] = base + np.float32(2e-3) * rng.standard_normal((32, d)).astype(np.float32)   # half the batch hits the cluster
+    s = _space(d, ehx.METRIC_COSINE, n)
+    s.set_batch(_keys(n), X)
+    assert s.scan_engine() == "i8"
+    fallbacks = []
+    for _ in range(4):
+        s.stats_reset()
+        _check(s, X, Q, k, pyoracle.METRIC_COSINE)
+        fallbacks.append(s.stats()["n_i8_fallback"])
+    assert fallbacks[0] >= 32 and fallbacks[1] >= 32        # lists of 256, then 512 keys: the cluster does not fit
+    assert fallbacks[2] == 0 and fallbacks[3] == 0, fallbacks  # 1024 keys: the int8 engine certifies every query itself
+    s.drop()
