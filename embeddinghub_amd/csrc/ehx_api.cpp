@@ -233,6 +233,7 @@ struct ehx_space {
   int g_maxlevel = -1;
   DevBuf<uint32_t> dVisited;
   unsigned long long* hUncertPin = nullptr;  // pinned landing place of a batch's verdict (uncertified-query count)
+  uint32_t i8_fb_score = 0;      // recent batches that lost queries to the next engine (see knn_device_locked)
   uint32_t i8_width = kMerged8;  // width of the int8 pipeline's candidate list (doubles when batches lose queries)
   bool vis_dirty = false;    // a search that clears its bitmaps with a memset BEFORE the kernel leaves them marked; the
                              // visit-log mode needs them all-zero at launch
@@ -1611,9 +1612,15 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     counted = true;
     s->n_i8_queries += nq;
     s->n_i8_fallback += next.size();
-    // a batch that loses more than 2 % of its queries to the next engine: the list was too short for this data
-    if (next.size() * 50 > nq && s->i8_width < kMerged8Max) {
+    // The list is too short for this data when batches keep losing queries to the next engine — which re-reads every
+    // row for them, nearly a batch's worth of time however few they are (12.5 M x 1536: 13 queries in 10 batches cost
+    // 45 % of the run).  A batch that loses more than 2 % of its queries widens the list at once; otherwise every
+    // losing batch adds 4 to a score that decays by 1 per clean batch, and 8 widens (two losing batches close together).
+    if (next.empty()) s->i8_fb_score = s->i8_fb_score ? s->i8_fb_score - 1 : 0;
+    else s->i8_fb_score += 4;
+    if ((next.size() * 50 > nq || s->i8_fb_score >= 8) && s->i8_width < kMerged8Max) {
       s->i8_width *= 2;
+      s->i8_fb_score = 0;
       if (getenv("EHX_I8_TRACE"))
         fprintf(stderr, "[ehx i8] %zu of %zu queries uncertified: candidate list widened to %u\n", next.size(), nq,
                 s->i8_width);
