@@ -655,20 +655,24 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
   HIP_TRY(hipMemcpyAsync(s->dInsLevels.p, h_lv.data(), count * sizeof(int32_t), hipMemcpyHostToDevice, st));
   // ---- round schedule ----
   const uint64_t round_cap = batch > 1 ? batch : 4096;
-  // Rows of one round do not see each other, so a round never exceeds a small share of the graph it joins: 1/256 while
-  // the graph is small (below 128 Ki nodes — hnswlib-python's add_items with 64 threads is blind to 64 / n of the graph),
-  // 1/64 above, at most `round_cap` rows.  Measured against the oracle's sequentially built graphs at equal ef
-  // (tests/test_graph_scale.py, 4096 queries): with 1/16 the 20 k x 768 index lost 0.009 of recall@10 at ef = 400, the
-  // 200 k x 768 index 0.0015; with 1/64: 0.005 and 0.001.  EHX_BUILD_DIV overrides both shares (A/B runs).
+  // Rows of one round do not see each other, so a round never exceeds a small share of the graph it joins: 1/64, at
+  // most `round_cap` rows — and 1/256 when the graph stays small (below 128 Ki nodes after this call: there every node is
+  // an early node, and hnswlib-python's add_items with 64 threads is blind to only 64 / n of the graph).  Measured
+  // against the oracle's sequentially built graphs at equal ef (tests/test_graph_scale.py, 4096 queries): with 1/16 the
+  // 20 k x 768 index lost 0.009 of recall@10 at ef = 400 and the 200 k x 768 index 0.0015; with 1/64: 0.005 and 0.001;
+  // with 1/256: 0.003 at 20 k.  A round costs ~2 ms however few rows it holds (one wave's ef_construction search is a
+  // millisecond of dependent steps), so the small share is not paid by builds that grow large: 2 M x 768 takes 18.4 s
+  // with 1/16, 24.0 s with 1/256 up to 128 Ki nodes, ~19.5 s with 1/64 throughout (profiles/r03_h_*).
+  // EHX_BUILD_DIV overrides the share (A/B runs).
   static const uint64_t div_env = [] {
     const char* e = getenv("EHX_BUILD_DIV");
     const long v = e ? atol(e) : 0;
     return (uint64_t)(v < 0 ? 0 : v);
   }();
+  const uint64_t div = div_env >= 2 ? div_env : (end < (128u << 10) ? 256 : 64);
   auto round_size = [&](uint64_t g_n, uint64_t left) {
     uint64_t P = 1;
     if (batch != 1 && g_n >= 64) {
-      const uint64_t div = div_env >= 2 ? div_env : (g_n < (128u << 10) ? 256 : 64);
       P = g_n / div;
       if (P > round_cap) P = round_cap;
       if (P < 1) P = 1;
@@ -1978,9 +1982,10 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
     s->has16 = s->use16;
     s->scan_sel = s->use16 ? s->params.scan : (uint32_t)EHX_SCAN_F32;
     s->ld16 = (uint32_t)round_up(dims, 128);
-    s->ld8 = (uint32_t)round_up(dims, 256);
-    // the int8 scan copy pays when its rows are clearly shorter than the fp16 copy's (both are padded to a whole
-    // number of LDS ring revolutions: 256 bytes here, 128 halves there)
+    s->ld8 = (uint32_t)round_up(dims, 64);
+    // the int8 scan copy pays when its rows are clearly shorter than the fp16 copy's (padded to whole 64-byte stages
+    // here — round 2 padded to 256 bytes, a whole ring revolution, which kept this engine off 128-dim rows and wasted
+    // a quarter of the work at 384 — and to a revolution of 128 halves there)
     // ... and while its error bound (~1.3e-2 in dot units whatever d) stays well below the spread of the scores
     // (~1/sqrt(d) for isotropic rows): beyond d = 2048 most queries would lose their certificate at 256 candidates
     // (measured at d = 4096: 12 of 20) and pay for a second pass, so longer rows start at the fp16 filter

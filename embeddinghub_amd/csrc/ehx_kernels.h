@@ -553,7 +553,7 @@ struct ScanArgsI8 {
   uint32_t* ovf;          // [q_tiles*256] 1 = the pool overflowed: the query must be answered by another engine
   uint32_t pool_cap;
   uint32_t n;
-  uint32_t ld;            // bytes (= k-values) per row of the scan copy, % 256 == 0
+  uint32_t ld;            // bytes (= k-values) per row of the scan copy, % 64 == 0 (whole 64-byte stages)
   uint32_t tile0, n_tiles, q_tiles, n_chunks, tiles_per_chunk;
   uint32_t xcd_map;
   uint32_t* sync = nullptr;  // [n_chunks] lock-step counters, zero before the launch (nullptr: off)

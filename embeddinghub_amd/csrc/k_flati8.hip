@@ -185,7 +185,7 @@ size_t scan_i8_lds_bytes() { return kLdsBytesI8; }
 
 // DUMP: the sample pass — every lower bound of the scanned tiles is written to a.dump[row - tile0*256][q] and
 // sample_select256_kernel turns them into the first thresholds.
-template <bool DUMP>
+template <bool DUMP, bool REV>
 __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanArgsI8 a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   uint32_t tile_end = tile_begin + a.tiles_per_chunk;
   if (tile_end > a.tile0 + a.n_tiles) tile_end = a.tile0 + a.n_tiles;
   const uint32_t my_tiles = tile_end > tile_begin ? tile_end - tile_begin : 0u;
-  const uint32_t ktiles = a.ld / kRowBI8;  // stages per tile, a multiple of 4
+  const uint32_t ktiles = a.ld / kRowBI8;  // stages per tile (a.ld % 64 == 0)
 
   // ---- DMA duty of this wave: 1-KiB pieces w and w+8 of the X stage block and of the Q stage block (linear
   // copies: the blocks are stored in HBM in the LDS image, scan8_index); waves 0..3 also one piece each of the
@@ -248,14 +248,22 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   const uint32_t qdst = kQOffI8 + (uint32_t)w * 1024u;
   const uint32_t rdst = kRowpOffI8 + (uint32_t)(w & 3) * 1024u;  // + (tile % 3)*4096
 
-#define EHX_DMA_ALWAYS(DST_BASE, DST_IMM, VOFF, SRC)                                                       \
+#define EHX_DMA(DST_BASE, DST_IMM, VOFF, SRC)                                                              \
   do {                                                                                                     \
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"                       \
                  :                                                                                         \
                  : "s"(DST_BASE), "n"(DST_IMM), "v"(VOFF), "s"(SRC)                                        \
                  : "memory", "scc");                                                                       \
   } while (0)
-#define EHX_DMA(DST_BASE, DST_IMM, VOFF, SRC) EHX_DMA_ALWAYS(DST_BASE, DST_IMM, VOFF, SRC)
+  // (the ring slot of a stage is a run-time value since round 3 — a tile may be any number of stages long — so the
+  // LDS destination comes in a scalar register)
+#define EHX_DMA_RT(DST, VOFF, SRC)                                                       \
+  do {                                                                                   \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"         \
+                 :                                                                       \
+                 : "s"(DST), "v"(VOFF), "s"(SRC)                                         \
+                 : "memory");                                                            \
+  } while (0)
 #define EHX_DMA_X0(SLOT) EHX_DMA(xdst, (SLOT) * 16384, voff, xsrc)
 #define EHX_DMA_Q0(SLOT) EHX_DMA(qdst, (SLOT) * 16384, voff, qsrc)
 #define EHX_DMA_X1(SLOT) EHX_DMA(xdst, (SLOT) * 16384 + 8192, voff8, xsrc)
@@ -390,15 +398,9 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   lds_barrier_i8();  // B_0
 #if EHX_I8_ABL & 4
   wait_vmcnt<0>();
-#define EHX_SDMA_X0(S) do { } while (0)
-#define EHX_SDMA_Q0(S) do { } while (0)
-#define EHX_SDMA_X1(S) do { } while (0)
-#define EHX_SDMA_Q1(S) do { } while (0)
+#define EHX_SDMA(DST, VOFF, SRC) do { } while (0)
 #else
-#define EHX_SDMA_X0(S) EHX_DMA_X0(S)
-#define EHX_SDMA_Q0(S) EHX_DMA_Q0(S)
-#define EHX_SDMA_X1(S) EHX_DMA_X1(S)
-#define EHX_SDMA_Q1(S) EHX_DMA_Q1(S)
+#define EHX_SDMA(DST, VOFF, SRC) EHX_DMA_RT(DST, VOFF, SRC)
 #endif
 
   // Fragments are double-buffered: set 0 feeds k-step 0, set 1 feeds k-step 1; the six fragment reads of
@@ -416,9 +418,20 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 #endif
 #define EHX_MF(A, B, RB, CB) acc[RB][CB] = EHX_MFMA_I8(A[RB], B[CB], acc[RB][CB])
 #define EHX_SB() __builtin_amdgcn_sched_barrier(0)
+#if EHX_I8_ABL & 4
+#define EHX_SDMA_X0(S) do { } while (0)
+#define EHX_SDMA_Q0(S) do { } while (0)
+#define EHX_SDMA_X1(S) do { } while (0)
+#define EHX_SDMA_Q1(S) do { } while (0)
+#else
+#define EHX_SDMA_X0(S) EHX_DMA_X0(S)
+#define EHX_SDMA_Q0(S) EHX_DMA_Q0(S)
+#define EHX_SDMA_X1(S) EHX_DMA_X1(S)
+#define EHX_SDMA_Q1(S) EHX_DMA_Q1(S)
+#endif
   // One stage, ring slot S (compile-time): no branches, no address arithmetic; every gap between two MFMAs carries
   // exactly one other instruction of this wave (a fragment read or a DMA piece).
-#define EHX_STAGE_I8(S)                                                                                  \
+#define EHX_STAGE_I8_CT(S)                                                                                  \
   do {                                                                                                   \
     constexpr uint32_t so = (uint32_t)(S) * kStageI8, sn = (uint32_t)(((S) + 1) & 3) * kStageI8;         \
     constexpr int sd = ((S) + 3) & 3;                                                                    \
@@ -445,82 +458,191 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     EHX_MF(fa1, fb1, 3, 1); EHX_SDMA_Q1(sd);                                 EHX_SB();                    \
   } while (0)
 
-  // One flat loop over groups of four stages (= one revolution of the ring; ld % 256 == 0 makes a tile a whole
-  // number of them); the tile boundary work hangs off a counter inside it.
-  const uint32_t kquads = ktiles >> 2;
-  const uint32_t total_quads = my_tiles * kquads;
-  // row parameters of tile 1 (consumed by its epilogue, a whole tile from now)
-  rsrc += kTileRows16 * 16;
-  if (w < 4) EHX_DMA(rdst, 4096, voff, rsrc);
-  uint32_t kq = 0, t = 0;
-  for (uint32_t q = 0; q < total_quads; ++q) {
-    EHX_STAGE_I8(0);
-    EHX_STAGE_I8(1);
-    EHX_STAGE_I8(2);
-    EHX_STAGE_I8(3);
-    if (sync_on && w == 0) {
-      // revolution q is done.  The snapshot taken after revolution q-1 (landed long ago: four stage waits have
-      // passed) must show every sibling through revolution q-2; then announce q and take the next snapshot.
-      const uint32_t seen = __builtin_amdgcn_readfirstlane(sync_lds[0]);
-      const uint32_t need = q >= 2 ? a.q_tiles * (q - 1) : 0u;
-      if (seen < need) {
-        uint32_t spins = 0;
-        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <
-               need) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++spins > 4000u) {  // a sibling is not resident (or died): never hang, just stop synchronising
-            sync_on = false;
-            break;
+  // One stage on ring slot SO (byte offset of the slot, a scalar): no branches; the slot's offset enters the four
+  // fragment base addresses once (four vector adds per stage), everything else is an immediate; every gap between two
+  // MFMAs carries one other instruction of this wave (a fragment read or a DMA piece).  SN: the next stage's slot,
+  // DX0 / DQ0 / DX1 / DQ1: LDS destinations of this wave's four DMA pieces of the stage three ahead.
+#define EHX_STAGE_I8_RT(SO, SN, DX0, DQ0, DX1, DQ1)                                                         \
+  do {                                                                                                   \
+    const uint32_t a1_ = a_off1 + (SO), b1_ = b_off1 + (SO), a0_ = a_off0 + (SN), b0_ = b_off0 + (SN);   \
+    EHX_MF(fa0, fb0, 0, 0); fb1[0] = EHX_FR(smem + b1_);                    EHX_SB();                    \
+    EHX_MF(fa0, fb0, 0, 1); fb1[1] = EHX_FR(smem + b1_ + 2048);             EHX_SB();                    \
+    EHX_MF(fa0, fb0, 1, 0); fa1[0] = EHX_FR(smem + a1_);                    EHX_SB();                    \
+    EHX_MF(fa0, fb0, 1, 1); fa1[1] = EHX_FR(smem + a1_ + 2048);             EHX_SB();                    \
+    EHX_MF(fa0, fb0, 2, 0); fa1[2] = EHX_FR(smem + a1_ + 4096);             EHX_SB();                    \
+    EHX_MF(fa0, fb0, 2, 1); fa1[3] = EHX_FR(smem + a1_ + 6144);             EHX_SB();                    \
+    EHX_MF(fa0, fb0, 3, 0); EHX_SDMA(DX0, voff, xsrc);                      EHX_SB();                    \
+    EHX_MF(fa0, fb0, 3, 1); EHX_SDMA(DQ0, voff, qsrc);                      EHX_SB();                    \
+    /* stage barrier: the next stage landed (own pieces counted: the younger stage and the two pieces    \
+       just issued may still be in flight) and is visible; every wave is done reading this stage */      \
+    wait_vmcnt<6>();                                                                                     \
+    lds_barrier_i8();                                                                                    \
+    EHX_SB();                                                                                            \
+    EHX_MF(fa1, fb1, 0, 0); fb0[0] = EHX_FR(smem + b0_);                    EHX_SB();                    \
+    EHX_MF(fa1, fb1, 0, 1); fb0[1] = EHX_FR(smem + b0_ + 2048);             EHX_SB();                    \
+    EHX_MF(fa1, fb1, 1, 0); fa0[0] = EHX_FR(smem + a0_);                    EHX_SB();                    \
+    EHX_MF(fa1, fb1, 1, 1); fa0[1] = EHX_FR(smem + a0_ + 2048);             EHX_SB();                    \
+    EHX_MF(fa1, fb1, 2, 0); fa0[2] = EHX_FR(smem + a0_ + 4096);             EHX_SB();                    \
+    EHX_MF(fa1, fb1, 2, 1); fa0[3] = EHX_FR(smem + a0_ + 6144);             EHX_SB();                    \
+    EHX_MF(fa1, fb1, 3, 0); EHX_SDMA(DX1, voff8, xsrc);                     EHX_SB();                    \
+    EHX_MF(fa1, fb1, 3, 1); EHX_SDMA(DQ1, voff8, qsrc);                     EHX_SB();                    \
+    xsrc += kStageI8;                                                                                    \
+    qsrc += kStageI8;                                                                                    \
+  } while (0)
+
+  // Two loops over the same stage body.  REV (a tile is a whole number of ring revolutions, ld % 256 == 0: d = 768, 1536,
+  // 1024, 512, 256 ...): the ring slot of every stage is a compile-time constant — no address arithmetic at all; same-box
+  // A/B at 10 M x 768: 7.33 ms per batch against 7.66 with run-time slots.  Otherwise (d = 128, 384, 640 ...; round 2
+  // padded those rows to a whole revolution, twice resp. 4/3 of their length, and kept this engine off 128-dim rows):
+  // one loop over single stages whose slot is a scalar.
+  if constexpr (REV) {
+    // One flat loop over groups of four stages (= one revolution of the ring; ld % 256 == 0 makes a tile a whole
+    // number of them); the tile boundary work hangs off a counter inside it.
+    const uint32_t kquads = ktiles >> 2;
+    const uint32_t total_quads = my_tiles * kquads;
+    // row parameters of tile 1 (consumed by its epilogue, a whole tile from now)
+    rsrc += kTileRows16 * 16;
+    if (w < 4) EHX_DMA(rdst, 4096, voff, rsrc);
+    uint32_t kq = 0, t = 0;
+    for (uint32_t q = 0; q < total_quads; ++q) {
+      EHX_STAGE_I8_CT(0);
+      EHX_STAGE_I8_CT(1);
+      EHX_STAGE_I8_CT(2);
+      EHX_STAGE_I8_CT(3);
+      if (sync_on && w == 0) {
+        // revolution q is done.  The snapshot taken after revolution q-1 (landed long ago: four stage waits have
+        // passed) must show every sibling through revolution q-2; then announce q and take the next snapshot.
+        const uint32_t seen = __builtin_amdgcn_readfirstlane(sync_lds[0]);
+        const uint32_t need = q >= 2 ? a.q_tiles * (q - 1) : 0u;
+        if (seen < need) {
+          uint32_t spins = 0;
+          while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <
+                 need) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > 4000u) {  // a sibling is not resident (or died): never hang, just stop synchronising
+              sync_on = false;
+              break;
+            }
           }
         }
+        if (lane == 0) __hip_atomic_fetch_add(sync_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1"
+                     :
+                     : "s"(sync_m0), "v"(sync_voff), "s"(sync_ctr)
+                     : "memory");
       }
-      if (lane == 0) __hip_atomic_fetch_add(sync_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1"
-                   :
-                   : "s"(sync_m0), "v"(sync_voff), "s"(sync_ctr)
-                   : "memory");
-    }
-    if (++kq == kquads) {
-      kq = 0;
+      if (++kq == kquads) {
+        kq = 0;
 #if !(EHX_I8_ABL & 1)
-      epilogue(t);
+        epilogue(t);
 #endif
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
+        for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+          for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0;
-      ++t;
-      // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
-      // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
-      qsrc = qbase + 3 * kStageI8;
-      rsrc += kTileRows16 * 16;
-      tp_cur = a.tilep[tile_begin + t];  // (past the last tile: the array's padding entries)
-      // tile t+1 (counting the new t) goes to the slot tile t-2 used: every wave left that epilogue long ago
-      const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 1) % 3 == (t - 2) % 3
-      rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
-      if (w < 4) {
-        const uint32_t rd = rdst + rp_next * 4096u;
-        EHX_DMA(rd, 0, voff, rsrc);
+            for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0;
+        ++t;
+        // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
+        // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
+        qsrc = qbase + 3 * kStageI8;
+        rsrc += kTileRows16 * 16;
+        tp_cur = a.tilep[tile_begin + t];  // (past the last tile: the array's padding entries)
+        // tile t+1 (counting the new t) goes to the slot tile t-2 used: every wave left that epilogue long ago
+        const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 1) % 3 == (t - 2) % 3
+        rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
+        if (w < 4) {
+          const uint32_t rd = rdst + rp_next * 4096u;
+          EHX_DMA(rd, 0, voff, rsrc);
+        }
+      }
+    }
+  } else {
+    // One flat loop over the stages of the chunk; a tile is `ktiles` of them (ld / 64: any number — round 2 wanted whole
+    // ring revolutions, ld % 256 == 0, which padded 128-dim rows to twice and 384-dim rows to 4/3 of their length and
+    // kept the int8 engine off short rows).  The tile boundary work hangs off a counter and may fall anywhere in a
+    // revolution: nothing in the ring depends on where a tile starts (X stages stream linearly, Q stages repeat with
+    // period ktiles, and the three blocks appended to the Q array cover the look-ahead across the boundary).
+    const uint32_t total_stages = my_tiles * ktiles;
+    // row parameters of tile 1 (consumed by its epilogue, a whole tile from now)
+    rsrc += kTileRows16 * 16;
+    if (w < 4) EHX_DMA(rdst, 4096, voff, rsrc);
+    uint32_t ks = 0, t = 0, slot = 0;
+#pragma unroll 1
+    for (uint32_t st = 0; st < total_stages; ++st) {
+      {
+        const uint32_t so = slot << 14, sn = ((slot + 1u) & 3u) << 14, sd = ((slot + 3u) & 3u) << 14;
+        const uint32_t dx0 = xdst + sd, dq0 = qdst + sd;
+        EHX_STAGE_I8_RT(so, sn, dx0, dq0, dx0 + 8192u, dq0 + 8192u);
+      }
+      slot = (slot + 1u) & 3u;
+      if (sync_on && w == 0 && slot == 0u) {
+        // revolution q is done.  The snapshot taken after revolution q-1 (landed long ago: four stage waits have
+        // passed) must show every sibling through revolution q-2; then announce q and take the next snapshot.
+        const uint32_t q = st >> 2;
+        const uint32_t seen = __builtin_amdgcn_readfirstlane(sync_lds[0]);
+        const uint32_t need = q >= 2 ? a.q_tiles * (q - 1) : 0u;
+        if (seen < need) {
+          uint32_t spins = 0;
+          while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <
+                 need) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > 4000u) {  // a sibling is not resident (or died): never hang, just stop synchronising
+              sync_on = false;
+              break;
+            }
+          }
+        }
+        if (lane == 0) __hip_atomic_fetch_add(sync_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1"
+                     :
+                     : "s"(sync_m0), "v"(sync_voff), "s"(sync_ctr)
+                     : "memory");
+      }
+      if (++ks == ktiles) {
+        ks = 0;
+#if !(EHX_I8_ABL & 1)
+        epilogue(t);
+#endif
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0;
+        ++t;
+        // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
+        // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
+        qsrc = qbase + 3 * kStageI8;
+        rsrc += kTileRows16 * 16;
+        tp_cur = a.tilep[tile_begin + t];  // (past the last tile: the array's padding entries)
+        // tile t+1 (counting the new t) goes to the slot tile t-2 used: every wave left that epilogue long ago
+        const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 1) % 3 == (t - 2) % 3
+        rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
+        if (w < 4) {
+          const uint32_t rd = rdst + rp_next * 4096u;
+          EHX_DMA(rd, 0, voff, rsrc);
+        }
       }
     }
   }
   }  // my_tiles > 0
-#undef EHX_STAGE_I8
 #undef EHX_MF
 #undef EHX_SB
 #undef EHX_FR
+#undef EHX_SDMA
+#undef EHX_DMA_RT
 #undef EHX_SDMA_X0
 #undef EHX_SDMA_Q0
 #undef EHX_SDMA_X1
 #undef EHX_SDMA_Q1
+#undef EHX_STAGE_I8_CT
+#undef EHX_STAGE_I8_RT
 #undef EHX_DMA_X0
 #undef EHX_DMA_Q0
 #undef EHX_DMA_X1
 #undef EHX_DMA_Q1
 #undef EHX_DMA
-#undef EHX_DMA_ALWAYS
 
   // ---- final: what is left in this wave's staging buffer goes to the pools ----
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -530,11 +652,19 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 
 hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st) {
   static DynLdsAttr attr;
-  const void* fns[2] = {(const void*)flat_scan_i8_kernel<false>, (const void*)flat_scan_i8_kernel<true>};
-  if (hipError_t e = attr.ensure(fns, 2, kLdsBytesI8); e != hipSuccess) return e;
+  const void* fns[4] = {(const void*)flat_scan_i8_kernel<false, true>, (const void*)flat_scan_i8_kernel<true, true>,
+                        (const void*)flat_scan_i8_kernel<false, false>, (const void*)flat_scan_i8_kernel<true, false>};
+  if (hipError_t e = attr.ensure(fns, 4, kLdsBytesI8); e != hipSuccess) return e;
+  if (a.ld == 0 || a.ld % kRowBI8) return hipErrorInvalidValue;
   const uint32_t grid = a.q_tiles * a.n_chunks;
-  if (a.dump) hipLaunchKernelGGL((flat_scan_i8_kernel<true>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
-  else hipLaunchKernelGGL((flat_scan_i8_kernel<false>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
+  const bool rev = a.ld % (4 * kRowBI8) == 0;  // whole ring revolutions per tile: the compile-time-slot loop
+  if (a.dump) {
+    if (rev) hipLaunchKernelGGL((flat_scan_i8_kernel<true, true>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
+    else hipLaunchKernelGGL((flat_scan_i8_kernel<true, false>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
+  } else {
+    if (rev) hipLaunchKernelGGL((flat_scan_i8_kernel<false, true>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
+    else hipLaunchKernelGGL((flat_scan_i8_kernel<false, false>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
+  }
   return hipGetLastError();
 }
 

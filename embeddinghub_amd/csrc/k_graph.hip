@@ -129,10 +129,13 @@ size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap) {
   return (size_t)ld * 4 + (size_t)ef_cap * 8 + 64 * 8 * 2 + 64 * 4 + (((size_t)ef_cap + 15) & ~(size_t)15);
 }
 
-template <int METRIC01, bool SCALE>
+// A/B builds: cap the registers so that this many waves share a SIMD (0 = the compiler's choice).  Measured in round 3:
+// 3 and 4 make the compiler spill 79-535 registers per lane (it keeps the row walk's register rings alive across
+// the LDS phases) — not shipped; at batch 1024 a SIMD holds one wave anyway.
 #ifndef EHX_GRAPH_WAVES
-#define EHX_GRAPH_WAVES 0  // A/B builds: cap the registers so that this many waves share a SIMD (0 = the compiler's choice)
+#define EHX_GRAPH_WAVES 0
 #endif
+template <int METRIC01, bool SCALE>
 #if EHX_GRAPH_WAVES
 __attribute__((amdgpu_waves_per_eu(EHX_GRAPH_WAVES, EHX_GRAPH_WAVES)))
 #endif

@@ -403,9 +403,12 @@ __global__ __launch_bounds__(64) void prep_queries8_kernel(const float* __restri
   const uint32_t row = blockIdx.x;
   const int lane = threadIdx.x;
   const uint32_t kts = ld8 >> 6;
-  auto put = [&](uint32_t c, int8_t v) {  // stages 0..2 are stored a second time after the last stage
-    Q8[scanq8_index(row, c >> 6, c & 63u, ld8)] = v;
-    if (c < 192) Q8[scanq8_index(row, kts + (c >> 6), c & 63u, ld8)] = v;
+  // the three blocks after the last stage repeat the tile's first stages — block kts + j holds stage j mod kts — so
+  // that the scan's three-stage look-ahead reads linearly across a tile boundary (kts = 2: stages 0, 1, 0)
+  auto put = [&](uint32_t c, int8_t v) {
+    const uint32_t stg = c >> 6;
+    Q8[scanq8_index(row, stg, c & 63u, ld8)] = v;
+    for (uint32_t j = stg; j < 3u; j += kts) Q8[scanq8_index(row, kts + j, c & 63u, ld8)] = v;
   };
   if (row >= nq) {
     for (uint32_t c = lane; c < ld8; c += 64) put(c, 0);

@@ -104,7 +104,7 @@ typedef struct ehx_params {
                                the oracle's), 1 = strictly sequential everywhere, N > 1 = rounds of up to N
                                rows, ALSO for an ehx_set_batch made only of fresh keys (hnswlib-python's
                                multi-threaded add_items), 0xFFFFFFFF = no graph building (import one).    */
-  uint32_t scan;            /* flat mode: EHX_SCAN_AUTO (0) = a matrix-core FILTER scan (int8 on long rows and
+  uint32_t scan;            /* flat mode: EHX_SCAN_AUTO (0) = a matrix-core FILTER scan (int8 on rows of up to 2048 dims and
                                >= 16 Ki rows, else fp16) in front of the canonical fp32 re-rank; every query a
                                filter cannot certify is re-run by the next engine (int8 -> fp16 -> fp32 scan ->
                                exhaustive canonical pass) — results identical to EHX_SCAN_F32 (1) = fp32

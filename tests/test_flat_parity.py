@@ -171,8 +171,11 @@ def test_random_parity(n, d, nq, k, em, om, scan):
     _check(s, X, Q, k, om)
     st = s.stats()
     assert st["n_uncertified"] == 0 and st["n_rows"] == n
-    assert st["n_filter_queries"] == (nq if scan == ehx.SCAN_AUTO else 0)
-    assert st["n_filter_fallback"] <= nq // 4  # re-runs through the fp32 scan must stay the exception
+    if scan == ehx.SCAN_AUTO:   # a filter engine answered first: int8 (>= 16 Ki rows, d <= 2048), else fp16
+        assert (st["n_i8_queries"] or st["n_filter_queries"]) == nq
+    else:
+        assert st["n_filter_queries"] == 0 and st["n_i8_queries"] == 0
+    assert st["n_filter_fallback"] <= nq // 4 and st["n_i8_fallback"] <= nq // 4  # re-runs must stay the exception
     s.drop()
 
 

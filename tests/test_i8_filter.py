@@ -38,6 +38,10 @@ def _space(d, em, n, **kw):
 
 @pytest.mark.parametrize("n,d,nq,k", [
     (20000, 768, 64, 10),     # the headline row length
+    (40000, 128, 200, 10),    # two stages per tile (round 3: rows padded to stage PAIRS, not ring revolutions)
+    (30000, 384, 64, 10),     # six stages per tile: the tile boundary falls in the middle of a ring revolution
+    (25000, 64, 40, 10),      # half of the row is padding
+    (20000, 640, 64, 10),     # ten stages per tile
     (70000, 200, 300, 10),    # dims not a multiple of the 64-byte stage row; two query tiles
     (40000, 1536, 33, 10),    # config-5 dims
     (30000, 300, 1024, 5),    # four query tiles share every row chunk (lock-step path)
@@ -156,14 +160,15 @@ def test_i8_synthetic_fill_matches_oracle_generator():
     s.drop()
 
 
-def test_small_or_short_row_spaces_use_the_fp16_filter():
+def test_small_or_very_long_row_spaces_use_the_fp16_filter():
     rng = np.random.default_rng(1)
     a = ehx.Space.unique("small", 768, metric=ehx.METRIC_COSINE)
     a.set_batch(_keys(3000), rng.standard_normal((3000, 768)).astype(np.float32))
     assert a.scan_engine() == "f16"          # below the int8 engine's minimum row count
     b = ehx.Space.unique("short", 128, metric=ehx.METRIC_L2SQ, initial_capacity=40000)
     b.set_batch(_keys(40000), rng.standard_normal((40000, 128)).astype(np.float32))
-    assert b.scan_engine() == "f16"          # 128-dim rows: the int8 copy would be as long as the fp16 one
+    assert b.scan_engine() == "i8"           # round 3: 128-dim rows are two stages of the int8 copy (round 2 padded
+                                             # them to a ring revolution, as long as the fp16 copy, and kept them on fp16)
     c = ehx.Space.unique("long", 4096, metric=ehx.METRIC_COSINE, initial_capacity=17000)
     c.set_batch(_keys(17000), rng.standard_normal((17000, 4096)).astype(np.float32))
     assert c.scan_engine() == "f16"          # beyond d = 2048 the int8 bound is too wide for 256 candidates
