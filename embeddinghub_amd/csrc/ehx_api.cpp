@@ -655,21 +655,22 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
   HIP_TRY(hipMemcpyAsync(s->dInsLevels.p, h_lv.data(), count * sizeof(int32_t), hipMemcpyHostToDevice, st));
   // ---- round schedule ----
   const uint64_t round_cap = batch > 1 ? batch : 4096;
-  // Rows of one round do not see each other, so a round never exceeds a small share of the graph it joins: 1/64, at
+  // Rows of one round do not see each other, so a round never exceeds a small share of the graph it joins: 1/128, at
   // most `round_cap` rows — and 1/256 when the graph stays small (below 128 Ki nodes after this call: there every node is
   // an early node, and hnswlib-python's add_items with 64 threads is blind to only 64 / n of the graph).  Measured
-  // against the oracle's sequentially built graphs at equal ef (tests/test_graph_scale.py, 4096 queries): with 1/16 the
-  // 20 k x 768 index lost 0.009 of recall@10 at ef = 400 and the 200 k x 768 index 0.0015; with 1/64: 0.005 and 0.001;
-  // with 1/256: 0.003 at 20 k.  A round costs ~2 ms however few rows it holds (one wave's ef_construction search is a
-  // millisecond of dependent steps), so the small share is not paid by builds that grow large: 2 M x 768 takes 18.4 s
-  // with 1/16, 24.0 s with 1/256 up to 128 Ki nodes, ~19.5 s with 1/64 throughout (profiles/r03_h_*).
+  // against the oracle's sequentially built graphs at equal ef (tests/test_graph_scale.py, recall@10 over 4096 queries,
+  // worst ef; profiles/r03_*_graph_scale_report*.jsonl): share 1/16 — 20 k x 768 Gaussian rows -0.009, 200 k x 768
+  // -0.0015; 1/64 — -0.005 and -0.001, but 200 k x 768 STRUCTURED rows (bench.py's manifold data, where recall is
+  // 0.97 and neighbours are real) -0.0052; 1/128 — structured -0.0017; 1/256 — -0.0013.  A round costs ~2 ms however
+  // few rows it holds (one wave's ef_construction search is a millisecond of dependent steps), so the small shares are
+  // paid once, while the graph is small: 2 M x 768 takes 18.4 s with 1/16 and 19.2 s with 1/64.
   // EHX_BUILD_DIV overrides the share (A/B runs).
   static const uint64_t div_env = [] {
     const char* e = getenv("EHX_BUILD_DIV");
     const long v = e ? atol(e) : 0;
     return (uint64_t)(v < 0 ? 0 : v);
   }();
-  const uint64_t div = div_env >= 2 ? div_env : (end < (128u << 10) ? 256 : 64);
+  const uint64_t div = div_env >= 2 ? div_env : (end < (128u << 10) ? 256 : 128);
   auto round_size = [&](uint64_t g_n, uint64_t left) {
     uint64_t P = 1;
     if (batch != 1 && g_n >= 64) {

@@ -33,6 +33,9 @@ CONFIGS = {
     # bench.py's structured leg (rows on a 32-dim linear manifold + 5 % noise, the workload where the graph path is
     # the operating point): only the CPU numbers are kept (profiles/r03_cpu_hnsw_*.json), not the graph
     "manifold1m768": (1_000_000, 768, pyoracle.METRIC_COSINE, "manifold"),
+    # ... and a structured index small enough to keep its graph: GPU-built against oracle-built where the graph path
+    # is the operating point (tests/test_graph_scale.py)
+    "man200k768": (200_000, 768, pyoracle.METRIC_COSINE, "manifold"),
 }
 EFS = (10, 100, 400)
 NQ, K = 256, 10
@@ -54,12 +57,14 @@ def make(name):
             x /= np.linalg.norm(x, axis=1, keepdims=True)
             return np.ascontiguousarray(x, dtype=np.float32)
         X = np.concatenate([manifold(SEED_CORPUS + 1 + i0 // chunk, min(chunk, n - i0)) for i0 in range(0, n, chunk)])
-        Q = manifold(SEED_QUERY, 1024)[:NQ]
+        Q = manifold(SEED_QUERY, 1024)[:NQ]  # (bench.py's first query batch)
     else:
         X = pyoracle.gen_rows(SEED_CORPUS, 0, n, d, normalize=norm)
         Q = pyoracle.gen_rows(SEED_QUERY, 0, NQ, d, normalize=norm)
     print("[%s] rows generated in %.1f s" % (name, time.time() - t0), flush=True)
-    h = pyoracle.Hnsw(d, metric, n)
+    import hashlib
+    rows_sha1 = hashlib.sha1(X.tobytes()).hexdigest()  # (the structured rows come out of a float32 matmul: the test checks
+    h = pyoracle.Hnsw(d, metric, n)                     # that its host produced the same bytes before it demands identity)
     t0 = time.time()
     step = max(1, n // 20)
     for r0 in range(0, n, step):
@@ -77,7 +82,7 @@ def make(name):
     res = {}
     meta = {"name": name, "rows": n, "dims": d, "metric": int(metric), "normalize": norm if isinstance(norm, str) else bool(norm), "M": 16,
             "ef_construction": 200, "seed": 100, "build_seconds": round(build_s, 1), "build_threads": 1,
-            "host_cores": cores, "queries": NQ, "k": K, "search": {}}
+            "host_cores": cores, "queries": NQ, "k": K, "rows_sha1": rows_sha1, "search": {}}
     efs = (10, 20, 40, 100) if norm == "manifold" else EFS  # (the structured leg's operating point is ef = 10 .. 40)
     meta["efs"] = list(efs)
     for ef in efs:
@@ -96,7 +101,7 @@ def make(name):
     prof = os.path.join(ROOT, "profiles", "r03_cpu_hnsw_%s.json" % name)
     with open(prof, "w") as f:  # the CPU baseline of the graph path, like for like (bench.py quotes these files)
         json.dump(meta, f, indent=1)
-    if norm == "manifold":
+    if name == "manifold1m768":
         return
     np.savez_compressed(out, level0=l0, levels=lv, upper_node=un, upper_level=ul, upper_off=off, upper_ids=uids,
                         entry_point=np.uint32(h.enterpoint), max_level=np.int32(h.maxlevel), truth=truth.astype(np.uint64),

@@ -4,6 +4,8 @@ recall@k").  The oracle-built graphs come from tests/golden/make_big_graphs.py (
 
   (a) the oracle's graph, IMPORTED: the engine's search must return the oracle's ids, distance bytes and counts for
       ef = 10 / 100 / 400 (the oracle's own results are stored next to the graph);
+      (the fourth configuration, man200k768, is bench.py's STRUCTURED data — rows on a 32-dim manifold, where the graph
+      path is the operating point — written through ehx_set_batch in chunks like the bench leg);
   (b) the same rows BUILT ON THE GPU in rounds of 4096 (what every >= 1 M-row number of this repo uses; hnswlib's
       multi-threaded add_items is the reference analogue, sdk/python/offlinehub.py:89): recall@10 against the exact
       answer, at equal ef, within 0.005 of the oracle-built graph's (BASELINE.md §2 gate), over 4096 queries;
@@ -38,12 +40,47 @@ def _upper(z):
             for i, (n, l) in enumerate(zip(z["upper_node"], z["upper_level"]))}
 
 
+def _manifold(meta):
+    """bench.py's structured rows (run_structured_leg) and tests/golden/make_big_graphs.py's: z ~ N(0, I_32) times a fixed
+    random 32 x d matrix, plus 5 % isotropic noise, normalised"""
+    d, R = meta["dims"], 32
+    A = np.random.default_rng(20250213).standard_normal((R, d)).astype(np.float32) / np.sqrt(R)
+
+    def gen(seed, rows):
+        r = np.random.default_rng(seed)
+        x = r.standard_normal((rows, R)).astype(np.float32) @ A
+        x += 0.05 * r.standard_normal((rows, d)).astype(np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        return np.ascontiguousarray(x, dtype=np.float32)
+    return gen
+
+
+def _fill(space, meta):
+    """the configuration's rows into `space`: EHX-GAUSS-1 generated on the device, or the structured rows through
+    ehx_set_batch in bench.py's chunks of 65536"""
+    n = meta["rows"]
+    if meta["normalize"] == "manifold":
+        gen, chunk = _manifold(meta), 65536
+        for i0 in range(0, n, chunk):
+            m = min(chunk, n - i0)
+            space.set_batch([b"%d" % i for i in range(i0, i0 + m)], gen(ehx.SEED_CORPUS + 1 + i0 // chunk, m))
+    else:
+        space.fill_synthetic(ehx.SEED_CORPUS, 0, n, meta["normalize"])
+
+
+def _queries(meta, nq):
+    if meta["normalize"] == "manifold":
+        gen = _manifold(meta)
+        return np.concatenate([gen(ehx.SEED_QUERY + b, 1024) for b in range((nq + 1023) // 1024)])[:nq]
+    return pyoracle.gen_rows(ehx.SEED_QUERY, 0, nq, meta["dims"], normalize=meta["normalize"])
+
+
 def _recall(ids, truth):
     k = truth.shape[1]
     return float(np.mean([len(set(ids[i].tolist()) & set(truth[i].tolist())) / k for i in range(truth.shape[0])]))
 
 
-@pytest.mark.parametrize("name", ["cos20k768", "cos200k768", "l2_1m128"])
+@pytest.mark.parametrize("name", ["cos20k768", "cos200k768", "l2_1m128", "man200k768"])
 def test_oracle_graph_at_scale_imported_and_gpu_built(name):
     z, meta = _load(name)
     n, d, norm = meta["rows"], meta["dims"], meta["normalize"]
@@ -51,10 +88,22 @@ def test_oracle_graph_at_scale_imported_and_gpu_built(name):
           pyoracle.METRIC_COSINE: ehx.METRIC_COSINE}[meta["metric"]]
     # ---- (a) the oracle's graph, imported over rows the DEVICE generates (EHX-GAUSS-1, bit-identical to the oracle's) ----
     s = ehx.Space.unique("scale-imp", d, metric=em, mode=ehx.MODE_GRAPH, initial_capacity=n, build_batch=0xFFFFFFFF)
-    s.fill_synthetic(ehx.SEED_CORPUS, 0, n, norm)
+    _fill(s, meta)
     s.graph_import(z["level0"], z["levels"], _upper(z), int(z["entry_point"]), int(z["max_level"]))
     nq, k = meta["queries"], meta["k"]
-    Q = pyoracle.gen_rows(ehx.SEED_QUERY, 0, nq, d, normalize=norm)
+    Q = _queries(meta, nq)
+    # The structured rows come out of a float32 matmul on the host: another CPU may round them differently than the box
+    # the oracle ran on.  Identity with the oracle's stored results is demanded when the rows are the same bytes (always
+    # for EHX-GAUSS-1, whose generator is bit-exact everywhere); otherwise the imported graph is still the oracle's
+    # graph over rows that differ in their last bits, and at most 5 % of the queries may come out differently.
+    same_rows = meta["normalize"] != "manifold"
+    if not same_rows and "rows_sha1" in meta:
+        import hashlib
+        gen, chunk = _manifold(meta), 65536
+        hsh = hashlib.sha1()
+        for i0 in range(0, n, chunk):
+            hsh.update(gen(ehx.SEED_CORPUS + 1 + i0 // chunk, min(chunk, n - i0)).tobytes())
+        same_rows = hsh.hexdigest() == meta["rows_sha1"]
     differing = {}
     for ef in meta["efs"]:
         s.set_ef(ef)
@@ -65,18 +114,20 @@ def test_oracle_graph_at_scale_imported_and_gpu_built(name):
         differing[ef] = len(bad)
         # bit-identical ids and distances; a query may differ only where two candidates tie EXACTLY in fp32 (heap order
         # vs (distance, id) order, test (c)) — on continuous data that is at most a query in a thousand
-        assert len(bad) <= max(1, nq // 500), "ef=%d: %d of %d queries differ from the oracle: %s" % (ef, len(bad), nq, bad[:8])
+        limit = max(1, nq // 500) if same_rows else nq // 20
+        assert len(bad) <= limit, "ef=%d: %d of %d queries differ from the oracle: %s" % (ef, len(bad), nq, bad[:8])
     # ---- (b) the same rows, built on the GPU in rounds of 4096 ----
     nq2 = 4096
-    Q2 = pyoracle.gen_rows(ehx.SEED_QUERY, 0, nq2, d, normalize=norm)
+    Q2 = _queries(meta, nq2)
     flat = ehx.Space.unique("scale-flat", d, metric=em, initial_capacity=n)
-    flat.fill_synthetic(ehx.SEED_CORPUS, 0, n, norm)
+    _fill(flat, meta)
     truth, _, _ = flat.knn(Q2, k)                      # the exact engine (oracle-identical: tests/test_flat_parity.py)
-    np.testing.assert_array_equal(truth[:nq], z["truth"])   # ... and here against the oracle's stored exhaustive scan
+    if same_rows:
+        np.testing.assert_array_equal(truth[:nq], z["truth"])   # ... and here against the oracle's stored exhaustive scan
     flat.drop()
     g = ehx.Space.unique("scale-gpu", d, metric=em, mode=ehx.MODE_GRAPH, initial_capacity=n, build_batch=4096)
-    g.fill_synthetic(ehx.SEED_CORPUS, 0, n, norm)
-    report = {"name": name, "build_div": os.environ.get("EHX_BUILD_DIV", "default"),
+    _fill(g, meta)
+    report = {"name": name, "build_div": os.environ.get("EHX_BUILD_DIV", "default"), "rows_identical_to_the_oracles": same_rows,
               "differing_queries_imported": differing, "recall": {}}
     worst = 0.0
     for ef in meta["efs"]:
