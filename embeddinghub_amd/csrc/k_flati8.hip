@@ -417,6 +417,10 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 #define EHX_FR(P) (*(const i32x4*)(P))
 #endif
 #define EHX_MF(A, B, RB, CB) acc[RB][CB] = EHX_MFMA_I8(A[RB], B[CB], acc[RB][CB])
+  // the first k-step of a tile starts its accumulators from the constant 0 (an inline operand of the MFMA) instead of
+  // 128 v_mov per wave after every epilogue — 4 % of a tile's issue slots at d = 768, a quarter at d = 128
+  const i32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define EHX_MFZ(A, B, RB, CB) acc[RB][CB] = EHX_MFMA_I8(A[RB], B[CB], zero16)
 #define EHX_SB() __builtin_amdgcn_sched_barrier(0)
 #if EHX_I8_ABL & 4
 #define EHX_SDMA_X0(S) do { } while (0)
@@ -431,18 +435,18 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 #endif
   // One stage, ring slot S (compile-time): no branches, no address arithmetic; every gap between two MFMAs carries
   // exactly one other instruction of this wave (a fragment read or a DMA piece).
-#define EHX_STAGE_I8_CT(S)                                                                                  \
+#define EHX_STAGE_I8_CT(S, M0)                                                                                 \
   do {                                                                                                   \
     constexpr uint32_t so = (uint32_t)(S) * kStageI8, sn = (uint32_t)(((S) + 1) & 3) * kStageI8;         \
     constexpr int sd = ((S) + 3) & 3;                                                                    \
-    EHX_MF(fa0, fb0, 0, 0); fb1[0] = EHX_FR(smem + b_off1 + so);            EHX_SB();                    \
-    EHX_MF(fa0, fb0, 0, 1); fb1[1] = EHX_FR(smem + b_off1 + so + 2048);     EHX_SB();                    \
-    EHX_MF(fa0, fb0, 1, 0); fa1[0] = EHX_FR(smem + a_off1 + so);            EHX_SB();                    \
-    EHX_MF(fa0, fb0, 1, 1); fa1[1] = EHX_FR(smem + a_off1 + so + 2048);     EHX_SB();                    \
-    EHX_MF(fa0, fb0, 2, 0); fa1[2] = EHX_FR(smem + a_off1 + so + 4096);     EHX_SB();                    \
-    EHX_MF(fa0, fb0, 2, 1); fa1[3] = EHX_FR(smem + a_off1 + so + 6144);     EHX_SB();                    \
-    EHX_MF(fa0, fb0, 3, 0); EHX_SDMA_X0(sd);                                 EHX_SB();                    \
-    EHX_MF(fa0, fb0, 3, 1); EHX_SDMA_Q0(sd);                                 EHX_SB();                    \
+    M0(fa0, fb0, 0, 0);    fb1[0] = EHX_FR(smem + b_off1 + so);            EHX_SB();                    \
+    M0(fa0, fb0, 0, 1);    fb1[1] = EHX_FR(smem + b_off1 + so + 2048);     EHX_SB();                    \
+    M0(fa0, fb0, 1, 0);    fa1[0] = EHX_FR(smem + a_off1 + so);            EHX_SB();                    \
+    M0(fa0, fb0, 1, 1);    fa1[1] = EHX_FR(smem + a_off1 + so + 2048);     EHX_SB();                    \
+    M0(fa0, fb0, 2, 0);    fa1[2] = EHX_FR(smem + a_off1 + so + 4096);     EHX_SB();                    \
+    M0(fa0, fb0, 2, 1);    fa1[3] = EHX_FR(smem + a_off1 + so + 6144);     EHX_SB();                    \
+    M0(fa0, fb0, 3, 0);    EHX_SDMA_X0(sd);                                 EHX_SB();                    \
+    M0(fa0, fb0, 3, 1);    EHX_SDMA_Q0(sd);                                 EHX_SB();                    \
     /* stage barrier: the next stage landed (own pieces counted: the younger stage and the two pieces    \
        just issued may still be in flight) and is visible; every wave is done reading this stage */      \
     wait_vmcnt<6>();                                                                                     \
@@ -462,17 +466,17 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   // fragment base addresses once (four vector adds per stage), everything else is an immediate; every gap between two
   // MFMAs carries one other instruction of this wave (a fragment read or a DMA piece).  SN: the next stage's slot,
   // DX0 / DQ0 / DX1 / DQ1: LDS destinations of this wave's four DMA pieces of the stage three ahead.
-#define EHX_STAGE_I8_RT(SO, SN, DX0, DQ0, DX1, DQ1)                                                         \
+#define EHX_STAGE_I8_RT(SO, SN, DX0, DQ0, DX1, DQ1, M0)                                                         \
   do {                                                                                                   \
     const uint32_t a1_ = a_off1 + (SO), b1_ = b_off1 + (SO), a0_ = a_off0 + (SN), b0_ = b_off0 + (SN);   \
-    EHX_MF(fa0, fb0, 0, 0); fb1[0] = EHX_FR(smem + b1_);                    EHX_SB();                    \
-    EHX_MF(fa0, fb0, 0, 1); fb1[1] = EHX_FR(smem + b1_ + 2048);             EHX_SB();                    \
-    EHX_MF(fa0, fb0, 1, 0); fa1[0] = EHX_FR(smem + a1_);                    EHX_SB();                    \
-    EHX_MF(fa0, fb0, 1, 1); fa1[1] = EHX_FR(smem + a1_ + 2048);             EHX_SB();                    \
-    EHX_MF(fa0, fb0, 2, 0); fa1[2] = EHX_FR(smem + a1_ + 4096);             EHX_SB();                    \
-    EHX_MF(fa0, fb0, 2, 1); fa1[3] = EHX_FR(smem + a1_ + 6144);             EHX_SB();                    \
-    EHX_MF(fa0, fb0, 3, 0); EHX_SDMA(DX0, voff, xsrc);                      EHX_SB();                    \
-    EHX_MF(fa0, fb0, 3, 1); EHX_SDMA(DQ0, voff, qsrc);                      EHX_SB();                    \
+    M0(fa0, fb0, 0, 0);    fb1[0] = EHX_FR(smem + b1_);                    EHX_SB();                    \
+    M0(fa0, fb0, 0, 1);    fb1[1] = EHX_FR(smem + b1_ + 2048);             EHX_SB();                    \
+    M0(fa0, fb0, 1, 0);    fa1[0] = EHX_FR(smem + a1_);                    EHX_SB();                    \
+    M0(fa0, fb0, 1, 1);    fa1[1] = EHX_FR(smem + a1_ + 2048);             EHX_SB();                    \
+    M0(fa0, fb0, 2, 0);    fa1[2] = EHX_FR(smem + a1_ + 4096);             EHX_SB();                    \
+    M0(fa0, fb0, 2, 1);    fa1[3] = EHX_FR(smem + a1_ + 6144);             EHX_SB();                    \
+    M0(fa0, fb0, 3, 0);    EHX_SDMA(DX0, voff, xsrc);                      EHX_SB();                    \
+    M0(fa0, fb0, 3, 1);    EHX_SDMA(DQ0, voff, qsrc);                      EHX_SB();                    \
     /* stage barrier: the next stage landed (own pieces counted: the younger stage and the two pieces    \
        just issued may still be in flight) and is visible; every wave is done reading this stage */      \
     wait_vmcnt<6>();                                                                                     \
@@ -496,19 +500,14 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   // padded those rows to a whole revolution, twice resp. 4/3 of their length, and kept this engine off 128-dim rows):
   // one loop over single stages whose slot is a scalar.
   if constexpr (REV) {
-    // One flat loop over groups of four stages (= one revolution of the ring; ld % 256 == 0 makes a tile a whole
-    // number of them); the tile boundary work hangs off a counter inside it.
+    // Tile by tile; a tile is `kquads` revolutions of the ring (ld % 256 == 0).  The first revolution of a tile is its
+    // own copy of the four stage bodies: its first k-step starts the accumulators from 0.
     const uint32_t kquads = ktiles >> 2;
-    const uint32_t total_quads = my_tiles * kquads;
     // row parameters of tile 1 (consumed by its epilogue, a whole tile from now)
     rsrc += kTileRows16 * 16;
     if (w < 4) EHX_DMA(rdst, 4096, voff, rsrc);
-    uint32_t kq = 0, t = 0;
-    for (uint32_t q = 0; q < total_quads; ++q) {
-      EHX_STAGE_I8_CT(0);
-      EHX_STAGE_I8_CT(1);
-      EHX_STAGE_I8_CT(2);
-      EHX_STAGE_I8_CT(3);
+    uint32_t q = 0;
+    auto after_revolution = [&]() {
       if (sync_on && w == 0) {
         // revolution q is done.  The snapshot taken after revolution q-1 (landed long ago: four stage waits have
         // passed) must show every sibling through revolution q-2; then announce q and take the next snapshot.
@@ -531,30 +530,35 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
                      : "s"(sync_m0), "v"(sync_voff), "s"(sync_ctr)
                      : "memory");
       }
-      if (++kq == kquads) {
-        kq = 0;
+      ++q;
+    };
+    for (uint32_t t = 0; t < my_tiles; ++t) {
+      EHX_STAGE_I8_CT(0, EHX_MFZ);
+      EHX_STAGE_I8_CT(1, EHX_MF);
+      EHX_STAGE_I8_CT(2, EHX_MF);
+      EHX_STAGE_I8_CT(3, EHX_MF);
+      after_revolution();
+      for (uint32_t kq = 1; kq < kquads; ++kq) {
+        EHX_STAGE_I8_CT(0, EHX_MF);
+        EHX_STAGE_I8_CT(1, EHX_MF);
+        EHX_STAGE_I8_CT(2, EHX_MF);
+        EHX_STAGE_I8_CT(3, EHX_MF);
+        after_revolution();
+      }
 #if !(EHX_I8_ABL & 1)
-        epilogue(t);
+      epilogue(t);
 #endif
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0;
-        ++t;
-        // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
-        // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
-        qsrc = qbase + 3 * kStageI8;
-        rsrc += kTileRows16 * 16;
-        tp_cur = a.tilep[tile_begin + t];  // (past the last tile: the array's padding entries)
-        // tile t+1 (counting the new t) goes to the slot tile t-2 used: every wave left that epilogue long ago
-        const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 1) % 3 == (t - 2) % 3
-        rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
-        if (w < 4) {
-          const uint32_t rd = rdst + rp_next * 4096u;
-          EHX_DMA(rd, 0, voff, rsrc);
-        }
+      // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
+      // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
+      qsrc = qbase + 3 * kStageI8;
+      rsrc += kTileRows16 * 16;
+      tp_cur = a.tilep[tile_begin + t + 1];  // (past the last tile: the array's padding entries)
+      // tile t+2 goes to the slot tile t-1 used: every wave left that epilogue long ago
+      const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 2) % 3 == (t - 1) % 3
+      rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
+      if (w < 4) {
+        const uint32_t rd = rdst + rp_next * 4096u;
+        EHX_DMA(rd, 0, voff, rsrc);
       }
     }
   } else {
@@ -573,7 +577,8 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       {
         const uint32_t so = slot << 14, sn = ((slot + 1u) & 3u) << 14, sd = ((slot + 3u) & 3u) << 14;
         const uint32_t dx0 = xdst + sd, dq0 = qdst + sd;
-        EHX_STAGE_I8_RT(so, sn, dx0, dq0, dx0 + 8192u, dq0 + 8192u);
+        if (ks == 0u) EHX_STAGE_I8_RT(so, sn, dx0, dq0, dx0 + 8192u, dq0 + 8192u, EHX_MFZ);
+      else EHX_STAGE_I8_RT(so, sn, dx0, dq0, dx0 + 8192u, dq0 + 8192u, EHX_MF);
       }
       slot = (slot + 1u) & 3u;
       if (sync_on && w == 0 && slot == 0u) {
@@ -637,6 +642,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 #undef EHX_SDMA_X1
 #undef EHX_SDMA_Q1
 #undef EHX_STAGE_I8_CT
+#undef EHX_MFZ
 #undef EHX_STAGE_I8_RT
 #undef EHX_DMA_X0
 #undef EHX_DMA_Q0
