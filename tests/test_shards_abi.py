@@ -95,7 +95,13 @@ def test_sharded_device_entry_point_and_graph_mode():
     g.set_batch(_keys(1200), X[:1200])
     gi, gd, gc = g.knn(Q[:16], k)
     oi, od, _ = pyoracle.exhaustive(X[:1200], Q[:16], k, pyoracle.METRIC_L2)
-    np.testing.assert_array_equal(gi, oi)
+    if not np.array_equal(gi, oi):
+        # (seen once in ~15 runs of round 3 and never reproduced: say which side is at fault if it happens again)
+        again = g.knn(Q[:16], k)[0]
+        missing = sorted(set(oi.ravel().tolist()) - set(gi.ravel().tolist()))
+        raise AssertionError("sharded graph search differs from the exact answer: ids never returned %s; a second "
+                             "search of the same graph %s" % (missing, "agrees with the exact answer (the SEARCH is "
+                             "not deterministic)" if np.array_equal(again, oi) else "differs too (the GRAPH misses links)"))
     assert gd.tobytes() == od.tobytes()
     g.drop()
 
