@@ -80,7 +80,11 @@ struct DevBuf {
     p = nullptr;
     n = 0;
     HIP_TRY(hipMalloc((void**)&p, want * sizeof(T)));
-    if (zero) HIP_TRY(hipMemset(p, 0, want * sizeof(T)));
+    if (zero) {
+      // (the fill runs on the NULL stream; the spaces' streams are non-blocking, i.e. not ordered with it: wait)
+      HIP_TRY(hipMemset(p, 0, want * sizeof(T)));
+      HIP_TRY(hipStreamSynchronize(nullptr));
+    }
     n = want;
     return EHX_OK;
   }
@@ -583,6 +587,7 @@ int graph_ensure_arrays(ehx_space* s) {
     HIP_TRY(hipMemcpy(na, s->dAdj0, s->g_n * M0 * sizeof(uint32_t), hipMemcpyDeviceToDevice));
     HIP_TRY(hipMemcpy(nu, s->dUpStart, s->g_n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
   }
+  HIP_TRY(hipStreamSynchronize(nullptr));  // (fills and copies above ran on the NULL stream; ours are non-blocking)
   if (s->dAdj0) (void)hipFree(s->dAdj0);
   if (s->dUpStart) (void)hipFree(s->dUpStart);
   s->dAdj0 = na;
@@ -601,6 +606,7 @@ int graph_ensure_lists(ehx_space* s, uint64_t lists) {
   HIP_TRY(hipMemset(nl, 0xFF, want * s->params.M * sizeof(uint32_t)));
   if (s->dUpLists && s->g_lists_used)
     HIP_TRY(hipMemcpy(nl, s->dUpLists, s->g_lists_used * s->params.M * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+  HIP_TRY(hipStreamSynchronize(nullptr));
   if (s->dUpLists) (void)hipFree(s->dUpLists);
   s->dUpLists = nl;
   s->g_lists_cap = want;
