@@ -171,11 +171,37 @@ def test_random_parity(n, d, nq, k, em, om, scan):
     _check(s, X, Q, k, om)
     st = s.stats()
     assert st["n_uncertified"] == 0 and st["n_rows"] == n
-    if scan == ehx.SCAN_AUTO:   # a filter engine answered first: int8 (>= 16 Ki rows, d <= 2048), else fp16
+    if scan == ehx.SCAN_AUTO and nq == 1:   # one query on a small shard: straight to the exhaustive canonical pass
+        assert st["n_exhaustive"] == 1 and st["n_i8_queries"] == 0 and st["n_filter_queries"] == 0
+    elif scan == ehx.SCAN_AUTO:   # a filter engine answered first: int8 (>= 16 Ki rows, d <= 2048), else fp16
         assert (st["n_i8_queries"] or st["n_filter_queries"]) == nq
     else:
         assert st["n_filter_queries"] == 0 and st["n_i8_queries"] == 0
     assert st["n_filter_fallback"] <= nq // 4 and st["n_i8_fallback"] <= nq // 4  # re-runs must stay the exception
+    s.drop()
+
+
+@pytest.mark.parametrize("em,om", METRICS)
+@pytest.mark.parametrize("n,d,k", [(10000, 128, 10), (5000, 768, 10), (300, 19, 48), (40000, 96, 100), (3, 8, 10)])
+def test_single_query_on_a_small_shard_takes_the_exhaustive_pass(n, d, k, em, om):
+    """The reference's own request shape — ONE query per NearestNeighbor call (server.cc:172-210; BASELINE configs[0]) —
+    on a shard small enough to be read in less time than the batch engines need to start: answered by the exhaustive
+    canonical pass alone, exactly; two or more queries in a call take the engines as before."""
+    rng = np.random.default_rng(n + d + k)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((3, d)).astype(np.float32)
+    Q[0] = X[n // 2] + np.float32(1e-3) * rng.standard_normal(d).astype(np.float32)
+    s = ehx.Space.unique("single", d, metric=em)
+    s.set_batch(_keys(n), X)
+    for i in range(3):
+        s.stats_reset()
+        _check(s, X, Q[i:i + 1], k, om)
+        st = s.stats()
+        assert st["n_exhaustive"] == 1 and st["n_i8_queries"] == 0 and st["n_filter_queries"] == 0 and st["n_uncertified"] == 0
+    s.stats_reset()
+    _check(s, X, Q, k, om)          # three queries in one call: the engine chain (k <= 48) or the paged pass (k > 48)
+    st = s.stats()
+    assert (st["n_i8_queries"] or st["n_filter_queries"]) == 3 if k <= 48 else st["n_exhaustive"] == 3
     s.drop()
 
 
