@@ -10,6 +10,6 @@ ROWS=$1; shift
 for sfx in "$@"; do
   L=$R/embeddinghub_amd/lib/libehx$sfx.so
   rm -rf gpurun_out/prof/abl$sfx
-  (cd /tmp && EHX_LIB=$L timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/prof/abl$sfx -o trace -- python $R/bench.py --rows $ROWS --steps 4 --warmup 2 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --check-queries 0 > $R/gpurun_out/prof/abl$sfx.log 2>&1)
+  (cd /tmp && EHX_LIB=$L timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/prof/abl$sfx -o trace -- python $R/bench.py --rows $ROWS --steps 4 --warmup 2 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --single-query 0 --check-queries 0 > $R/gpurun_out/prof/abl$sfx.log 2>&1)
   echo "== lib '$sfx'"; python scripts/rocpd_summary.py gpurun_out/prof/abl$sfx 2>/dev/null | grep -E "flat_scan_i8|last scan" | cut -c1-170
 done

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 ./scripts/ablate_i8.sh 10000000 "" _abl2 _abl16 > gpurun_out/r03_e_ablate_i8.txt 2>&1; cat gpurun_out/r03_e_ablate_i8.txt
 for sf in 4 2 1.5 1; do
-  EHX_I8_SAFETY=$sf timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --check-queries 0 > gpurun_out/r03_e_safety_$sf.json 2> gpurun_out/r03_e_safety_$sf.err
+  EHX_I8_SAFETY=$sf timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --single-query 0 --check-queries 0 > gpurun_out/r03_e_safety_$sf.json 2> gpurun_out/r03_e_safety_$sf.err
   python - <<P
 import json
 j = json.load(open("gpurun_out/r03_e_safety_$sf.json"))

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 R=$(pwd)
 timeout 900 python -m pytest tests/test_i8_filter.py tests/test_flat_parity.py tests/test_exactness.py tests/test_shards_abi.py -m gpu -q -x > gpurun_out/r03_f_tests.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/r03_f_tests.log
 for rows in 10000000 1250000 1000000; do
-  timeout 300 python bench.py --rows $rows --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --check-queries 0 > gpurun_out/r03_f_rows_$rows.json 2> gpurun_out/r03_f_rows_$rows.err
+  timeout 300 python bench.py --rows $rows --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --single-query 0 --check-queries 0 > gpurun_out/r03_f_rows_$rows.json 2> gpurun_out/r03_f_rows_$rows.err
   python - <<P
 import json
 j = json.load(open("gpurun_out/r03_f_rows_$rows.json"))
@@ -13,7 +13,7 @@ print("rows $rows: ms_per_step", j["ms_per_step"], "q/s", j["value"], "kernel_ms
 P
 done
 rm -rf gpurun_out/prof/r03_f_1250k
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/prof/r03_f_1250k -o trace -- python $R/bench.py --rows 1250000 --steps 6 --warmup 2 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --check-queries 0 > $R/gpurun_out/prof/r03_f_1250k.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/prof/r03_f_1250k -o trace -- python $R/bench.py --rows 1250000 --steps 6 --warmup 2 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --single-query 0 --check-queries 0 > $R/gpurun_out/prof/r03_f_1250k.log 2>&1)
 ROCPD_SEQ=16 python scripts/rocpd_summary.py gpurun_out/prof/r03_f_1250k > gpurun_out/r03_f_trace_1250k_rows_summary.txt 2>&1; grep -E "^#" gpurun_out/r03_f_trace_1250k_rows_summary.txt | tail -18 | cut -c1-120
 ./scripts/bench_configs.sh > gpurun_out/r03_f_bench_configs.log 2>&1; cp gpurun_out/bench_configs.jsonl gpurun_out/r03_f_bench_configs.jsonl; cut -c1-300 gpurun_out/r03_f_bench_configs.log
 TAG=r03_f ./scripts/gpu_profile_i8.sh > gpurun_out/r03_f_profile.log 2>&1; tail -30 gpurun_out/r03_f_profile.log | cut -c1-160

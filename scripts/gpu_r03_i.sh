@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_i8_filter.py tests/test_flat_parity.py tests/test_exactness.py tests/test_graph_scale.py tests/test_graph_parity.py -m gpu -q -x > gpurun_out/r03_i_tests.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/r03_i_tests.log
-run() { timeout 300 python bench.py "$@" --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --check-queries 0 > gpurun_out/r03_i_tmp.json 2> gpurun_out/r03_i_tmp.err; python - "$@" <<P
+run() { timeout 300 python bench.py "$@" --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --single-query 0 --check-queries 0 > gpurun_out/r03_i_tmp.json 2> gpurun_out/r03_i_tmp.err; python - "$@" <<P
 import json, sys
 j = json.load(open("gpurun_out/r03_i_tmp.json"))
 print(" ".join(sys.argv[1:]), "| ms_per_step", j["ms_per_step"], "q/s", j["value"], "|", j["roofline"]["kernel"][:20], "frac", j["roofline"]["frac"], "of", j["roofline"]["peak"], "| fallback", j["i8_fallback_queries"], j["filter_fallback_queries"], "identical", j["exactness"].get("filter_vs_f32_engine_identical"))

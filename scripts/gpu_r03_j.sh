@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$(pwd)
 for rep in 1 2; do for lib in _prev ""; do
-  EHX_LIB=$R/embeddinghub_amd/lib/libehx$lib.so timeout 300 python bench.py --rows 10000000 --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --check-queries 0 > gpurun_out/r03_j_tmp.json 2> gpurun_out/r03_j_tmp.err
+  EHX_LIB=$R/embeddinghub_amd/lib/libehx$lib.so timeout 300 python bench.py --rows 10000000 --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --single-query 0 --check-queries 0 > gpurun_out/r03_j_tmp.json 2> gpurun_out/r03_j_tmp.err
   python - "lib$lib" <<P
 import json, sys
 j = json.load(open("gpurun_out/r03_j_tmp.json"))

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$(pwd)
-run() { EHX_LIB=$R/embeddinghub_amd/lib/libehx$1.so timeout 300 python bench.py "${@:2}" --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --check-queries 0 > gpurun_out/r03_n_tmp.json 2> gpurun_out/r03_n_tmp.err; python - "lib$1" "${@:2}" <<P
+run() { EHX_LIB=$R/embeddinghub_amd/lib/libehx$1.so timeout 300 python bench.py "${@:2}" --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --single-query 0 --check-queries 0 > gpurun_out/r03_n_tmp.json 2> gpurun_out/r03_n_tmp.err; python - "lib$1" "${@:2}" <<P
 import json, sys
 j = json.load(open("gpurun_out/r03_n_tmp.json"))
 print(" ".join(sys.argv[1:]), "| ms_per_step", j["ms_per_step"], "kernel_ms", j["roofline"]["kernel_ms"], "frac", j["roofline"]["frac"], "| fallback", j["i8_fallback_queries"], "identical", j["exactness"].get("filter_vs_f32_engine_identical"))

@@ -45,8 +45,18 @@ class FakeSpace:
     def set_prepared(self, prep):
         self.set_batch(*prep)
 
+    def graph_import(self, level0, levels, upper, entry_point, max_level):
+        # an imported graph is walked as the oracle walks it: the stand-in rebuilds the oracle's (deterministic) graph
+        self._hnsw = pyoracle.Hnsw(self.dims, self._om(), self.X.shape[0])
+        self._hnsw.add_rows(self.X)
+        assert self._hnsw.enterpoint == entry_point and self._hnsw.maxlevel == max_level
+
     def knn(self, Q, k):
         Q = np.asarray(Q, dtype=np.float32).reshape(-1, self.dims)
+        if getattr(self, "_hnsw", None) is not None:
+            self._hnsw.set_ef(self.ef)
+            ids, dist, cnt, _, _ = self._hnsw.search_batch(Q, k, threads=1)
+            return ids, dist, cnt
         ids, dist, cnt = pyoracle.exhaustive(self.X, Q, k, self._om())
         self._st["scan_launches"] += 1
         self._st["n_queries"] += Q.shape[0]

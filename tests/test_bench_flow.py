@@ -47,7 +47,7 @@ def bench_on_stand_ins(monkeypatch):
 
 SMALL = ["--rows", "3000", "--dims", "32", "--batch", "16", "--steps", "3", "--warmup", "1", "--check-queries", "8",
          "--cpu-sample-rows", "3000", "--cpu-sample-queries", "8", "--cpu-hnsw-rows", "500", "--graph-batches", "2",
-         "--graph-efs", "10,20", "--set-concurrent", "0"]
+         "--graph-efs", "10,20", "--single-query", "0", "--set-concurrent", "0"]
 
 
 def test_default_flow_prints_one_json_line_with_the_contract_fields(bench_on_stand_ins):
@@ -82,6 +82,30 @@ def test_set_concurrent_is_a_default_leg(bench_on_stand_ins):
     assert sc["rows_written_meanwhile"] == 4096 and sc["error"] is None
     assert sc["search_batches_meanwhile"] >= 1 and sc["set_rows_per_s_meanwhile"] > 0
     assert "set_concurrent" not in r["optional_legs_skipped"]
+
+
+def test_single_query_leg_reports_configs0_and_checks_both_paths_against_the_oracle(bench_on_stand_ins):
+    """BASELINE configs[0] (10 k x 128 L2, one query per call) is a default leg: latency of the exact path and of graph
+    mode at the reference's ef = 10, each compared with the oracle before it is reported"""
+    monkey_argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        assert bench_on_stand_ins.module.parse().single_query > 0
+    finally:
+        sys.argv = monkey_argv
+    r = bench_on_stand_ins(SMALL[:-4] + ["--single-query", "12", "--set-concurrent", "0", "--graph-rows", "0",
+                                         "--structured-rows", "0", "--no-cpu-baseline"])
+    sq = r["single_query"]
+    assert sq["calls"] == 12 and "10000 x 128 L2" in sq["workload"]
+    assert sq["flat_exact"]["identical_to_oracle_exhaustive"] == "12 of 12" and sq["flat_exact"]["latency_us_median"] > 0
+    assert sq["graph_ef10"]["identical_to_oracle_hnsw"] == "12 of 12" and sq["graph_ef10"]["cpu_oracle_hnsw_us_1_thread"] > 0
+    assert "single_query" not in r["optional_legs_skipped"]
+
+
+def test_a_spent_time_budget_skips_the_single_query_leg(bench_on_stand_ins):
+    r = bench_on_stand_ins(SMALL[:-4] + ["--single-query", "12", "--set-concurrent", "0", "--graph-rows", "0",
+                                         "--structured-rows", "0", "--no-cpu-baseline", "--time-budget", "0"])
+    assert "single_query" not in r and "single_query" in r["optional_legs_skipped"]
 
 
 def test_a_spent_time_budget_skips_the_optional_legs_and_says_so(bench_on_stand_ins):
