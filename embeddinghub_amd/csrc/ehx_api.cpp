@@ -1899,7 +1899,14 @@ int sharded_knn(ehx_space* p, size_t nq, const float* h_queries, const float* d_
     HIP_TRY(hipEventRecord(c->xev, c->stream));
     return EHX_OK;
   });
-  if (rc) return rc;
+  if (rc) {
+    // a shard failed: the others may still be writing into the gather buffer and their own scratch — drain them
+    // before the error leaves (the next call reuses both); g_err keeps the failing shard's message
+    for (ehx_space* c : p->shards)
+      if (hipSetDevice(c->device) == hipSuccess) (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
+    return rc;
+  }
   HIP_TRY(hipSetDevice(home));
   for (size_t i = 0; i < G; ++i) HIP_TRY(hipStreamWaitEvent(p->stream, p->shards[i]->xev, 0));
   const unsigned char* gp = p->dGPack.p;

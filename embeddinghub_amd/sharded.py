@@ -46,15 +46,17 @@ def _engine_merge(stream):
 
 class ShardedSearcher:
     def __init__(self, row0, batch, k, device, group=None, local_search=None, merge=None, space=None,
-                 stream=None):
+                 stream=None, exchange=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # exchange=True: gather + merge even in a world of one rank (how a 1-GPU box exercises the RCCL step)
+        self.exchange = self.world > 1 if exchange is None else bool(exchange)
         self.row0, self.k, self.batch = int(row0), int(k), int(batch)
         self.local_search = local_search or _engine_local_search(space, stream)
-        self.merge = merge or (_engine_merge(stream) if self.world > 1 else None)
+        self.merge = merge or (_engine_merge(stream) if self.exchange else None)
         mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)  # noqa: E731
         # one packed buffer per rank: ids [B,k] i64 | dist [B,k] f32 | count [B] i32, padded to 16 bytes
         B = self.batch
@@ -63,7 +65,7 @@ class ShardedSearcher:
         self.pack = torch.zeros(self._P, dtype=torch.uint8, device=device)
         self.ids, self.dst, self.cnt = self._views(self.pack.view(1, self._P))
         self.ids, self.dst, self.cnt = self.ids[0], self.dst[0], self.cnt[0]
-        if self.world > 1:
+        if self.exchange:
             G = self.world
             self.g_pack = torch.zeros(G * self._P, dtype=torch.uint8, device=device)
             self.g_ids, self.g_dst, self.g_cnt = self._views(self.g_pack.view(G, self._P))
@@ -81,7 +83,7 @@ class ShardedSearcher:
     def knn(self, queries):
         """queries: [batch, dims] on `device`.  Returns (ids, dist, count) tensors (global ids)."""
         self.local_search(queries, self.k, self.ids, self.dst, self.cnt)
-        if self.world == 1:
+        if not self.exchange:
             if self.row0:
                 self.ids.add_(self.row0)
             return self.ids, self.dst, self.cnt

@@ -13,4 +13,20 @@ if os.environ.get("EHX_BENCH_STANDINS") == "1":
     standins.install(real_sharded=True)
     import torch.distributed as dist
     _real_init = dist.init_process_group
-    dist.init_process_group = lambda backend=None, **kw: _real_init("gloo", **{k: v for k, v in kw.items() if k != "device_id"})
+
+    _real_barrier = dist.barrier
+
+    def _chatter():
+        # what RCCL does on a GPU box: a line through C stdio, which is block-buffered on a pipe and would surface at
+        # process exit — after the JSON line — if bench.py did not flush / re-point stdout itself
+        import ctypes
+        ctypes.CDLL(None).printf(b"Librccl path : stand-in (rank %s)\n" % os.environ.get("RANK", "?").encode())
+
+    def _init(backend=None, **kw):
+        return _real_init("gloo", **{k: v for k, v in kw.items() if k != "device_id"})
+
+    def _barrier(*a, **kw):
+        _chatter()   # (after gloo's own connection message, whose std::endl would flush an earlier line with it)
+        return _real_barrier(*a, **kw)
+    dist.init_process_group = _init
+    dist.barrier = _barrier

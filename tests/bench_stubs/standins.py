@@ -95,7 +95,7 @@ class FakeSpace:
 
 
 class FakeSearcher:
-    def __init__(self, row0, B, k, device, space=None, stream=None):
+    def __init__(self, row0, B, k, device, space=None, stream=None, exchange=None):
         self.space, self.k = space, k
         self.ids = torch.empty((B, k), dtype=torch.int64)
         self.dst = torch.empty((B, k), dtype=torch.float32)

@@ -202,6 +202,10 @@ def test_gpus_2_launches_two_real_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
+    # the JSON line is the LAST line on stdout even though the ranks' collective library writes there through C stdio
+    # (RCCL's "Librccl path : ..." sits in a block buffer until exit): rank 0 flushes it first, the others write to stderr
+    assert r.stdout.strip().splitlines()[-1] == lines[0], r.stdout[-500:]
+    assert "Librccl path : stand-in (rank 0)" in r.stdout + r.stderr
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2
     assert out["config"]["rows_per_rank"] == [1500, 1501] and out["config"]["rows_per_gpu"] == 1500

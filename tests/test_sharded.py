@@ -149,3 +149,52 @@ def test_gpu_packed_gather_buffer_merges_like_the_natural_layout():
         c = e_cnt[q]
         np.testing.assert_array_equal(o_ids.cpu().numpy()[q, :c], e_ids[q, :c])
         np.testing.assert_array_equal(o_dist.cpu().numpy()[q, :c], e_dist[q, :c])
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["EHX_REPO"])
+import embeddinghub_amd as ehx
+from embeddinghub_amd.sharded import ShardedSearcher
+from oracle import pyoracle
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+n, d, B, k, row0 = 30000, 96, 64, 10, 1000
+X = pyoracle.gen_rows(ehx.SEED_CORPUS, row0, n, d, normalize=True)
+Q = pyoracle.gen_rows(ehx.SEED_QUERY, 0, B, d, normalize=True)
+s = ehx.Space.unique("rccl1", d, metric=ehx.METRIC_COSINE, initial_capacity=n)
+s.fill_synthetic(ehx.SEED_CORPUS, row0, n, True)
+ss = ShardedSearcher(row0, B, k, "cuda", space=s, stream=torch.cuda.current_stream().cuda_stream, exchange=True)
+q = torch.from_numpy(Q).cuda()
+for _ in range(3):   # (the gather buffer and the packed buffer are reused batch after batch)
+    ids, dst, cnt = ss.knn(q)
+torch.cuda.synchronize()
+o_ids, o_dist, o_cnt = pyoracle.exhaustive(X, Q, k, pyoracle.METRIC_COSINE)
+assert (cnt.cpu().numpy() == o_cnt).all()
+assert (ids.cpu().numpy().astype(np.uint64) == o_ids + row0).all(), "ids differ"
+assert dst.cpu().numpy().tobytes() == o_dist.tobytes(), "distance bytes differ"
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL-ONE-RANK-OK")
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_step_in_a_world_of_one_rank():
+    """The one-process-per-GPU path on the hardware a test box has: ONE rank, backend "nccl" (= RCCL), the real
+    all_gather_into_tensor of the packed local top-k and the engine's merge out of the gather buffer, on the streams
+    bench.py uses; results = the oracle's exhaustive scan with global ids.  (Two ranks need two GPUs: RCCL refuses two
+    ranks on one device; the two-rank logic runs on gloo above and in tests/test_bench_flow.py.)"""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EHX_REPO=repo,
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
