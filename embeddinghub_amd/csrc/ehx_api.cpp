@@ -1357,10 +1357,8 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   uint32_t* sync = s->dI8Ctl.p + 2 * (size_t)p.q_rows;
   if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
   HIP_TRY(hipEventRecord(s->ev[0], st));
-  HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, p.q_rows, s->metric, s->dQ.p, st));
-  HIP_TRY(launch_prep_queries8(d_queries, (uint32_t)nq, s->dims, s->ld8, p.q_rows, s->metric, s->dQ8.p, s->dQp8.p,
-                               s->dQuv.p, s->dThr8.p, st));
-  HIP_TRY(hipMemsetAsync(s->dI8Ctl.p, 0, ((size_t)p.q_rows * 2 + 256) * sizeof(uint32_t), st));
+  HIP_TRY(launch_prep_queries_i8(d_queries, (uint32_t)nq, s->dims, s->ld, s->ld8, p.q_rows, s->metric, s->dQ.p,
+                                 s->dQ8.p, s->dQp8.p, s->dQuv.p, s->dThr8.p, s->dI8Ctl.p, st));
   ScanArgsI8 a;
   a.Q = s->dQ8.p;
   a.X = s->dX8;

@@ -587,8 +587,11 @@ hipError_t launch_make_scan8(const void* X, int x_half, uint64_t row0, uint64_t 
 hipError_t launch_rowp8_pad(float4* rowp8, uint64_t row0, uint64_t n, hipStream_t st);
 hipError_t launch_tilep8_pad(float4* tilep8, uint64_t t0, uint64_t n, hipStream_t st);
 // int8 query tiles + (s_q, e_q, gamma_q) + (u, v) with D = u*S + v; thr[q] = +inf for q < nq, -inf for padding
-hipError_t launch_prep_queries8(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld8, uint32_t q_rows,
-                                int metric, int8_t* Q8, float4* qparams, float2* quv, float* thr, hipStream_t st);
+// ... in ONE launch with the prepared fp32 rows of the re-rank (launch_prep_queries' q_out) and the zeroing of the scan's
+// control words ctl = [q_rows] pool counts | [q_rows] overflow flags | [256] lock-step counters
+hipError_t launch_prep_queries_i8(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld, uint32_t ld8,
+                                  uint32_t q_rows, int metric, float* q_out, int8_t* Q8, float4* qparams, float2* quv,
+                                  float* thr, uint32_t* ctl, hipStream_t st);
 // sample pass -> first thresholds: thr[q] = the rank-th (<= 64) smallest of scores[0..n_rows)[q] (+inf if fewer)
 hipError_t launch_sample_select256(const float* scores, uint32_t n_rows, uint32_t q_rows, uint32_t nq,
                                    uint32_t rank, float* thr, hipStream_t st);

@@ -37,12 +37,10 @@ __device__ __forceinline__ float inv_norm_of(float sumsq) {
 }
 }  // namespace
 
-__global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restrict__ q_in, uint32_t nq,
-                                                          uint32_t dims, uint32_t ld, uint32_t q_rows,
-                                                          int metric, float* __restrict__ q_out) {
-  // one wave per output row: lane 0 computes the canonical norm, all lanes scale/copy
-  const uint32_t row = blockIdx.x;
-  const int lane = threadIdx.x;
+namespace {
+// one wave per output row: lane 0 computes the canonical norm, all lanes scale/copy
+__device__ __forceinline__ void prep_query_row(const float* __restrict__ q_in, uint32_t nq, uint32_t dims, uint32_t ld,
+                                               int metric, float* __restrict__ q_out, uint32_t row, int lane) {
   float* out = q_out + (size_t)row * ld;
   if (row >= nq) {
     for (uint32_t i = lane; i < ld; i += 64) out[i] = 0.0f;
@@ -83,6 +81,13 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restric
     if (metric == 2) v = ex_mul(v, inv);
     out[i] = v;
   }
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restrict__ q_in, uint32_t nq,
+                                                          uint32_t dims, uint32_t ld, uint32_t q_rows,
+                                                          int metric, float* __restrict__ q_out) {
+  prep_query_row(q_in, nq, dims, ld, metric, q_out, blockIdx.x, (int)threadIdx.x);
 }
 
 hipError_t launch_prep_queries(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld, uint32_t q_rows,
@@ -419,12 +424,11 @@ hipError_t launch_tilep8_pad(float4* tilep8, uint64_t t0, uint64_t n, hipStream_
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(64) void prep_queries8_kernel(const float* __restrict__ q_in, uint32_t nq, uint32_t dims,
-                                                           uint32_t ld8, int metric, int8_t* __restrict__ Q8,
-                                                           float4* __restrict__ qparams, float2* __restrict__ quv,
-                                                           float* __restrict__ thr) {
-  const uint32_t row = blockIdx.x;
-  const int lane = threadIdx.x;
+namespace {
+__device__ __forceinline__ void prep_query8_row(const float* __restrict__ q_in, uint32_t nq, uint32_t dims, uint32_t ld8,
+                                                int metric, int8_t* __restrict__ Q8, float4* __restrict__ qparams,
+                                                float2* __restrict__ quv, float* __restrict__ thr, uint32_t row,
+                                                int lane) {
   const uint32_t kts = ld8 >> 6;
   // the three blocks after the last stage repeat the tile's first stages — block kts + j holds stage j mod kts — so
   // that the scan's three-stage look-ahead reads linearly across a tile boundary (kts = 2: stages 0, 1, 0)
@@ -482,11 +486,34 @@ __global__ __launch_bounds__(64) void prep_queries8_kernel(const float* __restri
     thr[row] = __builtin_inff();
   }
 }
+}  // namespace
 
-hipError_t launch_prep_queries8(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld8, uint32_t q_rows,
-                                int metric, int8_t* Q8, float4* qparams, float2* quv, float* thr, hipStream_t st) {
-  hipLaunchKernelGGL(prep_queries8_kernel, dim3(q_rows), dim3(64), 0, st, q_in, nq, dims, ld8, metric, Q8, qparams,
-                     quv, thr);
+// Everything a batch of the int8 engine needs before its first scan launch, ONE launch (it was three: the fp32 query
+// rows of the re-rank, the int8 tiles + parameters, and a memset of the scan's control words): one wave per query row
+// writes its prepared fp32 row, its int8 tile and parameters, and zeroes its pool count and overflow flag; block 0 also
+// zeroes the 256 lock-step counters.  ctl = [q_rows] pool counts | [q_rows] overflow flags | [256] counters.
+__global__ __launch_bounds__(64) void prep_queries_i8_kernel(const float* __restrict__ q_in, uint32_t nq, uint32_t dims,
+                                                             uint32_t ld, uint32_t ld8, uint32_t q_rows, int metric,
+                                                             float* __restrict__ q_out, int8_t* __restrict__ Q8,
+                                                             float4* __restrict__ qparams, float2* __restrict__ quv,
+                                                             float* __restrict__ thr, uint32_t* __restrict__ ctl) {
+  const uint32_t row = blockIdx.x;
+  const int lane = threadIdx.x;
+  prep_query_row(q_in, nq, dims, ld, metric, q_out, row, lane);
+  prep_query8_row(q_in, nq, dims, ld8, metric, Q8, qparams, quv, thr, row, lane);
+  if (lane == 0) {
+    ctl[row] = 0;
+    ctl[q_rows + row] = 0;
+  }
+  if (row == 0)
+    for (uint32_t i = lane; i < 256; i += 64) ctl[2 * (size_t)q_rows + i] = 0;
+}
+
+hipError_t launch_prep_queries_i8(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld, uint32_t ld8,
+                                  uint32_t q_rows, int metric, float* q_out, int8_t* Q8, float4* qparams, float2* quv,
+                                  float* thr, uint32_t* ctl, hipStream_t st) {
+  hipLaunchKernelGGL(prep_queries_i8_kernel, dim3(q_rows), dim3(64), 0, st, q_in, nq, dims, ld, ld8, q_rows, metric,
+                     q_out, Q8, qparams, quv, thr, ctl);
   return hipGetLastError();
 }
 
