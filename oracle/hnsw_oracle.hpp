@@ -29,15 +29,18 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <queue>
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <utility>
@@ -694,6 +697,192 @@ class HnswOracle {
       }
     }
   }
+
+  // -----------------------------------------------------------------------------------------------
+  // Parallel bulk build — hnswlib's multi-threaded add_items (hnswlib-python; the reference's offline path calls it at
+  // sdk/python/offlinehub.py:89 with the default thread count).  ONLY for CPU BASELINES of bench.py and studies: like
+  // hnswlib's, the graph it builds depends on thread timing, so no parity test ever uses it — the sequential addPoint
+  // above is the oracle, and nothing below is called by it or changes it (separate functions on purpose).
+  // Locking as in hnswlib: one mutex per element guards its link lists (held while a searcher reads a list and while
+  // mutuallyConnect rewrites it), the element being inserted holds its own lock throughout, and an insertion that
+  // raises the top level holds the global lock until it has become the entry point.  Rows are fresh labels only; the
+  // first row of an empty index is inserted alone (hnswlib does the same); levels are drawn up front, in row order.
+  // -----------------------------------------------------------------------------------------------
+ public:
+  void addPointsParallel(const float* rows, size_t n, labeltype first_label, int threads) {
+    if (n == 0) return;
+    if (cur_element_count_ + n > max_elements_)
+      throw std::runtime_error("The number of elements exceeds the specified limit");
+    for (size_t i = 0; i < n; ++i)
+      if (label_lookup_.count(first_label + i)) throw std::runtime_error("parallel build: labels must be fresh");
+    size_t start = 0;
+    if (cur_element_count_ == 0) {  // the first element alone
+      addPoint(rows, first_label);
+      start = 1;
+    }
+    const size_t base = cur_element_count_;
+    const size_t m = n - start;
+    if (m == 0) return;
+    if (labels_.size() < base + m) labels_.resize(base + m);
+    for (size_t i = 0; i < m; ++i) {  // ids, levels, vectors, empty lists: before any thread starts
+      const tableint id = (tableint)(base + i);
+      label_lookup_[first_label + start + i] = id;
+      labels_[id] = first_label + start + i;
+      const int lvl = getRandomLevel(mult_);
+      element_levels_[id] = lvl;
+      std::memset(linklist0(id), 0, sizeof(unsigned) * (maxM0_ + 1));
+      std::memcpy(&data_[(size_t)id * dim_], rows + (start + i) * dim_, sizeof(float) * dim_);
+      links_upper_[id].assign((size_t)lvl * (maxM_ + 1), 0);
+    }
+    cur_element_count_ = base + m;
+    if (mt_locks_.size() < max_elements_) mt_locks_ = std::vector<std::mutex>(max_elements_);
+    if (threads < 1) threads = 1;
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    std::vector<std::string> errors((size_t)threads);
+    for (int t = 0; t < threads; ++t)
+      pool.emplace_back([&, t] {
+        SearchCtx ctx;
+        try {
+          for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= m) break;
+            insertLinkedMT((tableint)(base + i), ctx);
+          }
+        } catch (const std::exception& e) {
+          errors[(size_t)t] = e.what();
+          next.store(m);
+        }
+      });
+    for (auto& th : pool) th.join();
+    for (auto& e : errors)
+      if (!e.empty()) throw std::runtime_error("parallel build: " + e);
+  }
+
+ private:
+  void insertLinkedMT(tableint cur_c, SearchCtx& ctx) {
+    const float* data_point = vec(cur_c);
+    const int curlevel = element_levels_[cur_c];
+    std::unique_lock<std::mutex> lock_el(mt_locks_[cur_c]);
+    std::unique_lock<std::mutex> templock(mt_global_);
+    const int maxlevelcopy = maxlevel_;
+    tableint currObj = enterpoint_node_;
+    if (curlevel <= maxlevelcopy) templock.unlock();
+    if (curlevel < maxlevelcopy) {
+      float curdist = dist(data_point, vec(currObj));
+      for (int level = maxlevelcopy; level > curlevel; level--) {
+        bool changed = true;
+        while (changed) {
+          changed = false;
+          std::unique_lock<std::mutex> lk(mt_locks_[currObj]);
+          const unsigned* data = linklist(currObj, level);
+          const int size = (int)(data[0] & 0xffff);
+          const tableint* datal = data + 1;
+          for (int i = 0; i < size; i++) {
+            const tableint cand = datal[i];
+            const float d = dist(data_point, vec(cand));
+            if (d < curdist) {
+              curdist = d;
+              currObj = cand;
+              changed = true;
+            }
+          }
+        }
+      }
+    }
+    for (int level = std::min(curlevel, maxlevelcopy); level >= 0; level--) {
+      CandQueue top = searchBaseLayerMT(currObj, data_point, level, ctx);
+      currObj = connectMT(cur_c, top, level);
+    }
+    if (curlevel > maxlevelcopy) {  // (still under the global lock)
+      enterpoint_node_ = cur_c;
+      maxlevel_ = curlevel;
+    }
+  }
+
+  CandQueue searchBaseLayerMT(tableint ep_id, const float* data_point, int layer, SearchCtx& ctx) {
+    ctx.next_tag(max_elements_);
+    std::vector<unsigned short>& visited = ctx.visited;
+    const unsigned short tag = ctx.tag;
+    CandQueue top_candidates, candidateSet;
+    float lowerBound;
+    {
+      const float d = dist(data_point, vec(ep_id));
+      top_candidates.emplace(d, ep_id);
+      lowerBound = d;
+      candidateSet.emplace(-d, ep_id);
+    }
+    visited[ep_id] = tag;
+    std::vector<tableint> nbrs;
+    while (!candidateSet.empty()) {
+      const std::pair<float, tableint> curr = candidateSet.top();
+      if ((-curr.first) > lowerBound) break;
+      candidateSet.pop();
+      {
+        std::unique_lock<std::mutex> lk(mt_locks_[curr.second]);  // the list may be rewritten by a concurrent insertion
+        const unsigned* data = linklist_at(curr.second, layer);
+        const size_t size = data[0] & 0xffff;
+        nbrs.assign(data + 1, data + 1 + size);
+      }
+      for (const tableint cand : nbrs) {
+        if (visited[cand] == tag) continue;
+        visited[cand] = tag;
+        const float d1 = dist(data_point, vec(cand));
+        if (top_candidates.size() < ef_construction_ || lowerBound > d1) {
+          candidateSet.emplace(-d1, cand);
+          top_candidates.emplace(d1, cand);
+          if (top_candidates.size() > ef_construction_) top_candidates.pop();
+          if (!top_candidates.empty()) lowerBound = top_candidates.top().first;
+        }
+      }
+    }
+    return top_candidates;
+  }
+
+  // mutuallyConnectNewElement with the neighbour's lock held while its list changes (cur_c's own lock is held by the
+  // caller); a link may only go to an element that has the level (elements of the same batch may still be unlinked
+  // at it — their lists are valid, empty, and fill when their own insertion gets there)
+  tableint connectMT(tableint cur_c, CandQueue& top_candidates, int level) {
+    const size_t Mcurmax = level ? maxM_ : maxM0_;
+    getNeighborsByHeuristic2(top_candidates, M_);
+    std::vector<tableint> selected;
+    selected.reserve(M_);
+    while (top_candidates.size() > 0) {
+      selected.push_back(top_candidates.top().second);
+      top_candidates.pop();
+    }
+    const tableint next_closest_entry_point = selected.back();
+    {
+      unsigned* ll_cur = linklist_at(cur_c, level);
+      ll_cur[0] = (unsigned)selected.size();
+      for (size_t idx = 0; idx < selected.size(); idx++) ll_cur[1 + idx] = selected[idx];
+    }
+    for (const tableint other : selected) {
+      std::unique_lock<std::mutex> lk(mt_locks_[other]);
+      unsigned* ll_other = linklist_at(other, level);
+      const size_t sz = ll_other[0] & 0xffff;
+      tableint* data = ll_other + 1;
+      if (sz < Mcurmax) {
+        data[sz] = cur_c;
+        ll_other[0] = (unsigned)(sz + 1);
+      } else {
+        CandQueue candidates;
+        candidates.emplace(dist(vec(cur_c), vec(other)), cur_c);
+        for (size_t j = 0; j < sz; j++) candidates.emplace(dist(vec(data[j]), vec(other)), data[j]);
+        getNeighborsByHeuristic2(candidates, Mcurmax);
+        int indx = 0;
+        while (candidates.size() > 0) {
+          data[indx++] = candidates.top().second;
+          candidates.pop();
+        }
+        ll_other[0] = (unsigned)indx;
+      }
+    }
+    return next_closest_entry_point;
+  }
+
+  std::vector<std::mutex> mt_locks_;
+  std::mutex mt_global_;
 
   size_t dim_;
   int metric_;

@@ -89,6 +89,27 @@ int orc_hnsw_add(void* p, const float* v, uint64_t label, char* err, size_t cap)
 }
 // labels = row index; sequential insertion order (what the reference's mutex-serialised
 // server produces).  Returns seconds spent.
+// CPU BASELINES only: hnswlib's multi-threaded add_items (timing-dependent graph; never used by a parity test).
+// Returns seconds spent, or -1 on error (message in err).
+double orc_hnsw_add_rows_parallel(void* p, const float* X, size_t n, uint64_t first_label, int threads, char* err,
+                                  size_t err_cap) {
+  Handle* h = (Handle*)p;
+  auto t0 = std::chrono::steady_clock::now();
+  try {
+    if (h->metric == METRIC_COSINE) {
+      std::vector<float> t(n * h->dim);
+      for (size_t i = 0; i < n; i++) normalize_vector(X + i * h->dim, t.data() + i * h->dim, h->dim);
+      h->hnsw->addPointsParallel(t.data(), n, first_label, threads);
+    } else {
+      h->hnsw->addPointsParallel(X, n, first_label, threads);
+    }
+  } catch (const std::exception& e) {
+    if (err && err_cap) snprintf(err, err_cap, "%s", e.what());
+    return -1.0;
+  }
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 double orc_hnsw_add_rows(void* p, const float* X, size_t n, uint64_t first_label) {
   Handle* h = (Handle*)p;
   auto t0 = std::chrono::steady_clock::now();

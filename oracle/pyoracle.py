@@ -36,6 +36,8 @@ def lib():
         L.orc_hnsw_add.argtypes = [C.c_void_p, f32p, C.c_uint64, C.c_char_p, C.c_size_t]
         L.orc_hnsw_add_rows.restype = C.c_double
         L.orc_hnsw_add_rows.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_uint64]
+        L.orc_hnsw_add_rows_parallel.restype = C.c_double
+        L.orc_hnsw_add_rows_parallel.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_uint64, C.c_int, C.c_char_p, C.c_size_t]
         L.orc_hnsw_resize.restype = C.c_int
         L.orc_hnsw_resize.argtypes = [C.c_void_p, C.c_size_t]
         L.orc_hnsw_set_ef.argtypes = [C.c_void_p, C.c_size_t]
@@ -143,6 +145,17 @@ class Hnsw:
     def add_rows(self, X, first_label=0):
         X, pX = _f32(X)
         return lib().orc_hnsw_add_rows(self._h, pX, X.shape[0], first_label)
+
+    def add_rows_parallel(self, X, first_label=0, threads=0):
+        """hnswlib's multi-threaded add_items, for CPU BASELINES only: the graph depends on thread timing, so no parity
+        test may use it (add_rows is the oracle).  Returns the seconds spent."""
+        X, pX = _f32(X)
+        err = C.create_string_buffer(256)
+        sec = lib().orc_hnsw_add_rows_parallel(self._h, pX, X.shape[0], first_label, threads or os.cpu_count() or 1,
+                                               err, 256)
+        if sec < 0:
+            raise RuntimeError(err.value.decode())
+        return sec
 
     def resize(self, cap):
         if lib().orc_hnsw_resize(self._h, cap) != 0:
