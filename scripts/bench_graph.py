@@ -58,7 +58,7 @@ def main():
             if norm:
                 x /= np.linalg.norm(x, axis=1, keepdims=True)
             return np.ascontiguousarray(x, dtype=np.float32)
-        Q = manifold(ehx.SEED_QUERY, B)
+        Q = manifold(ehx.SEED_QUERY + 1000, B)  # (+1000: SEED_QUERY + i equals the seed of corpus chunk i — queries drawn with it are noisy copies of corpus rows)
     if manifold is not None:
         # host-generated rows through the public write path into a graph space (concurrent insertion rounds,
         # build_batch given explicitly) and a flat space (ground truth)

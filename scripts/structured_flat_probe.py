@@ -30,7 +30,7 @@ for i0 in range(0, n2, chunk):
     flat.set_batch([b"%d" % i for i in range(i0, i0 + m)], manifold(ehx.SEED_CORPUS + 1 + i0 // chunk, m))
 print("engine", flat.scan_engine(), "rows", len(flat), flush=True)
 for b in range(8):
-    Q = manifold(ehx.SEED_QUERY + b, B)
+    Q = manifold(ehx.SEED_QUERY + 1000 + b, B)  # (+1000: independent of the corpus chunks' seeds SEED_CORPUS + 1 + i)
     flat.stats_reset()
     t0 = time.perf_counter()
     flat.knn(Q, k)

@@ -4,8 +4,11 @@ recall@k").  The oracle-built graphs come from tests/golden/make_big_graphs.py (
 
   (a) the oracle's graph, IMPORTED: the engine's search must return the oracle's ids, distance bytes and counts for
       ef = 10 / 100 / 400 (the oracle's own results are stored next to the graph);
-      (the fourth configuration, man200k768, is bench.py's STRUCTURED data — rows on a 32-dim manifold, where the graph
-      path is the operating point — written through ehx_set_batch in chunks like the bench leg);
+      (the fourth configuration, man200k768, is STRUCTURED data — rows on a 32-dim manifold written through
+      ehx_set_batch in chunks like bench.py's structured leg; its queries are the ones that leg used in round 3, whose
+      generator seed coincides with a corpus chunk's: each is a corpus row's latent point under fresh noise, i.e. a
+      near-duplicate lookup — a regime with recall near 1 at every ef, which the identity and the recall-parity checks
+      below do not depend on; bench.py draws independent queries now);
   (b) the same rows BUILT ON THE GPU in rounds of 4096 (what every >= 1 M-row number of this repo uses; hnswlib's
       multi-threaded add_items is the reference analogue, sdk/python/offlinehub.py:89): recall@10 against the exact
       answer, at equal ef, within 0.005 of the oracle-built graph's (BASELINE.md §2 gate), over 4096 queries;
