@@ -66,7 +66,7 @@ def test_default_flow_prints_one_json_line_with_the_contract_fields(bench_on_sta
     assert r["graph_path"]["recall_vs_ef"][0]["ef"] == 10 and "operating_point" in r["graph_path"]
     assert "graph_path_structured" in r and r["optional_legs_skipped"] == {}
     cs = r["graph_path_structured"]["cpu_hnsw_sample_in_run"]   # the CPU oracle's HNSW over the same rows, built in the run
-    assert cs["rows"] == 600 and [p["ef"] for p in cs["recall_vs_ef"]] == [10, 20, 40, 100, 200] and cs["threads"] >= 1
+    assert cs["rows"] == 600 and [p["ef"] for p in cs["recall_vs_ef"]] == [10, 20, 40, 60, 100, 200] and cs["threads"] >= 1
     assert all(p["qps_all_cores"] > 0 and 0.0 <= p["recall_at_10"] <= 1.0 for p in cs["recall_vs_ef"])
     assert "host_pointer_path" in r and "f32_scan_engine" in r
 
