@@ -881,6 +881,143 @@ class HnswOracle {
     return next_closest_entry_point;
   }
 
+  // -----------------------------------------------------------------------------------------------
+  // A CPU MODEL of the engine's BULK build (embeddinghub_amd/csrc/ehx_api.cpp graph_insert + k_insert.hip) — for
+  // studies only (scripts/studies/bulk_build_model.py): rows join the graph in ROUNDS; every row of a round runs
+  // hnswlib's insertion search on the graph as it was BEFORE the round (so the rows of a round do not see each other),
+  // selects its neighbours with the heuristic, and then the round is linked in ascending id order: a new node's own
+  // lists are written as selected, every selected neighbour gets the back-link (appended, or its list re-selected
+  // with the heuristic when it is full) — mutuallyConnectNewElement with the candidates of the frozen graph.  Round
+  // size: graph_size / div, at most cap, 1 while the graph holds fewer than 64 nodes (graph_insert's round_size).
+  // Levels come from the same generator in the same order as the sequential build's.
+  // -----------------------------------------------------------------------------------------------
+ public:
+  void addPointsRounds(const float* rows, size_t n, labeltype first_label, size_t div, size_t cap, int threads) {
+    if (cur_element_count_ + n > max_elements_)
+      throw std::runtime_error("The number of elements exceeds the specified limit");
+    size_t pos = 0;
+    if (cur_element_count_ == 0 && n > 0) {
+      addPoint(rows, first_label);
+      pos = 1;
+    }
+    struct Plan {
+      std::vector<std::vector<tableint>> sel;  // [level] selected neighbours, farthest first (the heap's pop order)
+    };
+    if (threads < 1) threads = 1;
+    while (pos < n) {
+      const size_t g = cur_element_count_;
+      size_t P = 1;
+      if (g >= 64) P = std::max<size_t>(1, std::min(cap, g / div));
+      P = std::min(P, n - pos);
+      const size_t base = cur_element_count_;
+      if (labels_.size() < base + P) labels_.resize(base + P);
+      for (size_t i = 0; i < P; ++i) {  // register the round's rows (levels in row order); lists stay empty for now
+        const tableint id = (tableint)(base + i);
+        label_lookup_[first_label + pos + i] = id;
+        labels_[id] = first_label + pos + i;
+        const int lvl = getRandomLevel(mult_);
+        element_levels_[id] = lvl;
+        std::memset(linklist0(id), 0, sizeof(unsigned) * (maxM0_ + 1));
+        std::memcpy(&data_[(size_t)id * dim_], rows + (pos + i) * dim_, sizeof(float) * dim_);
+        links_upper_[id].assign((size_t)lvl * (maxM_ + 1), 0);
+      }
+      // phase 1: searches on the frozen graph (cur_element_count_ still excludes the round: nothing links to it)
+      std::vector<Plan> plans(P);
+      const int maxlevelcopy = maxlevel_;
+      const tableint ep = enterpoint_node_;
+      std::atomic<size_t> next{0};
+      auto work = [&] {
+        SearchCtx ctx;
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= P) break;
+          const tableint cur_c = (tableint)(base + i);
+          const float* q = vec(cur_c);
+          const int curlevel = element_levels_[cur_c];
+          tableint currObj = ep;
+          if (curlevel < maxlevelcopy) {
+            float curdist = dist(q, vec(currObj));
+            for (int level = maxlevelcopy; level > curlevel; level--) {
+              bool changed = true;
+              while (changed) {
+                changed = false;
+                const unsigned* data = linklist(currObj, level);
+                const int size = (int)(data[0] & 0xffff);
+                for (int j = 0; j < size; j++) {
+                  const tableint cand = data[1 + j];
+                  const float dd = dist(q, vec(cand));
+                  if (dd < curdist) {
+                    curdist = dd;
+                    currObj = cand;
+                    changed = true;
+                  }
+                }
+              }
+            }
+          }
+          const int top = std::min(curlevel, maxlevelcopy);
+          plans[i].sel.assign((size_t)top + 1, {});
+          for (int level = top; level >= 0; level--) {
+            CandQueue cand = searchBaseLayerMT(currObj, q, level, ctx);  // (locks uncontended: nothing writes now)
+            getNeighborsByHeuristic2(cand, M_);
+            std::vector<tableint>& sel = plans[i].sel[(size_t)level];
+            while (cand.size() > 0) {
+              sel.push_back(cand.top().second);
+              cand.pop();
+            }
+            currObj = sel.back();
+          }
+        }
+      };
+      if (mt_locks_.size() < max_elements_) mt_locks_ = std::vector<std::mutex>(max_elements_);
+      std::vector<std::thread> pool;
+      for (int t = 1; t < threads && (size_t)t < P; ++t) pool.emplace_back(work);
+      work();
+      for (auto& th : pool) th.join();
+      // phase 2: link the round in ascending id order
+      for (size_t i = 0; i < P; ++i) {
+        const tableint cur_c = (tableint)(base + i);
+        for (size_t level = 0; level < plans[i].sel.size(); ++level) {
+          const std::vector<tableint>& sel = plans[i].sel[level];
+          const size_t Mcurmax = level ? maxM_ : maxM0_;
+          unsigned* ll_cur = linklist_at(cur_c, (int)level);
+          ll_cur[0] = (unsigned)sel.size();
+          for (size_t x = 0; x < sel.size(); ++x) ll_cur[1 + x] = sel[x];
+          for (const tableint other : sel) {
+            unsigned* ll_other = linklist_at(other, (int)level);
+            const size_t sz = ll_other[0] & 0xffff;
+            tableint* data = ll_other + 1;
+            if (sz < Mcurmax) {
+              data[sz] = cur_c;
+              ll_other[0] = (unsigned)(sz + 1);
+            } else {
+              CandQueue candidates;
+              candidates.emplace(dist(vec(cur_c), vec(other)), cur_c);
+              for (size_t j = 0; j < sz; j++) candidates.emplace(dist(vec(data[j]), vec(other)), data[j]);
+              getNeighborsByHeuristic2(candidates, Mcurmax);
+              int indx = 0;
+              while (candidates.size() > 0) {
+                data[indx++] = candidates.top().second;
+                candidates.pop();
+              }
+              ll_other[0] = (unsigned)indx;
+            }
+          }
+        }
+      }
+      cur_element_count_ = base + P;
+      for (size_t i = 0; i < P; ++i) {  // entry point / top level: the first node of the round that raises it
+        const tableint id = (tableint)(base + i);
+        if (element_levels_[id] > maxlevel_) {
+          enterpoint_node_ = id;
+          maxlevel_ = element_levels_[id];
+        }
+      }
+      pos += P;
+    }
+  }
+
+ private:
   std::vector<std::mutex> mt_locks_;
   std::mutex mt_global_;
 

@@ -110,6 +110,26 @@ double orc_hnsw_add_rows_parallel(void* p, const float* X, size_t n, uint64_t fi
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// STUDIES only: a CPU model of the engine's bulk build (rounds whose rows do not see each other); see hnsw_oracle.hpp.
+double orc_hnsw_add_rows_rounds(void* p, const float* X, size_t n, uint64_t first_label, size_t div, size_t cap,
+                                int threads, char* err, size_t err_cap) {
+  Handle* h = (Handle*)p;
+  auto t0 = std::chrono::steady_clock::now();
+  try {
+    if (h->metric == METRIC_COSINE) {
+      std::vector<float> t(n * h->dim);
+      for (size_t i = 0; i < n; i++) normalize_vector(X + i * h->dim, t.data() + i * h->dim, h->dim);
+      h->hnsw->addPointsRounds(t.data(), n, first_label, div, cap, threads);
+    } else {
+      h->hnsw->addPointsRounds(X, n, first_label, div, cap, threads);
+    }
+  } catch (const std::exception& e) {
+    if (err && err_cap) snprintf(err, err_cap, "%s", e.what());
+    return -1.0;
+  }
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 double orc_hnsw_add_rows(void* p, const float* X, size_t n, uint64_t first_label) {
   Handle* h = (Handle*)p;
   auto t0 = std::chrono::steady_clock::now();

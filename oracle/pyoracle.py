@@ -36,6 +36,9 @@ def lib():
         L.orc_hnsw_add.argtypes = [C.c_void_p, f32p, C.c_uint64, C.c_char_p, C.c_size_t]
         L.orc_hnsw_add_rows.restype = C.c_double
         L.orc_hnsw_add_rows.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_uint64]
+        L.orc_hnsw_add_rows_rounds.restype = C.c_double
+        L.orc_hnsw_add_rows_rounds.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_size_t, C.c_int,
+                                               C.c_char_p, C.c_size_t]
         L.orc_hnsw_add_rows_parallel.restype = C.c_double
         L.orc_hnsw_add_rows_parallel.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_uint64, C.c_int, C.c_char_p, C.c_size_t]
         L.orc_hnsw_resize.restype = C.c_int
@@ -153,6 +156,17 @@ class Hnsw:
         err = C.create_string_buffer(256)
         sec = lib().orc_hnsw_add_rows_parallel(self._h, pX, X.shape[0], first_label, threads or os.cpu_count() or 1,
                                                err, 256)
+        if sec < 0:
+            raise RuntimeError(err.value.decode())
+        return sec
+
+    def add_rows_rounds(self, X, first_label=0, div=128, cap=4096, threads=0):
+        """A CPU MODEL of the engine's bulk build, for studies only: rounds of graph_size / div rows (at most cap) that do
+        not see each other, linked in ascending id order.  Returns the seconds spent."""
+        X, pX = _f32(X)
+        err = C.create_string_buffer(256)
+        sec = lib().orc_hnsw_add_rows_rounds(self._h, pX, X.shape[0], first_label, div, cap,
+                                             threads or os.cpu_count() or 1, err, 256)
         if sec < 0:
             raise RuntimeError(err.value.decode())
         return sec

@@ -75,3 +75,38 @@ def test_the_sequential_build_is_unchanged_by_the_parallel_code():
     hh.update(ids.tobytes())
     hh.update(dist.tobytes())
     assert (hh.hexdigest()[:16], h.enterpoint, h.maxlevel, st["n_dist"]) == ("07ade06e1ed23261", 115, 2, 49537)
+
+
+def test_bulk_build_model_with_rounds_of_one_row_is_the_sequential_build():
+    """oracle/hnsw_oracle.hpp addPointsRounds — the CPU model of the engine's bulk build (studies only): with one row per
+    round it must BE hnswlib's sequential build, list for list"""
+    n, d = 2500, 24
+    X = np.random.default_rng(1).standard_normal((n, d)).astype(np.float32)
+    for metric in (pyoracle.METRIC_L2, pyoracle.METRIC_COSINE):
+        a = pyoracle.Hnsw(d, metric, n)
+        a.add_rows(X)
+        b = pyoracle.Hnsw(d, metric, n)
+        b.add_rows_rounds(X, div=10 ** 9, cap=1, threads=3)
+        la, va, ua = a.export_graph()
+        lb, vb, ub = b.export_graph()
+        assert np.array_equal(la, lb) and np.array_equal(va, vb) and (a.enterpoint, a.maxlevel) == (b.enterpoint, b.maxlevel)
+        assert set(ua) == set(ub) and all(np.array_equal(ua[key], ub[key]) for key in ua)
+
+
+def test_bulk_build_model_rounds_keep_the_invariants_and_cost_little_recall():
+    n, d, nq, k = 8000, 32, 256, 10
+    X = pyoracle.gen_rows(21, 0, n, d, normalize=False)
+    Q = pyoracle.gen_rows(22, 0, nq, d, normalize=False)
+    truth, _, _ = pyoracle.exhaustive(X, Q, k, pyoracle.METRIC_L2)
+    seq = pyoracle.Hnsw(d, pyoracle.METRIC_L2, n)
+    seq.add_rows(X)
+    mod = pyoracle.Hnsw(d, pyoracle.METRIC_L2, n)
+    mod.add_rows_rounds(X, div=64, cap=4096, threads=4)
+    l0, lv, upper = mod.export_graph()
+    deg = l0[:, 0]
+    assert np.array_equal(lv, seq.export_graph()[1]) and (deg >= 1).all() and (deg <= 32).all()
+    for i in range(0, n, 7):
+        row = l0[i, 1:1 + deg[i]]
+        assert i not in row and len(set(row.tolist())) == len(row)
+    for ef in (10, 50, 200):
+        assert _recall(mod, Q, truth, k, ef) >= _recall(seq, Q, truth, k, ef) - 0.02
