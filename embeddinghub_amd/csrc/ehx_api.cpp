@@ -222,6 +222,9 @@ struct ehx_space {
   int8_t* dX8 = nullptr;       // [cap][ld8] in the stage-blocked scan8_index layout
   float4* dRowp8 = nullptr;    // [cap + 512] (A, B, C, D)
   float4* dTilep8 = nullptr;   // [cap/256 + 2]
+  float* dTileg8 = nullptr;    // [cap/256 + 2][16] per-lane-group max |A| (k_misc.hip: rows of a tile ordered by step)
+  uint8_t* dPerm8 = nullptr;   // [cap] position -> row index inside the tile
+  DevBuf<uint64_t> dTileList;  // scratch of launch_make_scan8
   uint32_t ld8 = 0;
   unsigned long long* dUnsafe8 = nullptr;
   uint64_t h_unsafe8 = 0;
@@ -239,8 +242,26 @@ struct ehx_space {
   unsigned long long* hUncertPin = nullptr;  // pinned landing place of a batch's verdict (uncertified-query count)
   char* hSmallPin = nullptr;                 // pinned staging of small host calls: [queries | ids, distances, counts]
   DevBuf<uint64_t> dSmallOut;                // their results, one block (one device-to-host copy)
+  // Host-pointer batches (ehx_knn with more than a handful of queries): every call in flight owns a SLOT — pinned
+  // staging for its queries and results, device buffers for both, a copy stream — so that the upload of call i + 1
+  // and the download of call i - 1 run beside the scan of call i (which alone needs scratch_mu).  One caller sees its
+  // own copies in series as before; two or more callers keep the scan kernels back to back.
+  struct HostSlot {
+    hipStream_t st = nullptr;
+    hipEvent_t in_ev = nullptr, done_ev = nullptr;
+    char* pin = nullptr;
+    size_t pin_bytes = 0;
+    DevBuf<float> dq;
+    DevBuf<unsigned char> dout;
+    bool busy = false;
+  };
+  static constexpr int kHostSlots = 3;
+  HostSlot hslot[kHostSlots];
+  std::mutex hs_mu;
+  std::condition_variable hs_cv;
   uint32_t i8_fb_score = 0;      // recent batches that lost queries to the next engine (see knn_device_locked)
-  uint32_t i8_width = kMerged8;  // width of the int8 pipeline's candidate list (doubles when batches lose queries)
+  uint32_t i8_width = kMerged8;  // width of the int8 pipeline's candidate list (doubles when batches lose queries;
+                                 // create_one seeds it from the row length)
   bool vis_dirty = false;    // a search that clears its bitmaps with a memset BEFORE the kernel leaves them marked; the
                              // visit-log mode needs them all-zero at launch
   // GPU-side insertion state
@@ -277,7 +298,7 @@ struct ehx_space {
   DevBuf<__half> dQ16;
   DevBuf<float> dQgamma, dFbQ, dFbDist, dSample;
   DevBuf<float2> dQuv;
-  DevBuf<uint32_t> dUflags, dFbCnt;
+  DevBuf<uint32_t> dUflags, dFbCnt, dFbIdx;
   DevBuf<uint64_t> dFbIds;
   unsigned long long* dUncert16 = nullptr;  // queries the filter pass could not certify
   // int8 filter scratch: query tiles + parameters, per-pass thresholds, sample scores, pools, running best 256
@@ -349,6 +370,9 @@ struct ehx_space {
     fr(dX8);
     fr(dRowp8);
     fr(dTilep8);
+    fr(dTileg8);
+    fr(dPerm8);
+    dTileList.release();
     fr(dUnsafe8);
     dQ8.release();
     dQp8.release();
@@ -366,6 +390,18 @@ struct ehx_space {
     hUncertPin = nullptr;
     if (hSmallPin) (void)hipHostFree(hSmallPin);
     hSmallPin = nullptr;
+    for (auto& h : hslot) {
+      if (h.pin) (void)hipHostFree(h.pin);
+      h.pin = nullptr;
+      h.pin_bytes = 0;
+      h.dq.release();
+      h.dout.release();
+      if (h.in_ev) (void)hipEventDestroy(h.in_ev);
+      if (h.done_ev) (void)hipEventDestroy(h.done_ev);
+      if (h.st) (void)hipStreamDestroy(h.st);
+      h.in_ev = h.done_ev = nullptr;
+      h.st = nullptr;
+    }
     fr(dAdj0);
     fr(dUpStart);
     fr(dUpLists);
@@ -379,6 +415,7 @@ struct ehx_space {
     dQuv.release();
     dUflags.release();
     dFbCnt.release();
+    dFbIdx.release();
     dFbIds.release();
     dVisited.release();
     dInsIds.release();
@@ -512,10 +549,16 @@ int grow(ehx_space* s, uint64_t rows) {
     hipError_t e5 = hipMalloc((void**)&nx8, want * s->ld8 + kScan8TailPadBytes);
     hipError_t e6 = hipMalloc((void**)&nr8, (want + 2 * kTileRows16) * sizeof(float4));
     hipError_t e7 = hipMalloc((void**)&nt8, (tiles + 2) * sizeof(float4));
-    if (e5 != hipSuccess || e6 != hipSuccess || e7 != hipSuccess) {
+    float* ng8 = nullptr;
+    uint8_t* np8 = nullptr;
+    hipError_t e8 = hipMalloc((void**)&ng8, (tiles + 2) * 16 * sizeof(float));
+    hipError_t e9 = hipMalloc((void**)&np8, want);
+    if (e5 != hipSuccess || e6 != hipSuccess || e7 != hipSuccess || e8 != hipSuccess || e9 != hipSuccess) {
       if (nx8) (void)hipFree(nx8);
       if (nr8) (void)hipFree(nr8);
       if (nt8) (void)hipFree(nt8);
+      if (ng8) (void)hipFree(ng8);
+      if (np8) (void)hipFree(np8);
       (void)hipFree(nx);
       (void)hipFree(nr);
       (void)hipFree(ni);
@@ -527,7 +570,11 @@ int grow(ehx_space* s, uint64_t rows) {
       HIP_TRY(hipMemcpyAsync(nx8, s->dX8, keep8 * s->ld8, hipMemcpyDeviceToDevice, s->stream));
       HIP_TRY(hipMemcpyAsync(nr8, s->dRowp8, keep8 * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
       HIP_TRY(hipMemcpyAsync(nt8, s->dTilep8, keep_tiles * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(ng8, s->dTileg8, keep_tiles * 16 * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(np8, s->dPerm8, keep8, hipMemcpyDeviceToDevice, s->stream));
     }
+    HIP_TRY(hipMemsetAsync(ng8 + keep_tiles * 16, 0, (tiles + 2 - keep_tiles) * 16 * sizeof(float), s->stream));
+    HIP_TRY(launch_perm8_pad(np8, keep8, want - keep8, s->stream));
     HIP_TRY(hipMemsetAsync(nx8 + keep8 * s->ld8, 0, (want - keep8) * s->ld8 + kScan8TailPadBytes, s->stream));
     HIP_TRY(launch_rowp8_pad(nr8, keep8, want + 2 * kTileRows16 - keep8, s->stream));
     HIP_TRY(launch_tilep8_pad(nt8, keep_tiles, tiles + 2 - keep_tiles, s->stream));
@@ -535,6 +582,10 @@ int grow(ehx_space* s, uint64_t rows) {
     if (s->dX8) (void)hipFree(s->dX8);
     if (s->dRowp8) (void)hipFree(s->dRowp8);
     if (s->dTilep8) (void)hipFree(s->dTilep8);
+    if (s->dTileg8) (void)hipFree(s->dTileg8);
+    if (s->dPerm8) (void)hipFree(s->dPerm8);
+    s->dTileg8 = ng8;
+    s->dPerm8 = np8;
     s->dX8 = nx8;
     s->dRowp8 = nr8;
     s->dTilep8 = nt8;
@@ -1364,6 +1415,8 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   a.X = s->dX8;
   a.rowp = s->dRowp8;
   a.tilep = s->dTilep8;
+  a.tileg = s->dTileg8;
+  a.perm = s->dPerm8;
   a.qparams = s->dQp8.p;
   a.thr = s->dThr8.p;
   a.cand = s->dCand.p;
@@ -1584,6 +1637,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   constexpr size_t kMaxExhaustive = 32;
   enum { kI8, kFilter, kF32, kExhaustive };
   int rc;
+  size_t n_short = 0;  // of the last stage's uncertified queries: those whose candidate LIST was too short (flag 2)
   // run one stage on `subset` (nullptr = every query); *unc = global indices it could not certify
   auto stage = [&](int kind, const std::vector<uint32_t>* subset, bool count_stats, std::vector<uint32_t>* unc) -> int {
     const size_t m = subset ? subset->size() : nq;
@@ -1596,9 +1650,10 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
       if ((rc = s->dFbIds.ensure(m * k))) return rc;
       if ((rc = s->dFbDist.ensure(m * k))) return rc;
       if ((rc = s->dFbCnt.ensure(m))) return rc;
-      for (size_t j = 0; j < m; ++j)
-        HIP_TRY(hipMemcpyAsync(s->dFbQ.p + j * s->dims, d_queries + (size_t)(*subset)[j] * s->dims,
-                               s->dims * sizeof(float), hipMemcpyDeviceToDevice, st));
+      if ((rc = s->dFbIdx.ensure(m))) return rc;
+      // (the index list comes from pageable host memory: the runtime stages it before the call returns)
+      HIP_TRY(hipMemcpyAsync(s->dFbIdx.p, subset->data(), m * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+      HIP_TRY(launch_gather_queries(d_queries, s->dFbIdx.p, (uint32_t)m, s->dims, s->dFbQ.p, st));
       q = s->dFbQ.p;
       oi = s->dFbIds.p;
       od = s->dFbDist.p;
@@ -1609,12 +1664,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     else rc = flat_pass(s, st, m, q, k, oi, od, oc, kind == kFilter, count_stats);
     if (rc) return rc;
     if (subset) {
-      for (size_t j = 0; j < m; ++j) {
-        const size_t g = (*subset)[j];
-        HIP_TRY(hipMemcpyAsync(d_ids + g * k, oi + j * k, k * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_dist + g * k, od + j * k, k * sizeof(float), hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_count + g, oc + j, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-      }
+      HIP_TRY(launch_scatter_results(oi, od, oc, s->dFbIdx.p, (uint32_t)m, k, d_ids, d_dist, d_count, st));
       HIP_TRY(hipEventRecord(s->ev[3], st));
     }
     // verdict
@@ -1632,8 +1682,12 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     std::vector<uint32_t> flags(m);
     HIP_TRY(hipMemcpyAsync(flags.data(), s->dUflags.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    n_short = 0;
     for (size_t j = 0; j < m; ++j)
-      if (flags[j]) unc->push_back(subset ? (*subset)[j] : (uint32_t)j);
+      if (flags[j]) {
+        unc->push_back(subset ? (*subset)[j] : (uint32_t)j);
+        n_short += flags[j] == 2u;
+      }
     return EHX_OK;
   };
 
@@ -1648,16 +1702,18 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     s->n_i8_fallback += next.size();
     // The list is too short for this data when batches keep losing queries to the next engine — which re-reads every
     // row for them, nearly a batch's worth of time however few they are (12.5 M x 1536: 13 queries in 10 batches cost
-    // 45 % of the run).  A batch that loses more than 2 % of its queries widens the list at once; otherwise every
-    // losing batch adds 4 to a score that decays by 1 per clean batch, and 8 widens (two losing batches close together).
-    if (next.empty()) s->i8_fb_score = s->i8_fb_score ? s->i8_fb_score - 1 : 0;
+    // 45 % of the run).  Only queries whose LIST was the failing part count (the re-rank flags them 2: a pool overflow,
+    // exact ties at the threshold or lost candidates are not cured by width, and a width, once raised, stays).  A batch of
+    // at least 64 queries that loses more than 2 % of them that way widens the list at once; otherwise every losing
+    // batch adds 4 to a score that decays by 1 per clean batch, and 8 widens (two losing batches close together).
+    if (n_short == 0) s->i8_fb_score = s->i8_fb_score ? s->i8_fb_score - 1 : 0;
     else s->i8_fb_score += 4;
-    if ((next.size() * 50 > nq || s->i8_fb_score >= 8) && s->i8_width < kMerged8Max) {
+    if (((nq >= 64 && n_short * 50 > nq) || s->i8_fb_score >= 8) && s->i8_width < kMerged8Max) {
       s->i8_width *= 2;
       s->i8_fb_score = 0;
       if (getenv("EHX_I8_TRACE"))
-        fprintf(stderr, "[ehx i8] %zu of %zu queries uncertified: candidate list widened to %u\n", next.size(), nq,
-                s->i8_width);
+        fprintf(stderr, "[ehx i8] %zu of %zu queries uncertified (%zu by a short list): candidate list widened to %u\n",
+                next.size(), nq, n_short, s->i8_width);
     }
     if (next.empty()) return EHX_OK;
     todo.swap(next);
@@ -2028,6 +2084,14 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
     // (measured at d = 4096: 12 of 20) and pay for a second pass, so longer rows start at the fp16 filter
     s->has8 = s->has16 && s->params.scan == EHX_SCAN_AUTO && !env_f16 && dims <= 2048 &&
               (uint64_t)s->ld8 * 10 < (uint64_t)s->ld16 * 2 * 8;
+    // the candidate list starts wider on long rows: the bound is ~1.3e-2 in dot units whatever d, the spread of the
+    // scores shrinks like 1/sqrt(d) — at d = 1536 (12.5 M rows) a fifth of the queries needed more than 256 candidates
+    // and the first batches paid a second engine's pass for them until the list had widened by itself
+    s->i8_width = dims >= 1536 ? 2 * kMerged8 : kMerged8;
+    if (const char* wd = getenv("EHX_I8_WIDTH")) {
+      const long v = atol(wd);
+      if (v == 256 || v == 512 || v == 1024) s->i8_width = (uint32_t)v;
+    }
     if (const char* mr = getenv("EHX_I8_MIN_ROWS")) s->i8_min_rows = std::max<uint64_t>(4096, strtoull(mr, nullptr, 10));
     if (s->has16) {
       HIP_TRY(hipMalloc((void**)&s->dUnsafe, sizeof(unsigned long long)));
@@ -2346,7 +2410,10 @@ static int sync_stream(ehx_space* s, hipStream_t st) {
 
 // (re)build the derived copies of rows [row0, row0+n) after they were written; must follow row_stats:
 // graph mode: the search copy; flat fp32 spaces: the fp16 scan copy
-static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n, hipStream_t st = nullptr) {
+// exclusive: no search can be reading the space (the caller holds s->mu exclusively and the writer's stream has waited
+// for the searches in flight) — rows below the published count may then move inside their tiles; otherwise every row
+// of [row0, row0 + n) lies beyond the published row count.  n_after: the row count once this write is published.
+static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n, hipStream_t st, bool exclusive, uint64_t n_after) {
   if (!st) st = s->stream;
   if (s->dXs && n)
     HIP_TRY(launch_make_search_copy(s->dX, s->x_half, s->dInv, row0, n, s->ld, s->metric, s->dXs, st));
@@ -2358,8 +2425,25 @@ static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n, hipStream_t s
     HIP_TRY(hipMemcpyAsync(&u, s->dUnsafe, sizeof(u), hipMemcpyDeviceToHost, st));
   }
   if (s->has8) {
-    HIP_TRY(launch_make_scan8(s->dX, s->x_half, row0, n, s->dims, s->ld, s->ld8, s->metric, s->dX8, s->dRowp8,
-                              s->dTilep8, s->dUnsafe8, st));
+    // Full tiles are stored ordered by quantisation step (k_misc.hip).  Re-ordering moves rows inside a tile, so it
+    // happens only where no scan can look: the fresh rows of an append (a tile that straddles the published row count
+    // keeps the row order, for good), or anywhere under an exclusive writer — which re-makes whole tiles, because a
+    // rewritten row of an ordered tile no longer sits where its id says.
+    uint64_t r8 = row0, e8 = row0 + n;
+    static const bool sort_tiles = [] {
+      const char* g = getenv("EHX_I8_SORT");
+      return g ? atoi(g) != 0 : true;
+    }();
+    if (exclusive) {
+      if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));  // searches still in flight on other streams
+      r8 = row0 & ~(uint64_t)255;
+      e8 = std::min<uint64_t>(round_up(row0 + n, 256), std::max<uint64_t>(n_after, row0 + n));
+    }
+    int rc8;
+    if ((rc8 = s->dTileList.ensure(((e8 + 255) >> 8) - (r8 >> 8) + 1))) return rc8;
+    HIP_TRY(launch_make_scan8(s->dX, s->x_half, r8, e8 - r8, s->dims, s->ld, s->ld8, s->metric, s->dX8, s->dRowp8,
+                              s->dTilep8, s->dPerm8, s->dTileg8, sort_tiles ? r8 : 0, sort_tiles ? e8 : 0,
+                              s->dTileList.p, s->dUnsafe8, st));
     HIP_TRY(hipMemcpyAsync(&u8, s->dUnsafe8, sizeof(u8), hipMemcpyDeviceToHost, st));
   }
   {
@@ -2449,7 +2533,7 @@ static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>
   // per-row statistics over the touched id range (idempotent for untouched rows in between)
   HIP_TRY(launch_row_stats(s->dX, s->x_half, min_id, max_id - min_id + 1, s->dims, s->ld, s->metric, s->dInv,
                            s->dRowp, s->dMaxSumsq, ws));
-  if ((rc = refresh_scan16(s, min_id, max_id - min_id + 1, ws))) return rc;
+  if ((rc = refresh_scan16(s, min_id, max_id - min_id + 1, ws, !append_only, next))) return rc;
   if ((rc = sync_stream(s, ws))) return rc;
   // commit: the rows are resident and described — publish the keys and the new row count
   // (the keys first, under their own lock — searches keep running — then the row count, under the space's lock for
@@ -2638,11 +2722,10 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
   std::shared_lock<std::shared_mutex> rl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   if (is_parent(s)) return sharded_knn(s, n_queries, queries, nullptr, 0, k, out_ids, out_dist, out_count, false, nullptr);
-  std::lock_guard<std::mutex> sl(s->scratch_mu);
+  std::unique_lock<std::mutex> sl(s->scratch_mu);
   HIP_TRY(hipSetDevice(s->device));
   int rc;
   const size_t qbytes = n_queries * s->dims * sizeof(float);
-  if ((rc = s->dQraw.ensure(n_queries * s->dims))) return rc;
   // A small call (the reference's request shape: one query, ten keys) is all fixed cost: its queries go through a
   // pinned staging buffer (an asynchronous copy instead of the runtime's pageable-memory path) and its three result
   // arrays come back as ONE block into pinned memory instead of three blocking copies.
@@ -2650,6 +2733,7 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
   const size_t nk = n_queries * k;
   const size_t out_bytes = nk * (sizeof(uint64_t) + sizeof(float)) + n_queries * sizeof(uint32_t);
   if (qbytes <= kSmallCall && out_bytes <= kSmallCall) {
+    if ((rc = s->dQraw.ensure(n_queries * s->dims))) return rc;
     if (!s->hSmallPin) HIP_TRY(hipHostMalloc((void**)&s->hSmallPin, 2 * kSmallCall, hipHostMallocDefault));
     if ((rc = s->dSmallOut.ensure(kSmallCall / sizeof(uint64_t)))) return rc;
     uint64_t* d_ids = s->dSmallOut.p;
@@ -2666,17 +2750,70 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
     memcpy(out_count, h + nk * (sizeof(uint64_t) + sizeof(float)), n_queries * sizeof(uint32_t));
     return EHX_OK;
   }
-  if ((rc = s->dOutIds.ensure(n_queries * k))) return rc;
-  if ((rc = s->dOutDist.ensure(n_queries * k))) return rc;
-  if ((rc = s->dOutCount.ensure(n_queries))) return rc;
-  HIP_TRY(hipMemcpyAsync(s->dQraw.p, queries, qbytes, hipMemcpyHostToDevice, s->stream));
-  if ((rc = knn_device_locked(s, s->stream, n_queries, s->dQraw.p, k, s->dOutIds.p, s->dOutDist.p,
-                              s->dOutCount.p)))
-    return rc;
-  HIP_TRY(hipMemcpyAsync(out_ids, s->dOutIds.p, n_queries * k * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipMemcpyAsync(out_dist, s->dOutDist.p, n_queries * k * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipMemcpyAsync(out_count, s->dOutCount.p, n_queries * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  // A batch: through a slot of its own (see ehx_space::HostSlot) — only the device pipeline itself is serialised.
+  sl.unlock();
+  ehx_space::HostSlot* hs = nullptr;
+  {
+    std::unique_lock<std::mutex> hl(s->hs_mu);
+    s->hs_cv.wait(hl, [&] {
+      for (auto& h : s->hslot)
+        if (!h.busy) return true;
+      return false;
+    });
+    for (auto& h : s->hslot)
+      if (!h.busy) {
+        hs = &h;
+        break;
+      }
+    hs->busy = true;
+  }
+  struct Release {
+    ehx_space* s;
+    ehx_space::HostSlot* h;
+    ~Release() {
+      {
+        std::lock_guard<std::mutex> hl(s->hs_mu);
+        h->busy = false;
+      }
+      s->hs_cv.notify_one();
+    }
+  } release{s, hs};
+  const size_t ids_b = nk * sizeof(uint64_t), dist_b = nk * sizeof(float);
+  const size_t need = qbytes + out_bytes;
+  if (!hs->st) {
+    HIP_TRY(hipStreamCreateWithFlags(&hs->st, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&hs->in_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&hs->done_ev, hipEventDisableTiming));
+  }
+  if (hs->pin_bytes < need) {
+    HIP_TRY(hipStreamSynchronize(hs->st));
+    if (hs->pin) (void)hipHostFree(hs->pin);
+    hs->pin = nullptr;
+    hs->pin_bytes = 0;
+    HIP_TRY(hipHostMalloc((void**)&hs->pin, need, hipHostMallocDefault));
+    hs->pin_bytes = need;
+  }
+  if ((rc = hs->dq.ensure(n_queries * s->dims))) return rc;
+  if ((rc = hs->dout.ensure(out_bytes))) return rc;
+  uint64_t* d_ids = (uint64_t*)hs->dout.p;
+  float* d_dist = (float*)(hs->dout.p + ids_b);
+  uint32_t* d_cnt = (uint32_t*)(hs->dout.p + ids_b + dist_b);
+  memcpy(hs->pin, queries, qbytes);
+  HIP_TRY(hipMemcpyAsync(hs->dq.p, hs->pin, qbytes, hipMemcpyHostToDevice, hs->st));
+  HIP_TRY(hipEventRecord(hs->in_ev, hs->st));
+  {
+    std::lock_guard<std::mutex> sl2(s->scratch_mu);
+    HIP_TRY(hipStreamWaitEvent(s->stream, hs->in_ev, 0));
+    if ((rc = knn_device_locked(s, s->stream, n_queries, hs->dq.p, k, d_ids, d_dist, d_cnt))) return rc;
+    HIP_TRY(hipEventRecord(hs->done_ev, s->stream));
+  }
+  char* ho = hs->pin + qbytes;
+  HIP_TRY(hipStreamWaitEvent(hs->st, hs->done_ev, 0));
+  HIP_TRY(hipMemcpyAsync(ho, hs->dout.p, out_bytes, hipMemcpyDeviceToHost, hs->st));
+  HIP_TRY(hipStreamSynchronize(hs->st));
+  memcpy(out_ids, ho, ids_b);
+  memcpy(out_dist, ho + ids_b, dist_b);
+  memcpy(out_count, ho + ids_b + dist_b, n_queries * sizeof(uint32_t));
   return EHX_OK;
 }
 
@@ -2893,7 +3030,7 @@ int fill_synthetic_locked(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n
   HIP_TRY(launch_row_stats(s->dX, s->x_half, s->n, n_rows, s->dims, s->ld, s->metric, s->dInv, s->dRowp, s->dMaxSumsq,
                            s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  if ((rc = refresh_scan16(s, s->n, n_rows))) return rc;
+  if ((rc = refresh_scan16(s, s->n, n_rows, nullptr, true, s->n + n_rows))) return rc;
   const uint64_t old_n = s->n;
   s->n += n_rows;
   if (s->params.mode == EHX_MODE_GRAPH && s->g_n == old_n && s->params.build_batch != 0xFFFFFFFFu) {

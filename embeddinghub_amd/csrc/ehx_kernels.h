@@ -544,6 +544,8 @@ struct ScanArgsI8 {
   const int8_t* X;        // scan copy, scan8_index layout; cap % 256 == 0
   const float4* rowp;     // [cap + 512] (A, B, C, D) per row; padding rows (0, +inf, 0, 0)
   const float4* tilep;    // [cap/256 + 2] (max|A|, max|C|, max|D|, min B) per 256-row tile
+  const float* tileg;     // [cap/256 + 2][16] max |A| of each 16-row lane group of the tile (g = 8 wr + 2 rb + h)
+  const uint8_t* perm;    // [cap] row index inside its tile of the row stored at each position (identity: unsorted tile)
   const float4* qparams;  // [q_tiles*256] (s_q, e_q, gamma_q, smallest threshold the query was scanned with so far)
   const float* thr;       // [q_tiles*256] score threshold of this pass per query (-inf: padding query)
   float* dump = nullptr;  // sample pass: every lower bound -> dump[row - tile0*256][q_tiles*256]
@@ -580,9 +582,17 @@ size_t scan_i8_lds_bytes();
 hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st);
 // scan copy of rows [row0, row0+n): X8 = int8(x/|x| / s_r), rowp8 = (A, B, C, D); then the tile parameters of
 // every tile touching the range.  Rows the filter cannot bound are counted in *n_unsafe.
+// Full tiles inside [sort_lo, sort_hi) are then stored ordered by quantisation step (perm8[position] = row index inside
+// the tile, tileg8[tile][16] = max |A| of each 16-row lane group: k_misc.hip, "rows of a tile ordered by quantisation
+// step"); every other touched tile keeps the row order.  The caller guarantees that no scan can read the tiles of
+// [sort_lo, sort_hi) meanwhile.  tile_list: device scratch, one entry per touched tile.
 hipError_t launch_make_scan8(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
-                             uint32_t ld8, int metric, int8_t* X8, float4* rowp8, float4* tilep8,
+                             uint32_t ld8, int metric, int8_t* X8, float4* rowp8, float4* tilep8, uint8_t* perm8,
+                             float* tileg8, uint64_t sort_lo, uint64_t sort_hi, uint64_t* tile_list,
                              unsigned long long* n_unsafe, hipStream_t st);
+hipError_t launch_tile_ids(uint64_t* out, uint64_t t0, uint64_t t1, uint64_t a0, uint64_t a1, hipStream_t st);
+// perm8 of rows [row0, row0+n): identity
+hipError_t launch_perm8_pad(uint8_t* perm8, uint64_t row0, uint64_t n, hipStream_t st);
 // rowp8 for padding rows [row0, row0+n): (0, +inf, 0, 0); tilep8 for padding tiles [t0, t0+n): never alarm
 hipError_t launch_rowp8_pad(float4* rowp8, uint64_t row0, uint64_t n, hipStream_t st);
 hipError_t launch_tilep8_pad(float4* tilep8, uint64_t t0, uint64_t n, hipStream_t st);
@@ -679,6 +689,14 @@ hipError_t launch_set_floor(const uint64_t* merged, uint32_t nq, uint64_t* floor
 // prepared queries: copy into the padded [q_rows][ld] buffer, L2-normalise for cosine
 hipError_t launch_prep_queries(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld,
                                uint32_t q_rows, int metric, float* q_out, hipStream_t st);
+
+// sub-batches of the engine chain: rows idx[0..m) of the caller's query batch gathered into a dense [m][dims] matrix,
+// and a sub-batch's results written back to the rows they belong to
+hipError_t launch_gather_queries(const float* src, const uint32_t* idx, uint32_t m, uint32_t dims, float* dst,
+                                 hipStream_t st);
+hipError_t launch_scatter_results(const uint64_t* ids, const float* dist, const uint32_t* cnt, const uint32_t* idx,
+                                  uint32_t m, uint32_t k, uint64_t* out_ids, float* out_dist, uint32_t* out_cnt,
+                                  hipStream_t st);
 
 // per-row statistics for rows [row0, row0+n): inv_norm (cosine), rowp (a,b) for the scan epilogue;
 // *max_sumsq (optional) is raised to the largest |x|^2 seen (the certification margin's norm bound)

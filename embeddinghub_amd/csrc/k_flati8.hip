@@ -117,6 +117,7 @@ struct I8Ctx {
   uint64_t* pool;        // [q_rows][pool_cap]
   uint32_t* pool_cnt;    // [q_rows]
   uint32_t* ovf;         // [q_rows]
+  const uint8_t* perm;   // [cap] position -> row index inside its tile (tiles ordered by step: k_misc.hip)
   uint32_t pool_cap;
   uint32_t n;            // valid rows
   uint32_t q_tile0;      // global index of this workgroup's query 0 (q_tile * 256)
@@ -138,7 +139,10 @@ __device__ __attribute__((noinline)) void i8_flush_staging() {
   if (n > kStgCap) n = kStgCap;
   const uint32_t cap = ctx->pool_cap;
   for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
-    const uint64_t key = keys[i];
+    uint64_t key = keys[i];
+    // the staged id is the row's POSITION in the scan copy; its tile may be stored ordered by step
+    const uint32_t posn = (uint32_t)key;
+    key = (key & 0xFFFFFFFFFFFFFF00ull) | (uint64_t)ctx->perm[posn];
     const uint32_t q = ctx->q_tile0 + (uint32_t)(w & 3) * 64u + qls[i];
     const uint32_t pos = atomicAdd(&ctx->pool_cnt[q], 1u);
     if (pos < cap) ctx->pool[(size_t)q * cap + pos] = key;
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     ctx->pool = a.pool;
     ctx->pool_cnt = a.pool_cnt;
     ctx->ovf = a.ovf;
+    ctx->perm = a.perm;
     ctx->pool_cap = a.pool_cap;
     ctx->n = a.n;
     ctx->q_tile0 = qt * kTileQ;
@@ -293,7 +298,26 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   uint32_t rp_slot = 0u;  // LDS slot (tile % 3) of the current tile's row parameters
   // tile parameters of the current tile: a scalar load issued a whole tile before its use (the epilogue must not
   // wait for a global round trip)
-  float4 tp_cur = a.tilep[tile_begin];
+  // (through the CONSTANT address space: real scalar loads, counted by lgkmcnt.  As plain global pointers they compiled
+  // to vector loads of a uniform address, and — the compiler cannot count the DMA pieces the inline asm issues — to an
+  // s_waitcnt vmcnt(0) at every tile boundary: the whole look-ahead of the ring drained once per tile, rounds 2 and 3.)
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(4))) f32x4* cf4p;
+  auto ldc = [](cf4p p, size_t i) -> float4 {
+    const f32x4 v = p[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+  };
+  auto uniform_ptr = [](const void* p) -> cf4p {  // (the address IS uniform; this tells the compiler so)
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (cf4p)(((uint64_t)hi << 32) | lo);
+  };
+  const cf4p tilep_c = uniform_ptr(a.tilep + tile_begin);
+  float4 tp_cur = ldc(tilep_c, 0);
+  // max |A| of this wave's eight 16-row lane groups (rb, h) of the current tile: uniform, loaded a tile ahead too
+  const cf4p tgp = uniform_ptr(a.tileg + (size_t)tile_begin * 16 + (size_t)wr * 8);
+  float4 tg0 = ldc(tgp, 0), tg1 = ldc(tgp, 1);
   // =============================== tile epilogue ===============================
   auto epilogue = [&](uint32_t t) {
     const uint32_t tile = tile_begin + t;
@@ -319,51 +343,40 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       return;
     }
     const float4 tp = tp_cur;  // uniform: (max|A|, max|C|, max|D|, min B) of the tile's rows (loaded a tile ago)
-    const float k0 = i8_alarm_k(tp, qq0), k1 = i8_alarm_k(tp, qq1);
+    const float k0 = i8_alarm_k(tp, qq0), k1 = i8_alarm_k(tp, qq1);  // -inf, +inf or > 0
+    const float tg[8] = {tg0.x, tg0.y, tg0.z, tg0.w, tg1.x, tg1.y, tg1.z, tg1.w};
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
-      // |A_r| of this lane's 16 rows of the row block (the same rows for both query blocks)
       const uint32_t rbase = (uint32_t)(wr * 128 + rb * 32) + 4u * h;
-      float aa[16];
-#if EHX_I8_ABL & 16
-      aa[0] = fabsf(rp[rbase].x);  // (one read per row block stands for the per-block step)
-#else
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) aa[reg] = fabsf(rp[rbase + (uint32_t)((reg & 3) + 8 * (reg >> 2))].x);
-#endif
+      // max |A_r| over this lane's 16 rows of the row block (tiles are stored ordered by |A_r|: the 16 differ by ~1 %)
+      const float gm = h ? tg[rb * 2 + 1] : tg[rb * 2];
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        // ---- phase 1: the largest I * |A_r| of the lane's 16 accumulators against the query's threshold ----
+        // ---- phase 1: can ANY of the lane's 16 accumulators belong to a candidate?  I |A_r| >= K needs
+        // max(I) max|A| >= K (K > 0: a negative I never qualifies; K = -inf: always) — an integer maximum, one
+        // convert, one multiply ----
         const i32x16 c = acc[rb][cb];
-#if EHX_I8_ABL & 16
-        {  // what an all-integer phase 1 would cost (a max3 tree and one compare; results meaningless)
-          const int i0 = max(max(c[0], c[1]), c[2]), i1 = max(max(c[3], c[4]), c[5]);
-          const int i2 = max(max(c[6], c[7]), c[8]), i3 = max(max(c[9], c[10]), c[11]);
-          const int i4 = max(max(c[12], c[13]), c[14]);
-          const int im = max(max(max(i0, i1), i2), max(max(i3, i4), c[15]));
-          if (im >= (int)((cb ? k1 : k0) * aa[0])) asm volatile("" ::: "memory");
-          continue;
-        }
-#endif
-        float p[16];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) p[reg] = (float)c[reg] * aa[reg];
-        const float m0 = fmaxf(fmaxf(p[0], p[1]), p[2]), m1 = fmaxf(fmaxf(p[3], p[4]), p[5]);
-        const float m2 = fmaxf(fmaxf(p[6], p[7]), p[8]), m3 = fmaxf(fmaxf(p[9], p[10]), p[11]);
-        const float m4 = fmaxf(fmaxf(p[12], p[13]), p[14]);
-        const float m = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), p[15]));
+        const int i0 = max(max(c[0], c[1]), c[2]), i1 = max(max(c[3], c[4]), c[5]);
+        const int i2 = max(max(c[6], c[7]), c[8]), i3 = max(max(c[9], c[10]), c[11]);
+        const int i4 = max(max(c[12], c[13]), c[14]);
+        const int im = max(max(max(i0, i1), i2), max(max(i3, i4), c[15]));
         const float kq = cb ? k1 : k0;
+        const float pm = (float)im * gm;
 #if EHX_I8_ABL & 2
-        if (m >= kq) asm volatile("" ::: "memory");  // (the comparison stays, the slow path does not)
+        if (pm >= kq) asm volatile("" ::: "memory");  // (the comparison stays, the slow path does not)
         continue;
 #endif
-        if (!__any(m >= kq)) continue;
-        // ---- phase 2: the accumulators at or above the threshold, one per lane and trip ----
+        if (!__any(pm >= kq)) continue;
+        // ---- phase 2: the accumulators at or above the threshold judged with their own row's |A_r|, one per lane
+        // and trip ----
         const float4 qq = cb ? qq1 : qq0;
         const int ql = cb * 32 + i31;
         uint32_t pend = 0u;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) pend |= (p[reg] >= kq) ? (1u << reg) : 0u;
+        for (int reg = 0; reg < 16; ++reg) {
+          const float aa = fabsf(rp[rbase + (uint32_t)((reg & 3) + 8 * (reg >> 2))].x);
+          pend |= ((float)c[reg] * aa >= kq) ? (1u << reg) : 0u;
+        }
         while (__any(pend != 0u)) {
           const bool hi = pend != 0u;
           int v = 0;
@@ -552,7 +565,9 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
       qsrc = qbase + 3 * kStageI8;
       rsrc += kTileRows16 * 16;
-      tp_cur = a.tilep[tile_begin + t + 1];  // (past the last tile: the array's padding entries)
+      tp_cur = ldc(tilep_c, t + 1);  // (past the last tile: the array's padding entries)
+      tg0 = ldc(tgp, (size_t)(t + 1) * 4);
+      tg1 = ldc(tgp, (size_t)(t + 1) * 4 + 1);
       // tile t+2 goes to the slot tile t-1 used: every wave left that epilogue long ago
       const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 2) % 3 == (t - 1) % 3
       rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
@@ -620,7 +635,9 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
         // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
         qsrc = qbase + 3 * kStageI8;
         rsrc += kTileRows16 * 16;
-        tp_cur = a.tilep[tile_begin + t];  // (past the last tile: the array's padding entries)
+        tp_cur = ldc(tilep_c, t);  // (past the last tile: the array's padding entries)
+        tg0 = ldc(tgp, (size_t)t * 4);
+        tg1 = ldc(tgp, (size_t)t * 4 + 1);
         // tile t+1 (counting the new t) goes to the slot tile t-2 used: every wave left that epilogue long ago
         const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 1) % 3 == (t - 2) % 3
         rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;

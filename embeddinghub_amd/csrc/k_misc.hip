@@ -385,8 +385,85 @@ __global__ __launch_bounds__(64) void tile_params8_kernel(const float4* __restri
   if (lane == 0) tilep8[tile] = make_float4(am, cm, dm, bm);
 }
 
+// ---- rows of a tile ordered by quantisation step (round 4) ---------------------------------------------------
+// The scan's epilogue asks, per 32 x 32 accumulator block, whether ANY accumulator can belong to a candidate:
+// I * |A_r| >= K_q.  With a per-row |A_r| that is a convert and a multiply per accumulator (40 vector instructions per
+// block: 13 % of a tile at d = 768, more than the matrix work at d = 128).  If the 16 rows a lane holds in one block
+// share (nearly) one step the test is an integer maximum and ONE product: max(I) * max|A| >= K_q.  |A_r| varies +-10 %
+// between rows, so the rows of a FULL tile are stored ordered by |A_r|: the lane's 16 rows of block (wr, rb, half h) —
+// positions base + (m & 3) + 8 (m >> 2), base = (g >> 1) 32 + (g & 1) 4, g = 8 wr + 2 rb + h — hold ranks 16 g ..
+// 16 g + 15, whose steps differ by ~1 %.  perm8[position] = the row's index inside its tile (the kernel maps a hit's
+// position back to the row id when it flushes its staging buffer); tileg8[tile][g] = max |A| of group g.  Tiles that
+// are not full when they are written (the tail of a batch, rows appended one by one) keep the identity order — their
+// group maxima are the actual maxima, looser but sound — and a tile may only be re-ordered while no scan can read it
+// (rows beyond the published row count, or a writer that holds the space exclusively).
+namespace {
+__device__ __forceinline__ uint32_t i8_group_of_pos(uint32_t p) { return ((p >> 5) << 1) | ((p >> 2) & 1u); }
+__device__ __forceinline__ uint32_t i8_pos_of_rank(uint32_t rank) {
+  const uint32_t g = rank >> 4, m = rank & 15u;
+  return (g >> 1) * 32u + (g & 1u) * 4u + (m & 3u) + 8u * (m >> 2);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void sort_tiles8_kernel(int8_t* __restrict__ X8, float4* __restrict__ rowp8,
+                                                          uint8_t* __restrict__ perm8, float* __restrict__ tileg8,
+                                                          const uint64_t* __restrict__ tiles, uint32_t ktiles) {
+  __shared__ float a_l[256];
+  __shared__ uint8_t perm_l[256];
+  __shared__ __attribute__((aligned(16))) char blk[256 * 64];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t tile = tiles[blockIdx.x];
+  const float4 P = rowp8[tile * 256 + tid];
+  const float a = fabsf(P.x);
+  a_l[tid] = a;
+  __syncthreads();
+  uint32_t rank = 0;
+  for (uint32_t j = 0; j < 256; ++j) {
+    const float b = a_l[j];
+    rank += (b < a || (b == a && j < tid)) ? 1u : 0u;
+  }
+  const uint32_t pos = i8_pos_of_rank(rank);
+  perm_l[pos] = (uint8_t)tid;
+  __syncthreads();  // (every thread holds its own P: the row parameters can be rewritten in place)
+  rowp8[tile * 256 + pos] = P;
+  perm8[tile * 256 + tid] = perm_l[tid];
+  if ((rank & 15u) == 15u) tileg8[tile * 16 + (rank >> 4)] = a;
+  // the tile's stage blocks, one at a time: position p takes the 64 bytes of row perm[p] (the 16-byte chunk swizzle
+  // of the layout depends on the row's place: scan8_index)
+  int4* g = (int4*)(X8 + (size_t)tile * ktiles * (256u * 64u));
+  for (uint32_t kt = 0; kt < ktiles; ++kt) {
+    int4* gb = g + (size_t)kt * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ((int4*)blk)[tid + 256 * j] = gb[tid + 256 * j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t e = tid + 256u * (uint32_t)j, p = e >> 2, c = e & 3u;
+      const uint32_t r = perm_l[p];
+      gb[p * 4u + (c ^ ((p >> 2) & 3u))] = ((const int4*)blk)[r * 4u + (c ^ ((r >> 2) & 3u))];
+    }
+    __syncthreads();
+  }
+}
+
+// tiles kept in row order: perm = identity, group maxima from the rows where they are
+__global__ __launch_bounds__(256) void ident_tiles8_kernel(const float4* __restrict__ rowp8, uint8_t* __restrict__ perm8,
+                                                           float* __restrict__ tileg8, const uint64_t* __restrict__ tiles) {
+  __shared__ uint32_t gm[16];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t tile = tiles[blockIdx.x];
+  if (tid < 16) gm[tid] = 0u;
+  __syncthreads();
+  const float a = fabsf(rowp8[tile * 256 + tid].x);
+  atomicMax(&gm[i8_group_of_pos(tid)], __float_as_uint(a));  // (non-negative floats order like their bit patterns)
+  perm8[tile * 256 + tid] = (uint8_t)tid;
+  __syncthreads();
+  if (tid < 16) tileg8[tile * 16 + tid] = __uint_as_float(gm[tid]);
+}
+
 hipError_t launch_make_scan8(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
-                             uint32_t ld8, int metric, int8_t* X8, float4* rowp8, float4* tilep8,
+                             uint32_t ld8, int metric, int8_t* X8, float4* rowp8, float4* tilep8, uint8_t* perm8,
+                             float* tileg8, uint64_t sort_lo, uint64_t sort_hi, uint64_t* tile_list,
                              unsigned long long* n_unsafe, hipStream_t st) {
   if (n == 0) return hipSuccess;
   const uint64_t max_rows = kMaxWorkItems / 64;  // one wave per row; a dispatch holds < 2^32 work-items
@@ -402,6 +479,47 @@ hipError_t launch_make_scan8(const void* X, int x_half, uint64_t row0, uint64_t 
   }
   const uint64_t t0 = row0 >> 8, t1 = (row0 + n + 255) >> 8;
   hipLaunchKernelGGL(tile_params8_kernel, dim3((uint32_t)(t1 - t0)), dim3(64), 0, st, rowp8, t0, tilep8);
+  // tiles wholly inside [sort_lo, sort_hi) are re-ordered by step, the others keep the row order.  tile_list (device,
+  // >= t1 - t0 entries) receives the two id lists back to back; written by iota kernels, no host copy
+  const uint64_t s0 = (sort_lo + 255) >> 8, s1 = sort_hi >> 8;   // sorted tiles: [max(t0, s0), min(t1, s1))
+  const uint64_t a0 = s0 > t0 ? s0 : t0, a1 = s1 < t1 ? s1 : t1;
+  const uint64_t n_sorted = a1 > a0 ? a1 - a0 : 0;
+  if (hipError_t e = launch_tile_ids(tile_list, t0, t1, n_sorted ? a0 : t1, n_sorted ? a1 : t1, st); e != hipSuccess) return e;
+  if (n_sorted)
+    hipLaunchKernelGGL(sort_tiles8_kernel, dim3((uint32_t)n_sorted), dim3(256), 0, st, X8, rowp8, perm8, tileg8, tile_list,
+                       ld8 >> 6);
+  const uint64_t n_ident = (t1 - t0) - n_sorted;
+  if (n_ident)
+    hipLaunchKernelGGL(ident_tiles8_kernel, dim3((uint32_t)n_ident), dim3(256), 0, st, rowp8, perm8, tileg8,
+                       tile_list + n_sorted);
+  return hipGetLastError();
+}
+
+// tile_list[0 .. a1-a0) = a0 .. a1-1 (the sorted tiles), then the tiles of [t0, t1) outside [a0, a1)
+__global__ __launch_bounds__(256) void tile_ids_kernel(uint64_t* __restrict__ out, uint64_t t0, uint64_t t1, uint64_t a0,
+                                                       uint64_t a1) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t ns = a1 - a0, total = t1 - t0;
+  if (i >= total) return;
+  if (i < ns) out[i] = a0 + i;
+  else {
+    const uint64_t j = i - ns;                  // j-th tile of [t0, a0) ++ [a1, t1)
+    out[i] = j < a0 - t0 ? t0 + j : a1 + (j - (a0 - t0));
+  }
+}
+hipError_t launch_tile_ids(uint64_t* out, uint64_t t0, uint64_t t1, uint64_t a0, uint64_t a1, hipStream_t st) {
+  if (t1 <= t0) return hipSuccess;
+  hipLaunchKernelGGL(tile_ids_kernel, dim3((uint32_t)((t1 - t0 + 255) / 256)), dim3(256), 0, st, out, t0, t1, a0, a1);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void perm8_pad_kernel(uint8_t* __restrict__ perm8, uint64_t row0, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) perm8[row0 + i] = (uint8_t)((row0 + i) & 255u);
+}
+hipError_t launch_perm8_pad(uint8_t* perm8, uint64_t row0, uint64_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(perm8_pad_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, perm8, row0, n);
   return hipGetLastError();
 }
 
@@ -646,6 +764,44 @@ hipError_t launch_gen_rows(uint64_t seed, uint64_t row0, uint64_t n_rows, uint32
     hipLaunchKernelGGL(normalize_rows_tiled_kernel, dim3((uint32_t)((n_rows + 63) / 64)), dim3(64), 0, st,
                        n_rows, dims, ld, out);
   }
+  return hipGetLastError();
+}
+
+// The queries a stage could not certify go to the next engine as a dense sub-batch: one launch gathers their raw rows
+// (idx[j] = index in the caller's batch), one launch scatters the sub-batch's results back.  (Round 3 issued one
+// hipMemcpyAsync per query for the gather and three per query for the scatter: 4756 copies for the 1189 queries a
+// 12.5 M x 1536 batch lost while its candidate list was still 256 wide.)
+__global__ void gather_queries_kernel(const float* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t dims,
+                                      float* __restrict__ dst) {
+  const float* s = src + (size_t)idx[blockIdx.x] * dims;
+  float* d = dst + (size_t)blockIdx.x * dims;
+  for (uint32_t c = threadIdx.x; c < dims; c += blockDim.x) d[c] = s[c];
+}
+
+__global__ void scatter_results_kernel(const uint64_t* __restrict__ ids, const float* __restrict__ dist,
+                                       const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ idx, uint32_t k,
+                                       uint64_t* __restrict__ out_ids, float* __restrict__ out_dist,
+                                       uint32_t* __restrict__ out_cnt) {
+  const uint32_t j = blockIdx.x, g = idx[j];
+  for (uint32_t c = threadIdx.x; c < k; c += blockDim.x) {
+    out_ids[(size_t)g * k + c] = ids[(size_t)j * k + c];
+    out_dist[(size_t)g * k + c] = dist[(size_t)j * k + c];
+  }
+  if (threadIdx.x == 0) out_cnt[g] = cnt[j];
+}
+
+hipError_t launch_gather_queries(const float* src, const uint32_t* idx, uint32_t m, uint32_t dims, float* dst,
+                                 hipStream_t st) {
+  if (m == 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_queries_kernel, dim3(m), dim3(256), 0, st, src, idx, dims, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter_results(const uint64_t* ids, const float* dist, const uint32_t* cnt, const uint32_t* idx,
+                                  uint32_t m, uint32_t k, uint64_t* out_ids, float* out_dist, uint32_t* out_cnt,
+                                  hipStream_t st) {
+  if (m == 0) return hipSuccess;
+  hipLaunchKernelGGL(scatter_results_kernel, dim3(m), dim3(64), 0, st, ids, dist, cnt, idx, k, out_ids, out_dist, out_cnt);
   return hipGetLastError();
 }
 

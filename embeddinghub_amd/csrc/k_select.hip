@@ -337,7 +337,14 @@ __device__ __forceinline__ void rerank_finish(const Rerank256Args& a, uint32_t q
   if (lane == 0) {
     a.out_count[q] = cnt;
     if (uncert) atomicAdd(a.n_uncertified, 1ull);
-    if (a.uncert_flags) a.uncert_flags[q] = uncert ? 1u : 0u;
+    if (a.uncert_flags) {
+      // 2 = the candidate LIST was what failed: it is full and its last entry — not the scan's threshold — is the floor
+      // the certificate ran into, so a wider list may certify this query (the host widens the space's list on these
+      // only: a pool overflow, lost candidates or a threshold-bound floor are not cured by width); 1 = any other cause
+      const uint64_t last = a.merged[(size_t)q * a.width + a.kprime - 1];
+      const bool by_list = last != kKeyInf && ordered_to_f32((uint32_t)(last >> 32)) <= a.qparams[q].w;
+      a.uncert_flags[q] = !uncert ? 0u : ((!a.ovf[q] && cnt >= a.k && a.k != 0 && by_list) ? 2u : 1u);
+    }
   }
 }
 

@@ -186,6 +186,19 @@ class Space:
                               cnt.ctypes.data_as(C.POINTER(C.c_uint32))))
         return ids[:, :k], dist[:, :k], cnt
 
+    def knn_into(self, queries, k, ids, dist, cnt):
+        """ehx_knn into the caller's arrays (C-contiguous: queries [nq, dims] f32, ids [nq, k] u64, dist [nq, k] f32,
+        cnt [nq] u32) — nothing is allocated or converted on the way; callable from several threads at once."""
+        nq = queries.shape[0]
+        if (queries.dtype != np.float32 or ids.dtype != np.uint64 or dist.dtype != np.float32 or cnt.dtype != np.uint32
+                or not (queries.flags.c_contiguous and ids.flags.c_contiguous and dist.flags.c_contiguous
+                        and cnt.flags.c_contiguous)
+                or queries.shape[1] != self.dims or ids.shape != (nq, k) or dist.shape != (nq, k) or cnt.shape != (nq,)):
+            raise ValueError("knn_into: arrays of the wrong dtype / shape / layout")
+        check(self._L.ehx_knn(self._h, nq, queries.ctypes.data_as(C.POINTER(C.c_float)), k,
+                              ids.ctypes.data_as(C.POINTER(C.c_uint64)), dist.ctypes.data_as(C.POINTER(C.c_float)),
+                              cnt.ctypes.data_as(C.POINTER(C.c_uint32))))
+
     def knn_keys(self, queries, k):
         """-> list (per query) of key lists, nearest first."""
         q, pq = _f32(queries)

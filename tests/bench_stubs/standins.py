@@ -21,6 +21,7 @@ class FakeSpace:
     def __init__(self, name, dims, metric=0, mode=0, initial_capacity=0, shards=0, dtype=0, build_batch=0, **kw):
         self.name, self.dims, self.metric, self.mode = name, dims, metric, mode
         self.X = np.zeros((0, dims), dtype=np.float32)
+        self.half = dtype == 1     # an fp16-row space holds its rows rounded to binary16
         self.ef, self._scan, self._st = 10, 0, self._zero()
         FakeSpace.spaces[name] = self
 
@@ -34,7 +35,10 @@ class FakeSpace:
         return {0: pyoracle.METRIC_L2, 1: pyoracle.METRIC_IP, 2: pyoracle.METRIC_COSINE}[self.metric]
 
     def fill_synthetic(self, seed, row0, n, normalize):
-        self.X = np.concatenate([self.X, pyoracle.gen_rows(seed, row0, n, self.dims, normalize=bool(normalize))])
+        rows = pyoracle.gen_rows(seed, row0, n, self.dims, normalize=bool(normalize))
+        if self.half:
+            rows = rows.astype(np.float16).astype(np.float32)
+        self.X = np.concatenate([self.X, rows])
 
     def set_batch(self, keys, X):
         self.X = np.concatenate([self.X, np.asarray(X, dtype=np.float32)])
@@ -65,6 +69,12 @@ class FakeSpace:
         self._st["bytes_algorithmic"] += 100 * Q.shape[0] * self.dims * 4
         self._st["n_i8_queries"] += Q.shape[0]
         return ids, dist, cnt
+
+    def knn_into(self, Q, k, ids, dist, cnt):
+        i, d, c = self.knn(Q, k)
+        ids[...] = i
+        dist[...] = d
+        cnt[...] = c
 
     def knn_device(self, q, k, ids, dst, cnt, stream=None):
         i, d, c = self.knn(q.numpy(), k)
@@ -192,7 +202,14 @@ def install(mp=None, real_sharded=False):
     mp.setattr(torch.cuda, "synchronize", lambda *a: None)
     mp.setattr(torch.cuda, "device_count", lambda: n_dev)
     mp.setattr(torch.cuda, "current_stream",
-               lambda *a: types.SimpleNamespace(cuda_stream=0, synchronize=lambda: None))
+               lambda *a: types.SimpleNamespace(cuda_stream=0, synchronize=lambda: None, wait_event=lambda e: None))
+    fake_stream = lambda *a, **kw: types.SimpleNamespace(wait_event=lambda e: None, cuda_stream=0,  # noqa: E731
+                                                         synchronize=lambda: None)
+    fake_event = lambda *a, **kw: types.SimpleNamespace(record=lambda *s: None)  # noqa: E731
+    import contextlib
+    mp.setattr(torch.cuda, "Stream", fake_stream)
+    mp.setattr(torch.cuda, "Event", fake_event)
+    mp.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
     no_dev = lambda f: (lambda *a, **kw: f(*a, **{k: v for k, v in kw.items() if k != "device"}))  # noqa: E731
     mp.setattr(torch, "empty", no_dev(torch.empty))
     mp.setattr(torch, "zeros", no_dev(torch.zeros))

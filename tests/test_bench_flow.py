@@ -47,7 +47,7 @@ def bench_on_stand_ins(monkeypatch):
 
 SMALL = ["--rows", "3000", "--dims", "32", "--batch", "16", "--steps", "3", "--warmup", "1", "--check-queries", "8",
          "--cpu-sample-rows", "3000", "--cpu-sample-queries", "8", "--cpu-hnsw-rows", "500", "--graph-batches", "2",
-         "--graph-efs", "10,20", "--single-query", "0", "--set-concurrent", "0"]
+         "--graph-efs", "10,20", "--config-legs", "0", "--single-query", "0", "--set-concurrent", "0"]
 
 
 def test_default_flow_prints_one_json_line_with_the_contract_fields(bench_on_stand_ins):
@@ -68,7 +68,56 @@ def test_default_flow_prints_one_json_line_with_the_contract_fields(bench_on_sta
     cs = r["graph_path_structured"]["cpu_hnsw_sample_in_run"]   # the CPU oracle's HNSW over the same rows, built in the run
     assert cs["rows"] == 600 and [p["ef"] for p in cs["recall_vs_ef"]] == [10, 20, 40, 60, 100, 200] and cs["threads"] >= 1
     assert all(p["qps_all_cores"] > 0 and 0.0 <= p["recall_at_10"] <= 1.0 for p in cs["recall_vs_ef"])
-    assert "host_pointer_path" in r and "f32_scan_engine" in r
+    assert "device_resident_queries" in r and "host_pointer_one_caller" in r and "f32_scan_engine" in r
+    assert "host pointers" in r["config"]["timed_from"] and r["exactness"]["host_pointer_path_identical"] is True
+    keys = list(r)                       # quoted tables last, the measured legs before them
+    assert keys[-1] == "cpu_hnsw_offline" and keys.index("roofline") < keys.index("cpu_baseline")
+
+
+def test_config_legs_report_three_more_shapes_with_exactness_and_roofline_before_the_cpu_tables(bench_on_stand_ins):
+    """configs[1], the configs[3] shard and the configs[4] shard (fp16 rows: the oracle must scan the
+    ROUNDED rows) are default legs, each with `exactness` (ids and distance bytes identical) and `roofline`, placed before
+    the CPU-baseline tables"""
+    monkey_argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        assert bench_on_stand_ins.module.parse().config_legs == 1      # the default itself
+    finally:
+        sys.argv = monkey_argv
+    argv = [a for a in SMALL]
+    argv[argv.index("--config-legs") + 1] = "1"
+    r = bench_on_stand_ins(argv + ["--config-legs-rows-div", "5000", "--graph-rows", "0", "--structured-rows", "0"])
+    legs = r["configs"]
+    assert list(legs) == ["configs[1]", "configs[3]", "configs[4]"]
+    for name, rows, dims in (("configs[1]", 200, 768), ("configs[3]", 1250, 128), ("configs[4]", 2500, 1536)):
+        leg = legs[name]
+        assert leg["workload"].startswith("%dx%d " % (rows, dims)) and leg["value"] > 0 and "host pointers" in leg["timed_from"]
+        assert set(("bound", "achieved", "peak", "unit", "frac", "kernel_ms")) <= set(leg["roofline"])
+        ex = leg["exactness"]
+        assert ex["ids_identical_to_oracle"] is True and ex["dist_bytes_identical_to_oracle"] is True
+        assert ex["oracle_rows"] == rows and ex["recall_at_10"] == 1.0
+    assert "rows f16" in legs["configs[4]"]["workload"]
+    keys = list(r)
+    assert keys.index("configs") < keys.index("cpu_baseline")
+
+
+def test_an_oracle_mismatch_ends_the_run(bench_on_stand_ins, monkeypatch):
+    """fail-closed: ids or distance bytes that differ from the oracle's abort the run — recall alone
+    does not decide.  Here the fp16 leg's stand-in space 'forgets' to round its rows: same ids almost everywhere, other
+    distance bytes."""
+    monkeypatch.setattr(FakeSpace, "half", False, raising=False)
+    real_init = FakeSpace.__init__
+
+    def init(self, *a, **kw):
+        real_init(self, *a, **kw)
+        self.half = False
+    monkeypatch.setattr(FakeSpace, "__init__", init)
+    argv = [a for a in SMALL]
+    argv[argv.index("--config-legs") + 1] = "1"
+    with pytest.raises(SystemExit) as e:
+        bench_on_stand_ins(argv + ["--config-legs-rows-div", "5000", "--graph-rows", "0", "--structured-rows", "0",
+                                   "--no-cpu-baseline"])
+    assert "EXACTNESS FAILURE" in str(e.value) and "f16 rows" in str(e.value)
 
 
 def test_set_concurrent_is_a_default_leg(bench_on_stand_ins):

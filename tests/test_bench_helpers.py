@@ -27,22 +27,53 @@ def _args(**kw):
 def test_oracle_truth_is_the_exhaustive_scan_and_can_be_time_boxed():
     args = _args()
     Q = pyoracle.gen_rows(20250212, 0, 6, args.dims, normalize=True)
-    ids, dist, covered = bench.oracle_truth(args, Q, 10, pyoracle.METRIC_COSINE, chunk=7_000)  # ragged last chunk
+    ids, dist, covered = bench.oracle_truth(args.rows, args.dims, Q, 10, pyoracle.METRIC_COSINE, chunk=7_000)  # ragged last chunk
     assert covered == args.rows
     X = pyoracle.gen_rows(20250211, 0, args.rows, args.dims, normalize=True)
     oids, odist, _ = pyoracle.exhaustive(X, Q, 10, pyoracle.METRIC_COSINE)
     np.testing.assert_array_equal(ids, oids.astype(np.uint64))
     assert dist.tobytes() == odist.tobytes()
     # a spent time box stops after the first chunk and says how far it got
-    _, _, part = bench.oracle_truth(args, Q, 10, pyoracle.METRIC_COSINE, chunk=7_000, max_seconds=0.0)
+    _, _, part = bench.oracle_truth(args.rows, args.dims, Q, 10, pyoracle.METRIC_COSINE, chunk=7_000, max_seconds=0.0)
     assert part == 7_000
+
+
+def test_oracle_truth_of_an_fp16_space_scans_the_rounded_rows_and_the_check_fails_closed():
+    """an fp16-row space stores the generated rows rounded to binary16 — the oracle must scan those;
+    and ANY id / distance-byte mismatch ends the run, whatever the recall"""
+    import pytest
+    rows, dims = 30_000, 64
+    Q = pyoracle.gen_rows(20250212, 0, 6, dims, normalize=True)
+    Xh = pyoracle.gen_rows(20250211, 0, rows, dims, normalize=True).astype(np.float16).astype(np.float32)
+    oids, odist, _ = pyoracle.exhaustive(Xh, Q, 10, pyoracle.METRIC_COSINE)
+    ids, dist, covered = bench.oracle_truth(rows, dims, Q, 10, pyoracle.METRIC_COSINE, f16_rows=True, chunk=8_000)
+    assert covered == rows and dist.tobytes() == odist.tobytes()
+    np.testing.assert_array_equal(ids, oids.astype(np.uint64))
+    res = bench.oracle_check(rows, dims, 10, pyoracle.METRIC_COSINE, True, Q, oids, odist, None)
+    assert res["ids_identical_to_oracle"] and res["dist_bytes_identical_to_oracle"] and res["recall_at_10"] == 1.0
+    # the answer of an engine that holds the UNROUNDED rows: same ids nearly everywhere, other bytes -> the run ends
+    X = pyoracle.gen_rows(20250211, 0, rows, dims, normalize=True)
+    wids, wdist, _ = pyoracle.exhaustive(X, Q, 10, pyoracle.METRIC_COSINE)
+    with pytest.raises(SystemExit) as e:
+        bench.oracle_check(rows, dims, 10, pyoracle.METRIC_COSINE, True, Q, wids, wdist, None)
+    assert "EXACTNESS FAILURE" in str(e.value)
+    # ... in prefix mode too (a host that only gets through the first chunk)
+    real = bench.oracle_truth
+    bench.oracle_truth = lambda *a, **kw: real(*a, **dict(kw, chunk=8_000, max_seconds=0.0))
+    try:
+        ok = bench.oracle_check(rows, dims, 10, pyoracle.METRIC_COSINE, True, Q, oids, odist, 0.0)
+        assert ok["oracle_partial"] and ok["ids_identical_to_oracle"]
+        with pytest.raises(SystemExit):
+            bench.oracle_check(rows, dims, 10, pyoracle.METRIC_COSINE, True, Q, wids, wdist, 0.0)
+    finally:
+        bench.oracle_truth = real
 
 
 def test_prefix_consistency_accepts_the_exact_answer_and_flags_wrong_ones():
     args = _args()
     Q = pyoracle.gen_rows(20250212, 0, 8, args.dims, normalize=True)
-    full_i, full_d, _ = bench.oracle_truth(args, Q, 10, pyoracle.METRIC_COSINE, chunk=10_000)
-    half_i, half_d, cov = bench.oracle_truth(args, Q, 10, pyoracle.METRIC_COSINE, rows=20_000, chunk=10_000)
+    full_i, full_d, _ = bench.oracle_truth(args.rows, args.dims, Q, 10, pyoracle.METRIC_COSINE, chunk=10_000)
+    half_i, half_d, cov = bench.oracle_truth(20_000, args.dims, Q, 10, pyoracle.METRIC_COSINE, chunk=10_000)
     ok, frac = bench.prefix_consistent(full_i, full_d, half_i, half_d, cov)
     assert ok and frac == 1.0
     # an engine that lost a prefix row which belongs to the global top-k
