@@ -262,6 +262,9 @@ struct ehx_space {
   uint32_t i8_fb_score = 0;      // recent batches that lost queries to the next engine (see knn_device_locked)
   uint32_t i8_width = kMerged8;  // width of the int8 pipeline's candidate list (doubles when batches lose queries;
                                  // create_one seeds it from the row length)
+  uint32_t i8_kprime_min = 0;    // floor of the list's logical length k' (raised when queries lose their certificate to
+                                 // a short list; flat_pass8 picks k' from the row count above it)
+  uint32_t i8_kprime_last = 0;   // the k' the last batch ran with
   bool vis_dirty = false;    // a search that clears its bitmaps with a memset BEFORE the kernel leaves them marked; the
                              // visit-log mode needs them all-zero at launch
   // GPU-side insertion state
@@ -1341,7 +1344,18 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
     const char* g = getenv("EHX_I8_KPRIME");
     return g ? atol(g) : 0L;
   }();
-  const uint32_t kprime = kprime_env >= 64 ? (uint32_t)std::min<long>(kprime_env, (long)width) : width;
+  // How many candidates a query keeps is what the scan's epilogue pays for (every key collected is a trip through its
+  // slow path, and the waves of a workgroup wait for each other at every stage: 1.25 M x 768 collected 470 keys per
+  // query, 70 % of the epilogue's tests alarmed).  The rows a query cannot exclude grow with the index (60-75 on average
+  // at 10 M x 768, far fewer at 1 M), so the list's LOGICAL length k' follows the row count — 64 below 1.5 M rows, 128
+  // below 4 M, else the full width; rows of 1024 dims and more always get the full width (the bound is ~1.3e-2 in dot
+  // units whatever d while the scores' spread shrinks like 1/sqrt(d): 18 000 x 2048 needs its 256) — and, like the
+  // width, doubles when queries lose their certificate because the list was too short (knn_device_locked).
+  uint32_t kp_auto = s->n >= 4000000 ? 256u : (s->n >= 1500000 ? 128u : 64u);
+  if (s->dims >= 1024) kp_auto = width;
+  const uint32_t kp_want = std::max(kp_auto, s->i8_kprime_min);
+  const uint32_t kprime = kprime_env >= 64 ? (uint32_t)std::min<long>(kprime_env, (long)width) : std::min(kp_want, width);
+  s->i8_kprime_last = kprime;
   const uint32_t n_tiles = (uint32_t)((s->n + kTileRows16 - 1) / kTileRows16);
   struct Pass {
     uint32_t tile0;
@@ -1377,7 +1391,7 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   // more than half of the first pass in the epilogue's slow path).
   const uint64_t first_rows = (uint64_t)passes.front().plan.n_tiles * kTileRows16;
   const uint64_t first_keys = std::min<uint64_t>(
-      2048, passes.size() == 1 ? 4ull * kprime : std::max<uint64_t>(512, 2ull * rank_after(0)));
+      2048, passes.size() == 1 ? 4ull * kprime : std::max<uint64_t>(std::min<uint64_t>(512, 4ull * kprime), 2ull * rank_after(0)));
   const uint32_t sample_rank =
       (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, first_keys * kSampleTiles * kTileRows16 / first_rows));
   const ScanPlan p = passes.back().plan;  // (q_tiles, q_rows are the same for every pass)
@@ -1487,6 +1501,12 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   r.ld = s->ld;
   r.metric = s->metric;
   HIP_TRY(launch_rerank256(r, st));
+  if (getenv("EHX_I8_COUNT")) {  // diagnosis builds (-DEHX_I8_COUNT=1): the scan's epilogue counters of this batch
+    unsigned long long c[8] = {0};
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(c, s->dCand.p, sizeof(c), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[i8 count] tests %llu alarms %llu row-block alarms %llu trips %llu (cumulative)\n", c[0], c[1], c[2], c[3]);
+  }
   if (getenv("EHX_I8_DEBUG")) {  // diagnosis only: what the uncertified queries of this batch look like
     HIP_TRY(hipStreamSynchronize(st));
     std::vector<uint32_t> fl(nq), ov(nq);
@@ -1708,12 +1728,17 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     // batch adds 4 to a score that decays by 1 per clean batch, and 8 widens (two losing batches close together).
     if (n_short == 0) s->i8_fb_score = s->i8_fb_score ? s->i8_fb_score - 1 : 0;
     else s->i8_fb_score += 4;
-    if (((nq >= 64 && n_short * 50 > nq) || s->i8_fb_score >= 8) && s->i8_width < kMerged8Max) {
-      s->i8_width *= 2;
+    if (((nq >= 64 && n_short * 50 > nq) || s->i8_fb_score >= 8) &&
+        (s->i8_width < kMerged8Max || s->i8_kprime_last < s->i8_width)) {
+      if (s->i8_kprime_last < s->i8_width) s->i8_kprime_min = std::min(s->i8_width, 2 * s->i8_kprime_last);  // k' first
+      else {
+        s->i8_width *= 2;
+        s->i8_kprime_min = s->i8_width;
+      }
       s->i8_fb_score = 0;
       if (getenv("EHX_I8_TRACE"))
-        fprintf(stderr, "[ehx i8] %zu of %zu queries uncertified (%zu by a short list): candidate list widened to %u\n",
-                next.size(), nq, n_short, s->i8_width);
+        fprintf(stderr, "[ehx i8] %zu of %zu queries uncertified (%zu by a short list): candidate list now %u of %u\n",
+                next.size(), nq, n_short, std::max(s->i8_kprime_min, s->i8_kprime_last), s->i8_width);
     }
     if (next.empty()) return EHX_OK;
     todo.swap(next);
@@ -2440,10 +2465,14 @@ static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n, hipStream_t s
       e8 = std::min<uint64_t>(round_up(row0 + n, 256), std::max<uint64_t>(n_after, row0 + n));
     }
     int rc8;
-    if ((rc8 = s->dTileList.ensure(((e8 + 255) >> 8) - (r8 >> 8) + 1))) return rc8;
+    const uint64_t slo = sort_tiles ? r8 : 0, shi = sort_tiles ? e8 : 0;
+    if ((rc8 = s->dTileList.ensure((make_scan8_scratch_bytes(r8, e8 - r8, slo, shi) + 7) / 8))) return rc8;
     HIP_TRY(launch_make_scan8(s->dX, s->x_half, r8, e8 - r8, s->dims, s->ld, s->ld8, s->metric, s->dX8, s->dRowp8,
-                              s->dTilep8, s->dPerm8, s->dTileg8, sort_tiles ? r8 : 0, sort_tiles ? e8 : 0,
-                              s->dTileList.p, s->dUnsafe8, st));
+                              s->dTilep8, s->dPerm8, s->dTileg8, slo, shi, s->dTileList.p, s->dUnsafe8, st));
+    if (s->dTileList.n > (64u << 20) / 8) {  // (a bulk load's scratch — 9 bytes per row — is not kept)
+      HIP_TRY(hipStreamSynchronize(st));
+      s->dTileList.release();
+    }
     HIP_TRY(hipMemcpyAsync(&u8, s->dUnsafe8, sizeof(u8), hipMemcpyDeviceToHost, st));
   }
   {
@@ -2722,7 +2751,6 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
   std::shared_lock<std::shared_mutex> rl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   if (is_parent(s)) return sharded_knn(s, n_queries, queries, nullptr, 0, k, out_ids, out_dist, out_count, false, nullptr);
-  std::unique_lock<std::mutex> sl(s->scratch_mu);
   HIP_TRY(hipSetDevice(s->device));
   int rc;
   const size_t qbytes = n_queries * s->dims * sizeof(float);
@@ -2733,6 +2761,7 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
   const size_t nk = n_queries * k;
   const size_t out_bytes = nk * (sizeof(uint64_t) + sizeof(float)) + n_queries * sizeof(uint32_t);
   if (qbytes <= kSmallCall && out_bytes <= kSmallCall) {
+    std::lock_guard<std::mutex> sl(s->scratch_mu);
     if ((rc = s->dQraw.ensure(n_queries * s->dims))) return rc;
     if (!s->hSmallPin) HIP_TRY(hipHostMalloc((void**)&s->hSmallPin, 2 * kSmallCall, hipHostMallocDefault));
     if ((rc = s->dSmallOut.ensure(kSmallCall / sizeof(uint64_t)))) return rc;
@@ -2750,8 +2779,9 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
     memcpy(out_count, h + nk * (sizeof(uint64_t) + sizeof(float)), n_queries * sizeof(uint32_t));
     return EHX_OK;
   }
-  // A batch: through a slot of its own (see ehx_space::HostSlot) — only the device pipeline itself is serialised.
-  sl.unlock();
+  // A batch: through a slot of its own (see ehx_space::HostSlot) — only the device pipeline itself is serialised (the
+  // pipeline's lock is NOT held while the queries are staged: the first version took it on entry and two callers ran
+  // strictly one after the other).
   ehx_space::HostSlot* hs = nullptr;
   {
     std::unique_lock<std::mutex> hl(s->hs_mu);

@@ -47,7 +47,6 @@
 
 namespace ehx {
 
-typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -61,7 +60,8 @@ constexpr uint32_t kQOffI8 = kRingI8 * kStageI8;                   // 64 KiB
 constexpr uint32_t kStgCap = 128;                                  // staging entries per wave
 constexpr uint32_t kRowpOffI8 = 2 * kRingI8 * kStageI8;            // float4 rowp_lds[3][256]
 constexpr uint32_t kQpOffI8 = kRowpOffI8 + 3 * kTileRows16 * 16;   // float4 qp_lds[256] = (s_q, e_q, gamma_q, thr_q)
-constexpr uint32_t kSyncOffI8 = kQpOffI8 + kTileQ * 16;            // u32 snapshot[64] of the lock-step counter
+constexpr uint32_t kQinvOffI8 = kQpOffI8 + kTileQ * 16;            // float qinv_lds[256] = (1 - 1e-5) / s_q
+constexpr uint32_t kSyncOffI8 = kQinvOffI8 + kTileQ * 4;           // u32 snapshot[64] of the lock-step counter
 constexpr uint32_t kCtxOffI8 = kSyncOffI8 + 256;                   // I8Ctx: what the (rare) flush path needs
 constexpr uint32_t kStgKeyOffI8 = kCtxOffI8 + 64;                  // u64 stg_key[8][128]
 constexpr uint32_t kStgQlOffI8 = kStgKeyOffI8 + 8 * kStgCap * 8;   // u32 stg_ql[8][128]
@@ -70,14 +70,24 @@ constexpr uint32_t kLdsBytesI8 = kStgCntOffI8 + 64;
 static_assert(kLdsBytesI8 <= 160 * 1024, "LDS budget");
 static_assert(kTileRows16 == 256 && kTileQ == 256, "kernel geometry is hard-wired");
 
-#define EHX_MFMA_I8(A, B, C) __builtin_amdgcn_mfma_i32_32x32x32_i8((A), (B), (C), 0, 0, 0)
+#define EHX_MFMA_I8(A, B, C) __builtin_amdgcn_mfma_i32_16x16x64_i8((A), (B), (C), 0, 0, 0)
 
 // Ablation builds (scripts/ablate_i8.sh; results are WRONG by construction, only the scan's duration is looked at):
 //   1  no tile epilogue      2  epilogue phase 1 only (alarms never taken)      4  no DMA after the prologue (the ring
 //   keeps its first three stages; no counted wait)      8  no fragment reads (MFMAs on the prologue's fragments)
-//   16 an all-integer phase 1 (what rows ordered by step inside a tile would allow), alarms never taken
+//   16 no stage barrier
 #ifndef EHX_I8_ABL
 #define EHX_I8_ABL 0
+#endif
+// EHX_I8_COUNT: diagnosis build — a.cand[0..4] count (phase-1 tests, alarms, alarmed row blocks, phase-2 trips, staged
+// keys) per launch sequence (never in the shipped library)
+#ifndef EHX_I8_COUNT
+#define EHX_I8_COUNT 0
+#endif
+#if EHX_I8_COUNT
+#define EHX_CNT(I) do { if (lane == 0) atomicAdd((unsigned long long*)a.cand + (I), 1ull); } while (0)
+#else
+#define EHX_CNT(I) do { } while (0)
 #endif
 
 __device__ __forceinline__ void lds_barrier_i8() {
@@ -103,13 +113,12 @@ __device__ __forceinline__ float i8_score(const float4 P, const float4 qq, int v
 // per block (tests/test_i8_model.py reproduces the rates).  Per row the test costs a convert and a multiply per
 // accumulator and 18-50 % of the blocks go on (scripts/studies/int8_alarm_rates.py).  K errs towards alarms
 // (relative slack); -inf = always, +inf = never.
-__device__ __forceinline__ float i8_alarm_k(const float4 tp, const float4 qq) {
+__device__ __forceinline__ float i8_alarm_k(const float4 tp, const float4 qq, const float qinv) {
   const float bg = tp.w * qq.z, ce = tp.y * qq.y;
   float num = bg - tp.z - ce - qq.w;
   num -= 1e-5f * (fabsf(bg) + tp.z + ce + fabsf(qq.w));
   if (!(num > 0.0f)) return -__builtin_inff();              // thr = +inf, NaN, or the bound is already below thr
-  if (!(qq.x > 0.0f)) return __builtin_inff();              // the query's step is 0: S_lower does not depend on I
-  return num / qq.x * (1.0f - 1e-5f);
+  return num * qinv;   // qinv = (1 - 1e-5) / s_q, or +inf when the query's step is 0 (S_lower does not depend on I)
 }
 
 // What the flush path needs lives in LDS (written once per workgroup): the out-of-line flush takes no arguments.
@@ -154,33 +163,35 @@ __device__ __attribute__((noinline)) void i8_flush_staging() {
 }
 
 // phase 2 of the epilogue for one accumulator value per lane: lanes with `hi` evaluate their row's exact lower
-// bound and stage it when it does not exceed the query's threshold (qq.w).  LDS traffic only (see the header).
+// bound and stage it when it does not exceed the query's threshold (qq.w).  LDS traffic only (see the header), and ONE
+// LDS round trip (the row's parameters): the staging buffer belongs to this wave alone, so its fill count lives in a
+// wave-uniform register (stg_n) and the slots are handed out by a ballot and a lane prefix count — round 3 took them
+// with an LDS atomic per key and waited for its return.
 __device__ __forceinline__ void i8_hit(int v, bool hi, uint32_t r_local, uint32_t tile_row0, uint32_t rp_off,
-                                       const float4 qq, int ql, int w, uint32_t n_rows) {
+                                       const float4 qq, int ql, int w, uint32_t n_rows, uint32_t& stg_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const float4 P = *(const float4*)(smem + rp_off + r_local * 16u);
   const float S = i8_score(P, qq, v);
   const uint32_t grow = tile_row0 + r_local;
-  bool ok = hi && (S <= qq.w) && grow < n_rows;
-  if (!__any(ok)) return;
-  const uint64_t key = ((uint64_t)f32_to_ordered(S) << 32) | grow;
-  uint64_t* keys = (uint64_t*)(smem + kStgKeyOffI8) + (size_t)w * kStgCap;
-  uint32_t* qls = (uint32_t*)(smem + kStgQlOffI8) + (size_t)w * kStgCap;
+  const bool ok = hi && (S <= qq.w) && grow < n_rows;
+  const uint64_t m = __ballot(ok);
+  if (m == 0ull) return;
+  const uint32_t k = (uint32_t)__builtin_popcountll(m);
   uint32_t* cnt = (uint32_t*)(smem + kStgCntOffI8) + w;
-  for (int round = 0; round < 8 && __any(ok); ++round) {  // (64 lanes, 128 entries: a flushed buffer takes them all)
-    bool full = false;
-    if (ok) {
-      const uint32_t pos = atomicAdd(cnt, 1u);
-      if (pos < kStgCap) {
-        keys[pos] = key;
-        qls[pos] = (uint32_t)ql;
-        ok = false;
-      } else {
-        full = true;
-      }
-    }
-    if (__any(full)) i8_flush_staging();
+  if (stg_n + k > kStgCap) {  // (64 lanes, 128 entries: an emptied buffer takes them all)
+    if ((threadIdx.x & 63) == 0) *cnt = stg_n;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    i8_flush_staging();
+    stg_n = 0u;
   }
+  if (ok) {
+    const uint32_t pos = stg_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    uint64_t* keys = (uint64_t*)(smem + kStgKeyOffI8) + (size_t)w * kStgCap;
+    uint32_t* qls = (uint32_t*)(smem + kStgQlOffI8) + (size_t)w * kStgCap;
+    keys[pos] = ((uint64_t)f32_to_ordered(S) << 32) | grow;
+    qls[pos] = (uint32_t)ql;
+  }
+  stg_n += k;
 }
 
 }  // namespace
@@ -189,6 +200,14 @@ size_t scan_i8_lds_bytes() { return kLdsBytesI8; }
 
 // DUMP: the sample pass — every lower bound of the scanned tiles is written to a.dump[row - tile0*256][q] and
 // sample_select256_kernel turns them into the first thresholds.
+//
+// Round 4: the matrix instruction is v_mfma_i32_16x16x64_i8.  Same rate on paper as 32x32x32, but measured on this part
+// (scripts/ubench/i8_mfma_shapes.hip, profiles/r04_a_i8_mfma_shapes_ubench.txt; register-resident operands, two waves
+// per SIMD): 4200-4280 TOP/s at 2.10-2.17 GHz against 3400-3680 at 1.69-1.88 GHz — the 32x32x32 stream is what makes
+// the part clock down.  Wave tile unchanged (128 rows x 64 queries): 8 x 4 blocks of 16 x 16, four accumulator
+// registers each; a stage row's 64 bytes are ONE k-step: lane l holds bytes [16 (l >> 4), +16) of row / query l & 15 of
+// its block — one ds_read_b128 per block and stage, twelve per stage as before.  Every block gets exactly one MFMA
+// per stage.  An accumulator block holds, per lane, rows 4 (l >> 4) + 0..3 of its 16 rows for query l & 15.
 template <bool DUMP, bool REV>
 __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanArgsI8 a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 2, wc = w & 3;
-  const int h = lane >> 5, i31 = lane & 31;
+  const int j15 = lane & 15, qd = lane >> 4;
 
   uint32_t qt, chunk;
   {
@@ -209,8 +228,13 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       qt = b % a.q_tiles;
       chunk = b / a.q_tiles;
     }
+    // (a division by a run-time value goes through the vector ALU: without this the tile range, the loop bound and the
+    // DMA sources derived from it would live in vector registers — and, this kernel being out of them, in scratch)
+    qt = (uint32_t)__builtin_amdgcn_readfirstlane((int)qt);
+    chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
   }
   float4* qp_lds = (float4*)(smem + kQpOffI8);
+  float* qinv_lds = (float*)(smem + kQinvOffI8);
   const volatile uint32_t* sync_lds = (const volatile uint32_t*)(smem + kSyncOffI8);
 
   if (tid < (int)kTileQ) {  // query parameters and this pass's threshold, once per workgroup
@@ -218,6 +242,9 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     float4 qp = a.qparams[qg];
     qp.w = a.thr ? a.thr[qg] : __builtin_inff();
     qp_lds[tid] = qp;
+    // 1 / s_q, erring low (the alarm threshold K = num * this must err towards alarms); +inf: the query's step is 0,
+    // S_lower does not depend on I and nothing can alarm
+    qinv_lds[tid] = qp.x > 0.0f ? (1.0f - 1e-5f) / qp.x : __builtin_inff();
   }
   if (tid < 64) ((uint32_t*)(smem + kSyncOffI8))[tid] = 0u;
   if (tid < 8) ((uint32_t*)(smem + kStgCntOffI8))[tid] = 0u;
@@ -260,8 +287,8 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
                  : "s"(DST_BASE), "n"(DST_IMM), "v"(VOFF), "s"(SRC)                                        \
                  : "memory", "scc");                                                                       \
   } while (0)
-  // (the ring slot of a stage is a run-time value since round 3 — a tile may be any number of stages long — so the
-  // LDS destination comes in a scalar register)
+  // (the ring slot of a stage is a run-time value in the second loop — a tile may be any number of stages long — so
+  // the LDS destination comes in a scalar register)
 #define EHX_DMA_RT(DST, VOFF, SRC)                                                       \
   do {                                                                                   \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"         \
@@ -279,23 +306,28 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     qsrc += kStageI8;                                  \
   } while (0)
 
-  // ---- fragment read offsets: k-step j (0/1) of a stage row is its logical 16-byte chunks 2j (lanes 0-31) and
-  // 2j+1 (lanes 32-63); any fixed permutation of k is fine as long as rows and queries use the same one
-  const uint32_t sw = ((uint32_t)i31 >> 2) & 3u;
-  const uint32_t a_off0 = kXOffI8 + (uint32_t)(wr * 128 + i31) * kRowBI8 + (((uint32_t)h) ^ sw) * 16u;       // + rb*2048
-  const uint32_t a_off1 = kXOffI8 + (uint32_t)(wr * 128 + i31) * kRowBI8 + ((2u + (uint32_t)h) ^ sw) * 16u;
-  const uint32_t b_off0 = kQOffI8 + (uint32_t)(wc * 64 + i31) * kRowBI8 + (((uint32_t)h) ^ sw) * 16u;        // + cb*2048
-  const uint32_t b_off1 = kQOffI8 + (uint32_t)(wc * 64 + i31) * kRowBI8 + ((2u + (uint32_t)h) ^ sw) * 16u;
+  // ---- fragment read offsets: lane l reads the 16-byte chunk (l >> 4) of row / query (l & 15) of its block (any fixed
+  // assignment of k to lanes is fine as long as rows and queries use the same one); the chunk's physical place is
+  // swizzled by the row (scan8_swz) so that the four 16-lane groups a ds_read_b128 is served in hit 16 different slots
+  const uint32_t sw = scan8_swz((uint32_t)j15);
+  uint32_t a_off = kXOffI8 + (uint32_t)(wr * 128 + j15) * kRowBI8 + (((uint32_t)qd) ^ sw) * 16u;  // + rb*1024
+  uint32_t b_off = kQOffI8 + (uint32_t)(wc * 64 + j15) * kRowBI8 + (((uint32_t)qd) ^ sw) * 16u;   // + cb*1024
+  // (opaque to the compiler: it would fold kQOffI8 = 64 KiB into every read's constant, find that the sum no longer
+  // fits the instruction's 16-bit offset field, and keep one address register per (ring slot, block) — 24 registers
+  // spilled to scratch, whose reloads sit in the stage loop behind s_waitcnt vmcnt(0).  As two opaque bases every
+  // read is base + immediate.)
+  asm volatile("" : "+v"(a_off), "+v"(b_off));
 
-  i32x16 acc[4][2];
+  i32x4 acc[8][4];
 #pragma unroll
-  for (int rb = 0; rb < 4; ++rb)
+  for (int rb = 0; rb < 8; ++rb)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0;
+      for (int r = 0; r < 4; ++r) acc[rb][cb][r] = 0;
 
   uint32_t rp_slot = 0u;  // LDS slot (tile % 3) of the current tile's row parameters
+  uint32_t stg_n = 0u;    // keys in this wave's staging buffer (wave-uniform; the buffer is the wave's own)
   // tile parameters of the current tile: a scalar load issued a whole tile before its use (the epilogue must not
   // wait for a global round trip)
   // (through the CONSTANT address space: real scalar loads, counted by lgkmcnt.  As plain global pointers they compiled
@@ -315,81 +347,108 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   };
   const cf4p tilep_c = uniform_ptr(a.tilep + tile_begin);
   float4 tp_cur = ldc(tilep_c, 0);
-  // max |A| of this wave's eight 16-row lane groups (rb, h) of the current tile: uniform, loaded a tile ahead too
-  const cf4p tgp = uniform_ptr(a.tileg + (size_t)tile_begin * 16 + (size_t)wr * 8);
-  float4 tg0 = ldc(tgp, 0), tg1 = ldc(tgp, 1);
+  // max |A| of this wave's four 32-row lane groups (one per l >> 4) of the current tile: uniform, loaded a tile ahead
+  const cf4p tgp = uniform_ptr(a.tileg + (size_t)tile_begin * 16 + (size_t)wr * 4);
+  float4 tg_cur = ldc(tgp, 0);
   // =============================== tile epilogue ===============================
   auto epilogue = [&](uint32_t t) {
     const uint32_t tile = tile_begin + t;
     const uint32_t tile_row0 = tile * kTileRows16;
     const uint32_t rp_off = kRowpOffI8 + rp_slot * 4096u;  // this tile's row parameters in LDS
     const float4* rp = (const float4*)(smem + rp_off);
-    const int col = wc * 64 + i31;
-    const float4 qq0 = qp_lds[col], qq1 = qp_lds[col + 32];
+    // (the lane's coordinates are derived afresh, behind an opaque copy of the lane id: left to itself the compiler
+    // keeps a dozen epilogue addresses alive across the stage loop, which has no registers to spare)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int j15 = lane_e & 15, qd = lane_e >> 4;
+    const int col0 = wc * 64 + j15;                          // + 16 cb: this lane's four queries
+    const uint32_t rbase = (uint32_t)(wr * 128) + 4u * (uint32_t)qd;  // + 16 rb + r: this lane's 32 rows
     if (DUMP) {
-      const size_t qcol = (size_t)qt * kTileQ + col;
       const size_t q_rows = (size_t)a.q_tiles * kTileQ;
+      float* const o0 = a.dump + (size_t)(tile_row0 - a.tile0 * kTileRows16 + rbase) * q_rows + (size_t)qt * kTileQ + col0;
+      const float4 q0 = qp_lds[col0], q1 = qp_lds[col0 + 16], q2 = qp_lds[col0 + 32], q3 = qp_lds[col0 + 48];
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
+      for (int rb = 0; rb < 8; ++rb) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const uint32_t r = (uint32_t)(wr * 128 + rb * 32 + (reg & 3) + 8 * (reg >> 2)) + 4u * h;
-          const float4 P = rp[r];
-          float* o = a.dump + (size_t)(tile_row0 - a.tile0 * kTileRows16 + r) * q_rows + qcol;
-          o[0] = i8_score(P, qq0, acc[rb][0][reg]);
-          o[32] = i8_score(P, qq1, acc[rb][1][reg]);
+        for (int r = 0; r < 4; ++r) {
+          const float4 P = rp[rbase + 16u * (uint32_t)rb + (uint32_t)r];
+          float* o = o0 + (size_t)(16 * rb + r) * q_rows;
+          o[0] = i8_score(P, q0, acc[rb][0][r]);
+          o[16] = i8_score(P, q1, acc[rb][1][r]);
+          o[32] = i8_score(P, q2, acc[rb][2][r]);
+          o[48] = i8_score(P, q3, acc[rb][3][r]);
+          asm volatile("" ::: "memory");  // (one row at a time: 32 rows of parameters held at once spill)
         }
       }
       return;
     }
     const float4 tp = tp_cur;  // uniform: (max|A|, max|C|, max|D|, min B) of the tile's rows (loaded a tile ago)
-    const float k0 = i8_alarm_k(tp, qq0), k1 = i8_alarm_k(tp, qq1);  // -inf, +inf or > 0
-    const float tg[8] = {tg0.x, tg0.y, tg0.z, tg0.w, tg1.x, tg1.y, tg1.z, tg1.w};
+    // max |A_r| over this lane's 32 rows (tiles are stored ordered by |A_r|: the 32 differ by a few per cent)
+    const float4 tg = tg_cur;
+    const float gm = qd == 0 ? tg.x : (qd == 1 ? tg.y : (qd == 2 ? tg.z : tg.w));
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      const uint32_t rbase = (uint32_t)(wr * 128 + rb * 32) + 4u * h;
-      // max |A_r| over this lane's 16 rows of the row block (tiles are stored ordered by |A_r|: the 16 differ by ~1 %)
-      const float gm = h ? tg[rb * 2 + 1] : tg[rb * 2];
+    for (int cb = 0; cb < 4; ++cb) {
+      // ---- phase 1: can ANY of the lane's 32 accumulators of this query belong to a candidate?  I |A_r| >= K needs
+      // max(I) max|A| >= K (K > 0: a negative I never qualifies; K = -inf: always) — an integer maximum, one convert,
+      // one multiply ----
+      const float4 qq = qp_lds[col0 + 16 * cb];
+      const float kq = i8_alarm_k(tp, qq, qinv_lds[col0 + 16 * cb]);  // -inf, +inf or > 0
+      int m8[8];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        // ---- phase 1: can ANY of the lane's 16 accumulators belong to a candidate?  I |A_r| >= K needs
-        // max(I) max|A| >= K (K > 0: a negative I never qualifies; K = -inf: always) — an integer maximum, one
-        // convert, one multiply ----
-        const i32x16 c = acc[rb][cb];
-        const int i0 = max(max(c[0], c[1]), c[2]), i1 = max(max(c[3], c[4]), c[5]);
-        const int i2 = max(max(c[6], c[7]), c[8]), i3 = max(max(c[9], c[10]), c[11]);
-        const int i4 = max(max(c[12], c[13]), c[14]);
-        const int im = max(max(max(i0, i1), i2), max(max(i3, i4), c[15]));
-        const float kq = cb ? k1 : k0;
-        const float pm = (float)im * gm;
+      for (int rb = 0; rb < 8; ++rb) {
+        const i32x4 c = acc[rb][cb];
+        m8[rb] = max(max(c[0], c[1]), max(c[2], c[3]));
+      }
+      const int im = max(max(max(m8[0], m8[1]), max(m8[2], m8[3])), max(max(m8[4], m8[5]), max(m8[6], m8[7])));
+      const float pm = (float)im * gm;
 #if EHX_I8_ABL & 2
-        if (pm >= kq) asm volatile("" ::: "memory");  // (the comparison stays, the slow path does not)
-        continue;
+      if (pm >= kq) asm volatile("" ::: "memory");  // (the comparison stays, the slow path does not)
+      continue;
 #endif
-        if (!__any(pm >= kq)) continue;
-        // ---- phase 2: the accumulators at or above the threshold judged with their own row's |A_r|, one per lane
-        // and trip ----
-        const float4 qq = cb ? qq1 : qq0;
-        const int ql = cb * 32 + i31;
-        uint32_t pend = 0u;
+      EHX_CNT(0);
+      if (!__any(pm >= kq)) continue;
+      EHX_CNT(1);
+      // ---- phase 2: which accumulators?  First the row blocks whose own maximum reaches the threshold (the eight
+      // per-block maxima are at hand), then their four accumulators against the same level — in a tile ordered by step
+      // every row of the lane's group has |A_r| = gm, so this IS the row's own test (a tile in row order: a superset;
+      // the hit path judges every key by its exact lower bound anyway).  A 32-bit mask per lane (bit 4 rb + r), then one
+      // set bit per lane and trip. ----
+      const int ql = cb * 16 + j15;
+      uint32_t pend = 0u;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const float aa = fabsf(rp[rbase + (uint32_t)((reg & 3) + 8 * (reg >> 2))].x);
-          pend |= ((float)c[reg] * aa >= kq) ? (1u << reg) : 0u;
+      for (int rb = 7; rb >= 0; --rb) {  // (nibble by nibble: the bit constants stay inline operands)
+        uint32_t nib = 0u;
+        if (__any((float)m8[rb] * gm >= kq)) {
+          EHX_CNT(2);
+          const i32x4 c = acc[rb][cb];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) nib |= ((float)c[r] * gm >= kq) ? (1u << r) : 0u;
         }
-        while (__any(pend != 0u)) {
-          const bool hi = pend != 0u;
-          int v = 0;
-          uint32_t r_local = rbase;
-          if (hi) {
-            const int b = __builtin_ctz(pend);
-            pend &= pend - 1u;
+        pend = (pend << 4) | nib;
+      }
+      while (__any(pend != 0u)) {
+        EHX_CNT(3);
+        const bool hi = pend != 0u;
+        int v = 0;
+        uint32_t r_local = rbase;
+        if (hi) {
+          const int b = __builtin_ctz(pend);
+          pend &= pend - 1u;
+          i32x4 c4 = acc[0][cb];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v = (b == i) ? c[i] : v;
-            r_local = rbase + (uint32_t)((b & 3) + 8 * (b >> 2));
+          for (int rb = 1; rb < 8; ++rb) {
+            const bool pick = (b >> 2) == rb;
+            const i32x4 o = acc[rb][cb];
+            c4[0] = pick ? o[0] : c4[0];
+            c4[1] = pick ? o[1] : c4[1];
+            c4[2] = pick ? o[2] : c4[2];
+            c4[3] = pick ? o[3] : c4[3];
           }
-          i8_hit(v, hi, r_local, tile_row0, rp_off, qq, ql, w, a.n);
+          const int r = b & 3;
+          v = r == 0 ? c4[0] : (r == 1 ? c4[1] : (r == 2 ? c4[2] : c4[3]));
+          r_local = rbase + 16u * (uint32_t)(b >> 2) + (uint32_t)r;
         }
+        i8_hit(v, hi, r_local, tile_row0, rp_off, qq, ql, w, a.n, stg_n);
       }
     }
   };
@@ -416,25 +475,32 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 #define EHX_SDMA(DST, VOFF, SRC) EHX_DMA_RT(DST, VOFF, SRC)
 #endif
 
-  // Fragments are double-buffered: set 0 feeds k-step 0, set 1 feeds k-step 1; the six fragment reads of
-  // the next k-step are issued ahead of the current k-step's 8 MFMAs and land in their shadow.
-  i32x4 fa0[4], fb0[2], fa1[4], fb1[2];
+  // Fragments.  The eight row-block fragments of a stage are single-buffered: block rb's fragment is dead after its
+  // four MFMAs and is re-read for the NEXT stage in place; the four query-block fragments feed every row block and
+  // are double-buffered (fb0 / fb1 swap roles every stage).  All twelve reads of the next stage are issued in the
+  // second half of a stage, after its barrier has made the next stage visible.
+  i32x4 fa[8], fb0[4], fb1[4];
 #pragma unroll
-  for (int rb = 0; rb < 4; ++rb) fa0[rb] = *(const i32x4*)(smem + a_off0 + rb * 2048);
+  for (int rb = 0; rb < 8; ++rb) fa[rb] = *(const i32x4*)(smem + a_off + rb * 1024);
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) fb0[cb] = *(const i32x4*)(smem + b_off0 + cb * 2048);
+  for (int cb = 0; cb < 4; ++cb) fb0[cb] = *(const i32x4*)(smem + b_off + cb * 1024);
 
 #if EHX_I8_ABL & 8
-#define EHX_FR(P) fa0[0]
+#define EHX_FR(P) fa[0]
 #else
 #define EHX_FR(P) (*(const i32x4*)(P))
 #endif
-#define EHX_MF(A, B, RB, CB) acc[RB][CB] = EHX_MFMA_I8(A[RB], B[CB], acc[RB][CB])
-  // the first k-step of a tile starts its accumulators from the constant 0 (an inline operand of the MFMA) instead of
-  // 128 v_mov per wave after every epilogue — 4 % of a tile's issue slots at d = 768, a quarter at d = 128
-  const i32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define EHX_MFZ(A, B, RB, CB) acc[RB][CB] = EHX_MFMA_I8(A[RB], B[CB], zero16)
+#define EHX_MF(B, RB, CB) acc[RB][CB] = EHX_MFMA_I8(fa[RB], B[CB], acc[RB][CB])
+  // the first (for this shape: only the first) MFMA of a block in a tile's first stage starts from the constant 0 (an
+  // inline operand) instead of 128 v_mov per wave after every epilogue
+  const i32x4 zero4 = {0, 0, 0, 0};
+#define EHX_MFZ(B, RB, CB) acc[RB][CB] = EHX_MFMA_I8(fa[RB], B[CB], zero4)
 #define EHX_SB() __builtin_amdgcn_sched_barrier(0)
+#if EHX_I8_ABL & 16
+#define EHX_STAGE_BARRIER() do { } while (0)
+#else
+#define EHX_STAGE_BARRIER() lds_barrier_i8()
+#endif
 #if EHX_I8_ABL & 4
 #define EHX_SDMA_X0(S) do { } while (0)
 #define EHX_SDMA_Q0(S) do { } while (0)
@@ -446,75 +512,66 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 #define EHX_SDMA_X1(S) EHX_DMA_X1(S)
 #define EHX_SDMA_Q1(S) EHX_DMA_Q1(S)
 #endif
-  // One stage, ring slot S (compile-time): no branches, no address arithmetic; every gap between two MFMAs carries
-  // exactly one other instruction of this wave (a fragment read or a DMA piece).
-#define EHX_STAGE_I8_CT(S, M0)                                                                                 \
+  // One stage = 32 MFMAs, every accumulator block once.  First half: row blocks 0-3 (fragments loaded during the
+  // previous stage) and this wave's four DMA pieces of the stage three ahead (its ring slot was last read two stages
+  // ago); then the stage barrier (own pieces counted: the two younger stages may still be in flight); second half:
+  // row blocks 4-7 and the twelve fragment reads of the next stage — one other instruction at most between two MFMAs.
+#define EHX_STAGE16_BODY(M0, BC, BN, AN, BNX, DX0, DQ0, DX1, DQ1)                                         \
   do {                                                                                                   \
-    constexpr uint32_t so = (uint32_t)(S) * kStageI8, sn = (uint32_t)(((S) + 1) & 3) * kStageI8;         \
-    constexpr int sd = ((S) + 3) & 3;                                                                    \
-    M0(fa0, fb0, 0, 0);    fb1[0] = EHX_FR(smem + b_off1 + so);            EHX_SB();                    \
-    M0(fa0, fb0, 0, 1);    fb1[1] = EHX_FR(smem + b_off1 + so + 2048);     EHX_SB();                    \
-    M0(fa0, fb0, 1, 0);    fa1[0] = EHX_FR(smem + a_off1 + so);            EHX_SB();                    \
-    M0(fa0, fb0, 1, 1);    fa1[1] = EHX_FR(smem + a_off1 + so + 2048);     EHX_SB();                    \
-    M0(fa0, fb0, 2, 0);    fa1[2] = EHX_FR(smem + a_off1 + so + 4096);     EHX_SB();                    \
-    M0(fa0, fb0, 2, 1);    fa1[3] = EHX_FR(smem + a_off1 + so + 6144);     EHX_SB();                    \
-    M0(fa0, fb0, 3, 0);    EHX_SDMA_X0(sd);                                 EHX_SB();                    \
-    M0(fa0, fb0, 3, 1);    EHX_SDMA_Q0(sd);                                 EHX_SB();                    \
-    /* stage barrier: the next stage landed (own pieces counted: the younger stage and the two pieces    \
-       just issued may still be in flight) and is visible; every wave is done reading this stage */      \
-    wait_vmcnt<6>();                                                                                     \
-    lds_barrier_i8();                                                                                    \
+    M0(BC, 0, 0); DX0;                                     EHX_SB();                                     \
+    M0(BC, 0, 1);                                          EHX_SB();                                     \
+    M0(BC, 0, 2); DQ0;                                     EHX_SB();                                     \
+    M0(BC, 0, 3);                                          EHX_SB();                                     \
+    M0(BC, 1, 0); DX1;                                     EHX_SB();                                     \
+    M0(BC, 1, 1);                                          EHX_SB();                                     \
+    M0(BC, 1, 2); DQ1;                                     EHX_SB();                                     \
+    M0(BC, 1, 3);                                          EHX_SB();                                     \
+    M0(BC, 2, 0);                                          EHX_SB();                                     \
+    M0(BC, 2, 1);                                          EHX_SB();                                     \
+    M0(BC, 2, 2);                                          EHX_SB();                                     \
+    M0(BC, 2, 3);                                          EHX_SB();                                     \
+    M0(BC, 3, 0);                                          EHX_SB();                                     \
+    M0(BC, 3, 1);                                          EHX_SB();                                     \
+    M0(BC, 3, 2);                                          EHX_SB();                                     \
+    M0(BC, 3, 3);                                          EHX_SB();                                     \
+    /* stage barrier: the next stage landed and is visible; nobody reads the slot the stage after the    \
+       next two will be copied into */                                                                   \
+    wait_vmcnt<8>();                                                                                     \
+    EHX_STAGE_BARRIER();                                                                                 \
     EHX_SB();                                                                                            \
-    EHX_MF(fa1, fb1, 0, 0); fb0[0] = EHX_FR(smem + b_off0 + sn);            EHX_SB();                    \
-    EHX_MF(fa1, fb1, 0, 1); fb0[1] = EHX_FR(smem + b_off0 + sn + 2048);     EHX_SB();                    \
-    EHX_MF(fa1, fb1, 1, 0); fa0[0] = EHX_FR(smem + a_off0 + sn);            EHX_SB();                    \
-    EHX_MF(fa1, fb1, 1, 1); fa0[1] = EHX_FR(smem + a_off0 + sn + 2048);     EHX_SB();                    \
-    EHX_MF(fa1, fb1, 2, 0); fa0[2] = EHX_FR(smem + a_off0 + sn + 4096);     EHX_SB();                    \
-    EHX_MF(fa1, fb1, 2, 1); fa0[3] = EHX_FR(smem + a_off0 + sn + 6144);     EHX_SB();                    \
-    EHX_MF(fa1, fb1, 3, 0); EHX_SDMA_X1(sd);                                 EHX_SB();                    \
-    EHX_MF(fa1, fb1, 3, 1); EHX_SDMA_Q1(sd);                                 EHX_SB();                    \
+    M0(BC, 4, 0); BN[0] = EHX_FR(smem + (BNX));           EHX_SB();                                     \
+    M0(BC, 4, 1); BN[1] = EHX_FR(smem + (BNX) + 1024);    EHX_SB();                                     \
+    M0(BC, 4, 2); BN[2] = EHX_FR(smem + (BNX) + 2048);    EHX_SB();                                     \
+    M0(BC, 4, 3); BN[3] = EHX_FR(smem + (BNX) + 3072);    EHX_SB();                                     \
+    M0(BC, 5, 0); fa[0] = EHX_FR(smem + (AN));            EHX_SB();                                     \
+    M0(BC, 5, 1); fa[1] = EHX_FR(smem + (AN) + 1024);     EHX_SB();                                     \
+    M0(BC, 5, 2); fa[2] = EHX_FR(smem + (AN) + 2048);     EHX_SB();                                     \
+    M0(BC, 5, 3); fa[3] = EHX_FR(smem + (AN) + 3072);     EHX_SB();                                     \
+    M0(BC, 6, 0); fa[4] = EHX_FR(smem + (AN) + 4096);     EHX_SB();                                     \
+    M0(BC, 6, 1); fa[5] = EHX_FR(smem + (AN) + 5120);     EHX_SB();                                     \
+    M0(BC, 6, 2);                                          EHX_SB();                                     \
+    M0(BC, 6, 3);                                          EHX_SB();                                     \
+    M0(BC, 7, 0); fa[6] = EHX_FR(smem + (AN) + 6144);     EHX_SB();                                     \
+    M0(BC, 7, 1);                                          EHX_SB();                                     \
+    M0(BC, 7, 2);                                          EHX_SB();                                     \
+    M0(BC, 7, 3);                                          EHX_SB();                                     \
+    fa[7] = EHX_FR(smem + (AN) + 7168);                    EHX_SB();                                     \
   } while (0)
-
-  // One stage on ring slot SO (byte offset of the slot, a scalar): no branches; the slot's offset enters the four
-  // fragment base addresses once (four vector adds per stage), everything else is an immediate; every gap between two
-  // MFMAs carries one other instruction of this wave (a fragment read or a DMA piece).  SN: the next stage's slot,
-  // DX0 / DQ0 / DX1 / DQ1: LDS destinations of this wave's four DMA pieces of the stage three ahead.
-#define EHX_STAGE_I8_RT(SO, SN, DX0, DQ0, DX1, DQ1, M0)                                                         \
+  // ring slot S a compile-time constant: no address arithmetic at all
+#define EHX_STAGE16_CT(S, M0, BC, BN)                                                                    \
   do {                                                                                                   \
-    const uint32_t a1_ = a_off1 + (SO), b1_ = b_off1 + (SO), a0_ = a_off0 + (SN), b0_ = b_off0 + (SN);   \
-    M0(fa0, fb0, 0, 0);    fb1[0] = EHX_FR(smem + b1_);                    EHX_SB();                    \
-    M0(fa0, fb0, 0, 1);    fb1[1] = EHX_FR(smem + b1_ + 2048);             EHX_SB();                    \
-    M0(fa0, fb0, 1, 0);    fa1[0] = EHX_FR(smem + a1_);                    EHX_SB();                    \
-    M0(fa0, fb0, 1, 1);    fa1[1] = EHX_FR(smem + a1_ + 2048);             EHX_SB();                    \
-    M0(fa0, fb0, 2, 0);    fa1[2] = EHX_FR(smem + a1_ + 4096);             EHX_SB();                    \
-    M0(fa0, fb0, 2, 1);    fa1[3] = EHX_FR(smem + a1_ + 6144);             EHX_SB();                    \
-    M0(fa0, fb0, 3, 0);    EHX_SDMA(DX0, voff, xsrc);                      EHX_SB();                    \
-    M0(fa0, fb0, 3, 1);    EHX_SDMA(DQ0, voff, qsrc);                      EHX_SB();                    \
-    /* stage barrier: the next stage landed (own pieces counted: the younger stage and the two pieces    \
-       just issued may still be in flight) and is visible; every wave is done reading this stage */      \
-    wait_vmcnt<6>();                                                                                     \
-    lds_barrier_i8();                                                                                    \
-    EHX_SB();                                                                                            \
-    EHX_MF(fa1, fb1, 0, 0); fb0[0] = EHX_FR(smem + b0_);                    EHX_SB();                    \
-    EHX_MF(fa1, fb1, 0, 1); fb0[1] = EHX_FR(smem + b0_ + 2048);             EHX_SB();                    \
-    EHX_MF(fa1, fb1, 1, 0); fa0[0] = EHX_FR(smem + a0_);                    EHX_SB();                    \
-    EHX_MF(fa1, fb1, 1, 1); fa0[1] = EHX_FR(smem + a0_ + 2048);             EHX_SB();                    \
-    EHX_MF(fa1, fb1, 2, 0); fa0[2] = EHX_FR(smem + a0_ + 4096);             EHX_SB();                    \
-    EHX_MF(fa1, fb1, 2, 1); fa0[3] = EHX_FR(smem + a0_ + 6144);             EHX_SB();                    \
-    EHX_MF(fa1, fb1, 3, 0); EHX_SDMA(DX1, voff8, xsrc);                     EHX_SB();                    \
-    EHX_MF(fa1, fb1, 3, 1); EHX_SDMA(DQ1, voff8, qsrc);                     EHX_SB();                    \
-    xsrc += kStageI8;                                                                                    \
-    qsrc += kStageI8;                                                                                    \
+    constexpr uint32_t sn = (uint32_t)(((S) + 1) & 3) * kStageI8;                                        \
+    constexpr int sd = ((S) + 3) & 3;                                                                    \
+    EHX_STAGE16_BODY(M0, BC, BN, a_off + sn, b_off + sn, EHX_SDMA_X0(sd), EHX_SDMA_Q0(sd), EHX_SDMA_X1(sd), \
+                     EHX_SDMA_Q1(sd));                                                                   \
   } while (0)
 
   // Two loops over the same stage body.  REV (a tile is a whole number of ring revolutions, ld % 256 == 0: d = 768, 1536,
-  // 1024, 512, 256 ...): the ring slot of every stage is a compile-time constant — no address arithmetic at all; same-box
-  // A/B at 10 M x 768: 7.33 ms per batch against 7.66 with run-time slots.  Otherwise (d = 128, 384, 640 ...; round 2
-  // padded those rows to a whole revolution, twice resp. 4/3 of their length, and kept this engine off 128-dim rows):
+  // 1024, 512, 256 ...): the ring slot of every stage is a compile-time constant.  Otherwise (d = 128, 384, 640 ...):
   // one loop over single stages whose slot is a scalar.
   if constexpr (REV) {
-    // Tile by tile; a tile is `kquads` revolutions of the ring (ld % 256 == 0).  The first revolution of a tile is its
-    // own copy of the four stage bodies: its first k-step starts the accumulators from 0.
+    // Tile by tile; a tile is `kquads` revolutions of the ring (ld % 256 == 0).  The first stage of a tile is its own
+    // copy of the stage body: its MFMAs start the accumulators from 0.
     const uint32_t kquads = ktiles >> 2;
     // row parameters of tile 1 (consumed by its epilogue, a whole tile from now)
     rsrc += kTileRows16 * 16;
@@ -546,16 +603,16 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       ++q;
     };
     for (uint32_t t = 0; t < my_tiles; ++t) {
-      EHX_STAGE_I8_CT(0, EHX_MFZ);
-      EHX_STAGE_I8_CT(1, EHX_MF);
-      EHX_STAGE_I8_CT(2, EHX_MF);
-      EHX_STAGE_I8_CT(3, EHX_MF);
+      EHX_STAGE16_CT(0, EHX_MFZ, fb0, fb1);
+      EHX_STAGE16_CT(1, EHX_MF, fb1, fb0);
+      EHX_STAGE16_CT(2, EHX_MF, fb0, fb1);
+      EHX_STAGE16_CT(3, EHX_MF, fb1, fb0);
       after_revolution();
       for (uint32_t kq = 1; kq < kquads; ++kq) {
-        EHX_STAGE_I8_CT(0, EHX_MF);
-        EHX_STAGE_I8_CT(1, EHX_MF);
-        EHX_STAGE_I8_CT(2, EHX_MF);
-        EHX_STAGE_I8_CT(3, EHX_MF);
+        EHX_STAGE16_CT(0, EHX_MF, fb0, fb1);
+        EHX_STAGE16_CT(1, EHX_MF, fb1, fb0);
+        EHX_STAGE16_CT(2, EHX_MF, fb0, fb1);
+        EHX_STAGE16_CT(3, EHX_MF, fb1, fb0);
         after_revolution();
       }
 #if !(EHX_I8_ABL & 1)
@@ -566,8 +623,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       qsrc = qbase + 3 * kStageI8;
       rsrc += kTileRows16 * 16;
       tp_cur = ldc(tilep_c, t + 1);  // (past the last tile: the array's padding entries)
-      tg0 = ldc(tgp, (size_t)(t + 1) * 4);
-      tg1 = ldc(tgp, (size_t)(t + 1) * 4 + 1);
+      tg_cur = ldc(tgp, (size_t)(t + 1) * 4);
       // tile t+2 goes to the slot tile t-1 used: every wave left that epilogue long ago
       const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 2) % 3 == (t - 1) % 3
       rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
@@ -577,11 +633,11 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       }
     }
   } else {
-    // One flat loop over the stages of the chunk; a tile is `ktiles` of them (ld / 64: any number — round 2 wanted whole
-    // ring revolutions, ld % 256 == 0, which padded 128-dim rows to twice and 384-dim rows to 4/3 of their length and
-    // kept the int8 engine off short rows).  The tile boundary work hangs off a counter and may fall anywhere in a
-    // revolution: nothing in the ring depends on where a tile starts (X stages stream linearly, Q stages repeat with
-    // period ktiles, and the three blocks appended to the Q array cover the look-ahead across the boundary).
+    // One flat loop over the stages of the chunk; a tile is `ktiles` of them (ld / 64: any number).  The tile boundary
+    // work hangs off a counter and may fall anywhere in a revolution: nothing in the ring depends on where a tile starts
+    // (X stages stream linearly, Q stages repeat with period ktiles, and the three blocks appended to the Q array cover
+    // the look-ahead across the boundary).  The query fragments change hands by a copy here (a tile may be an odd
+    // number of stages).
     const uint32_t total_stages = my_tiles * ktiles;
     // row parameters of tile 1 (consumed by its epilogue, a whole tile from now)
     rsrc += kTileRows16 * 16;
@@ -590,10 +646,23 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 #pragma unroll 1
     for (uint32_t st = 0; st < total_stages; ++st) {
       {
-        const uint32_t so = slot << 14, sn = ((slot + 1u) & 3u) << 14, sd = ((slot + 3u) & 3u) << 14;
+        const uint32_t sn = ((slot + 1u) & 3u) << 14, sd = ((slot + 3u) & 3u) << 14;
         const uint32_t dx0 = xdst + sd, dq0 = qdst + sd;
-        if (ks == 0u) EHX_STAGE_I8_RT(so, sn, dx0, dq0, dx0 + 8192u, dq0 + 8192u, EHX_MFZ);
-      else EHX_STAGE_I8_RT(so, sn, dx0, dq0, dx0 + 8192u, dq0 + 8192u, EHX_MF);
+        const uint32_t an_ = a_off + sn, bn_ = b_off + sn;
+#define EHX_RT_DX0 EHX_SDMA(dx0, voff, xsrc)
+#define EHX_RT_DQ0 EHX_SDMA(dq0, voff, qsrc)
+#define EHX_RT_DX1 EHX_SDMA(dx0 + 8192u, voff8, xsrc)
+#define EHX_RT_DQ1 EHX_SDMA(dq0 + 8192u, voff8, qsrc)
+        if (ks == 0u) EHX_STAGE16_BODY(EHX_MFZ, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1);
+        else EHX_STAGE16_BODY(EHX_MF, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1);
+#undef EHX_RT_DX0
+#undef EHX_RT_DQ0
+#undef EHX_RT_DX1
+#undef EHX_RT_DQ1
+        xsrc += kStageI8;
+        qsrc += kStageI8;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) fb0[cb] = fb1[cb];
       }
       slot = (slot + 1u) & 3u;
       if (sync_on && w == 0 && slot == 0u) {
@@ -624,20 +693,13 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 #if !(EHX_I8_ABL & 1)
         epilogue(t);
 #endif
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0;
         ++t;
         // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
         // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
         qsrc = qbase + 3 * kStageI8;
         rsrc += kTileRows16 * 16;
         tp_cur = ldc(tilep_c, t);  // (past the last tile: the array's padding entries)
-        tg0 = ldc(tgp, (size_t)t * 4);
-        tg1 = ldc(tgp, (size_t)t * 4 + 1);
+        tg_cur = ldc(tgp, (size_t)t * 4);
         // tile t+1 (counting the new t) goes to the slot tile t-2 used: every wave left that epilogue long ago
         const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 1) % 3 == (t - 2) % 3
         rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
@@ -658,9 +720,10 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 #undef EHX_SDMA_Q0
 #undef EHX_SDMA_X1
 #undef EHX_SDMA_Q1
-#undef EHX_STAGE_I8_CT
+#undef EHX_STAGE16_CT
+#undef EHX_STAGE16_BODY
+#undef EHX_STAGE_BARRIER
 #undef EHX_MFZ
-#undef EHX_STAGE_I8_RT
 #undef EHX_DMA_X0
 #undef EHX_DMA_Q0
 #undef EHX_DMA_X1
@@ -670,6 +733,8 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   // ---- final: what is left in this wave's staging buffer goes to the pools ----
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   if (DUMP) return;
+  if (lane == 0) ((uint32_t*)(smem + kStgCntOffI8))[w] = stg_n;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   i8_flush_staging();
 }
 

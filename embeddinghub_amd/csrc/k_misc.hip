@@ -310,11 +310,16 @@ __device__ __forceinline__ float i8_slack(uint32_t dims) { return 4e-6f + 1.5e-7
 __device__ __forceinline__ float i8_err_up(float e2) { return __builtin_sqrtf(e2) * (1.0f + 1e-4f) + 3e-7f; }
 }  // namespace
 
+// tgtA / posn (optional, both or neither; indexed by row - base): the row's step is RAISED so that |A_r| equals tgtA
+// exactly (the maximum of its 32-row lane group: "rows of a tile ordered by quantisation step" below) and the row is
+// stored at position posn of its tile instead of at its own index.
 template <typename XT>
 __global__ __launch_bounds__(256) void make_scan8_kernel(const XT* __restrict__ X, uint64_t row0, uint64_t n,
                                                          uint32_t dims, uint32_t ld, uint32_t ld8, int metric,
                                                          int8_t* __restrict__ X8, float4* __restrict__ rowp8,
-                                                         unsigned long long* __restrict__ n_unsafe) {
+                                                         unsigned long long* __restrict__ n_unsafe,
+                                                         const float* __restrict__ tgtA, const uint8_t* __restrict__ posn,
+                                                         uint64_t base) {
   const int lane = threadIdx.x & 63;
   const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
@@ -329,14 +334,22 @@ __global__ __launch_bounds__(256) void make_scan8_kernel(const XT* __restrict__ 
   float amax = 0.0f;
   for (uint32_t c = lane; c < dims; c += 64) amax = fmaxf(amax, fabsf(ld_row(x, c) * inv));
   amax = wave_max(amax);
-  const float s = amax / 127.0f;
-  const float rs = amax > 0.0f ? 127.0f / amax : 0.0f;
+  const float a_abs = metric == 2 ? 1.0f : nr;          // |a_r|: cosine 1, inner product and L2^2 the row's norm
+  float s = amax / 127.0f;
+  if (tgtA) {
+    // the step that makes |a_r| s equal to the group's |A| (never below the row's own: tgt is the group maximum of
+    // |a_r| amax / 127 computed with these very operations; a rounding of the division downwards is caught here)
+    const float want = a_abs > 0.0f ? tgtA[r - base] / a_abs : s;
+    s = fmaxf(s, want);
+  }
+  const float rs = s > 0.0f ? 1.0f / s : 0.0f;
+  const uint64_t pr = posn ? ((r & ~(uint64_t)255) | (uint64_t)posn[r - base]) : r;   // where the row is stored
   float e2 = 0.0f;
   for (uint32_t c = lane; c < ld8; c += 64) {
     const float v = c < dims ? ld_row(x, c) * inv : 0.0f;
     float qf = rintf(v * rs);
     qf = fminf(fmaxf(qf, -127.0f), 127.0f);
-    X8[scan8_index(r, c, ld8)] = (int8_t)(int)qf;
+    X8[scan8_index(pr, c, ld8)] = (int8_t)(int)qf;
     const float res = v - s * qf;
     e2 += res * res;
   }
@@ -357,8 +370,29 @@ __global__ __launch_bounds__(256) void make_scan8_kernel(const XT* __restrict__ 
       }
       p = make_float4(a_r * s, b_r * (1.0f - 1e-6f), a_r * (1.0001f + e), a_r * (1.0001f * e + i8_slack(dims)));
     }
-    rowp8[r] = p;
+    rowp8[pr] = p;
   }
+}
+
+// natural |A_r| = |a_r| max|x^| / 127 of rows [row0, row0 + n) (what make_scan8_kernel would give the row on its own;
+// 0 for a row the filter cannot bound): the sort key of the tile ordering
+template <typename XT>
+__global__ __launch_bounds__(256) void scan8_step_kernel(const XT* __restrict__ X, uint64_t row0, uint64_t n, uint32_t dims,
+                                                         uint32_t ld, int metric, float* __restrict__ natA) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const XT* x = X + (row0 + i) * ld;
+  float ss = 0.0f;
+  for (uint32_t c = lane; c < dims; c += 64) ss += ld_row(x, c) * ld_row(x, c);
+  ss = wave_sum(ss);
+  const bool ok = norm_ok(ss);
+  const float nr = ok ? __builtin_sqrtf(ss) : 0.0f;
+  const float inv = nr > 0.0f ? 1.0f / nr : 0.0f;
+  float amax = 0.0f;
+  for (uint32_t c = lane; c < dims; c += 64) amax = fmaxf(amax, fabsf(ld_row(x, c) * inv));
+  amax = wave_max(amax);
+  if (lane == 0) natA[i] = ok ? (metric == 2 ? 1.0f : nr) * (amax / 127.0f) : 0.0f;
 }
 
 // (max|A|, max|C|, max|D|, min B) over the 256 rows of each tile: one wave per tile, 4 rows per lane
@@ -386,35 +420,36 @@ __global__ __launch_bounds__(64) void tile_params8_kernel(const float4* __restri
 }
 
 // ---- rows of a tile ordered by quantisation step (round 4) ---------------------------------------------------
-// The scan's epilogue asks, per 32 x 32 accumulator block, whether ANY accumulator can belong to a candidate:
-// I * |A_r| >= K_q.  With a per-row |A_r| that is a convert and a multiply per accumulator (40 vector instructions per
-// block: 13 % of a tile at d = 768, more than the matrix work at d = 128).  If the 16 rows a lane holds in one block
-// share (nearly) one step the test is an integer maximum and ONE product: max(I) * max|A| >= K_q.  |A_r| varies +-10 %
-// between rows, so the rows of a FULL tile are stored ordered by |A_r|: the lane's 16 rows of block (wr, rb, half h) —
-// positions base + (m & 3) + 8 (m >> 2), base = (g >> 1) 32 + (g & 1) 4, g = 8 wr + 2 rb + h — hold ranks 16 g ..
-// 16 g + 15, whose steps differ by ~1 %.  perm8[position] = the row's index inside its tile (the kernel maps a hit's
-// position back to the row id when it flushes its staging buffer); tileg8[tile][g] = max |A| of group g.  Tiles that
-// are not full when they are written (the tail of a batch, rows appended one by one) keep the identity order — their
-// group maxima are the actual maxima, looser but sound — and a tile may only be re-ordered while no scan can read it
-// (rows beyond the published row count, or a writer that holds the space exclusively).
+// The scan's epilogue asks, per query and wave tile, whether ANY accumulator can belong to a candidate:
+// I * |A_r| >= K_q.  With a per-row |A_r| that is a convert and a multiply per accumulator (13 % of a tile at d = 768,
+// more than the matrix work at d = 128).  If the 32 rows a lane holds for one query share (nearly) one step the test is
+// an integer maximum and ONE product: max(I) * max|A| >= K_q.  |A_r| varies +-10 % between rows, so the rows of a FULL
+// tile are stored ordered by |A_r|: the lane's 32 rows of wave row wr and lane quarter q' = l >> 4 — positions
+// 128 wr + 16 rb + 4 q' + r, rb = 0..7, r = 0..3 — hold ranks 32 g .. 32 g + 31, g = 4 wr + q', whose steps differ by a
+// few per cent.  perm8[position] = the row's index inside its tile (the kernel maps a hit's position back to the row
+// id when it flushes its staging buffer); tileg8[tile][g] = max |A| of group g (8 of the 16 floats of a tile's entry are
+// used).  Tiles that are not full when they are written (the tail of a batch, rows appended one by one) keep the
+// identity order — their group maxima are the actual maxima, looser but sound — and a tile may only be re-ordered while
+// no scan can read it (rows beyond the published row count, or a writer that holds the space exclusively).
 namespace {
-__device__ __forceinline__ uint32_t i8_group_of_pos(uint32_t p) { return ((p >> 5) << 1) | ((p >> 2) & 1u); }
+__device__ __forceinline__ uint32_t i8_group_of_pos(uint32_t p) { return ((p >> 7) << 2) | ((p >> 2) & 3u); }
 __device__ __forceinline__ uint32_t i8_pos_of_rank(uint32_t rank) {
-  const uint32_t g = rank >> 4, m = rank & 15u;
-  return (g >> 1) * 32u + (g & 1u) * 4u + (m & 3u) + 8u * (m >> 2);
+  const uint32_t g = rank >> 5, m = rank & 31u;
+  return (g >> 2) * 128u + (m >> 2) * 16u + (g & 3u) * 4u + (m & 3u);
 }
 }  // namespace
 
-__global__ __launch_bounds__(256) void sort_tiles8_kernel(int8_t* __restrict__ X8, float4* __restrict__ rowp8,
+// one workgroup per FULL tile (tile index tile0 + blockIdx.x): ranks of the 256 natural |A_r| -> the rows' positions
+// (posn, perm8), the eight group maxima (tileg8) and every row's target |A| = the maximum of its group
+__global__ __launch_bounds__(256) void rank_tiles8_kernel(const float* __restrict__ natA, uint64_t tile0,
                                                           uint8_t* __restrict__ perm8, float* __restrict__ tileg8,
-                                                          const uint64_t* __restrict__ tiles, uint32_t ktiles) {
+                                                          float* __restrict__ tgtA, uint8_t* __restrict__ posn) {
   __shared__ float a_l[256];
-  __shared__ uint8_t perm_l[256];
-  __shared__ __attribute__((aligned(16))) char blk[256 * 64];
+  __shared__ float g_l[8];
   const uint32_t tid = threadIdx.x;
-  const uint64_t tile = tiles[blockIdx.x];
-  const float4 P = rowp8[tile * 256 + tid];
-  const float a = fabsf(P.x);
+  const uint64_t tile = tile0 + blockIdx.x;
+  const size_t i = (size_t)blockIdx.x * 256 + tid;   // index into natA / tgtA / posn (rows from tile0 * 256)
+  const float a = natA[i];
   a_l[tid] = a;
   __syncthreads();
   uint32_t rank = 0;
@@ -423,75 +458,118 @@ __global__ __launch_bounds__(256) void sort_tiles8_kernel(int8_t* __restrict__ X
     rank += (b < a || (b == a && j < tid)) ? 1u : 0u;
   }
   const uint32_t pos = i8_pos_of_rank(rank);
-  perm_l[pos] = (uint8_t)tid;
-  __syncthreads();  // (every thread holds its own P: the row parameters can be rewritten in place)
-  rowp8[tile * 256 + pos] = P;
-  perm8[tile * 256 + tid] = perm_l[tid];
-  if ((rank & 15u) == 15u) tileg8[tile * 16 + (rank >> 4)] = a;
-  // the tile's stage blocks, one at a time: position p takes the 64 bytes of row perm[p] (the 16-byte chunk swizzle
-  // of the layout depends on the row's place: scan8_index)
-  int4* g = (int4*)(X8 + (size_t)tile * ktiles * (256u * 64u));
-  for (uint32_t kt = 0; kt < ktiles; ++kt) {
-    int4* gb = g + (size_t)kt * 1024;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ((int4*)blk)[tid + 256 * j] = gb[tid + 256 * j];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t e = tid + 256u * (uint32_t)j, p = e >> 2, c = e & 3u;
-      const uint32_t r = perm_l[p];
-      gb[p * 4u + (c ^ ((p >> 2) & 3u))] = ((const int4*)blk)[r * 4u + (c ^ ((r >> 2) & 3u))];
-    }
-    __syncthreads();
-  }
+  if ((rank & 31u) == 31u) g_l[rank >> 5] = a;
+  __syncthreads();
+  const float gmax = g_l[rank >> 5];
+  posn[i] = (uint8_t)pos;
+  tgtA[i] = gmax;
+  perm8[tile * 256 + pos] = (uint8_t)tid;
+  if (tid < 8) tileg8[tile * 16 + tid] = g_l[tid];
+  else if (tid < 16) tileg8[tile * 16 + tid] = 0.0f;
 }
 
 // tiles kept in row order: perm = identity, group maxima from the rows where they are
+// (tiles == nullptr: tiles tile0 + blockIdx.x, perm8 left alone — the ordered tiles, whose group maxima are taken from
+// the row parameters as stored too: the alarm's |A| must bound the rows' ACTUAL |A_r| to the last bit)
 __global__ __launch_bounds__(256) void ident_tiles8_kernel(const float4* __restrict__ rowp8, uint8_t* __restrict__ perm8,
-                                                           float* __restrict__ tileg8, const uint64_t* __restrict__ tiles) {
+                                                           float* __restrict__ tileg8, const uint64_t* __restrict__ tiles,
+                                                           uint64_t tile0) {
   __shared__ uint32_t gm[16];
   const uint32_t tid = threadIdx.x;
-  const uint64_t tile = tiles[blockIdx.x];
-  if (tid < 16) gm[tid] = 0u;
+  const uint64_t tile = tiles ? tiles[blockIdx.x] : tile0 + blockIdx.x;
+  if (tid < 16) gm[tid] = 0u;  // (groups 8..15 are unused: zero)
   __syncthreads();
   const float a = fabsf(rowp8[tile * 256 + tid].x);
   atomicMax(&gm[i8_group_of_pos(tid)], __float_as_uint(a));  // (non-negative floats order like their bit patterns)
-  perm8[tile * 256 + tid] = (uint8_t)tid;
+  if (tiles) perm8[tile * 256 + tid] = (uint8_t)tid;
   __syncthreads();
   if (tid < 16) tileg8[tile * 16 + tid] = __uint_as_float(gm[tid]);
 }
 
-hipError_t launch_make_scan8(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
-                             uint32_t ld8, int metric, int8_t* X8, float4* rowp8, float4* tilep8, uint8_t* perm8,
-                             float* tileg8, uint64_t sort_lo, uint64_t sort_hi, uint64_t* tile_list,
-                             unsigned long long* n_unsafe, hipStream_t st) {
-  if (n == 0) return hipSuccess;
+namespace {
+template <typename XT>
+void make_rows8(const XT* X, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld, uint32_t ld8, int metric, int8_t* X8,
+                float4* rowp8, unsigned long long* n_unsafe, const float* tgtA, const uint8_t* posn, uint64_t base,
+                hipStream_t st) {
   const uint64_t max_rows = kMaxWorkItems / 64;  // one wave per row; a dispatch holds < 2^32 work-items
   for (uint64_t r0 = 0; r0 < n; r0 += max_rows) {
     const uint64_t m = n - r0 < max_rows ? n - r0 : max_rows;
-    const dim3 grid((uint32_t)((m + 3) / 4));
-    if (x_half)
-      hipLaunchKernelGGL(make_scan8_kernel<__half>, grid, dim3(256), 0, st, (const __half*)X, row0 + r0, m, dims, ld,
-                         ld8, metric, X8, rowp8, n_unsafe);
-    else
-      hipLaunchKernelGGL(make_scan8_kernel<float>, grid, dim3(256), 0, st, (const float*)X, row0 + r0, m, dims, ld, ld8,
-                         metric, X8, rowp8, n_unsafe);
+    hipLaunchKernelGGL(make_scan8_kernel<XT>, dim3((uint32_t)((m + 3) / 4)), dim3(256), 0, st, X, row0 + r0, m, dims, ld,
+                       ld8, metric, X8, rowp8, n_unsafe, tgtA, posn, base);
   }
+}
+template <typename XT>
+void step_rows8(const XT* X, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld, int metric, float* natA,
+                hipStream_t st) {
+  const uint64_t max_rows = kMaxWorkItems / 64;
+  for (uint64_t r0 = 0; r0 < n; r0 += max_rows) {
+    const uint64_t m = n - r0 < max_rows ? n - r0 : max_rows;
+    hipLaunchKernelGGL(scan8_step_kernel<XT>, dim3((uint32_t)((m + 3) / 4)), dim3(256), 0, st, X, row0 + r0, m, dims, ld,
+                       metric, natA + r0);
+  }
+}
+}  // namespace
+
+size_t make_scan8_scratch_bytes(uint64_t row0, uint64_t n, uint64_t sort_lo, uint64_t sort_hi) {
   const uint64_t t0 = row0 >> 8, t1 = (row0 + n + 255) >> 8;
-  hipLaunchKernelGGL(tile_params8_kernel, dim3((uint32_t)(t1 - t0)), dim3(64), 0, st, rowp8, t0, tilep8);
-  // tiles wholly inside [sort_lo, sort_hi) are re-ordered by step, the others keep the row order.  tile_list (device,
-  // >= t1 - t0 entries) receives the two id lists back to back; written by iota kernels, no host copy
-  const uint64_t s0 = (sort_lo + 255) >> 8, s1 = sort_hi >> 8;   // sorted tiles: [max(t0, s0), min(t1, s1))
+  const uint64_t s0 = (sort_lo + 255) >> 8, s1 = sort_hi >> 8;
   const uint64_t a0 = s0 > t0 ? s0 : t0, a1 = s1 < t1 ? s1 : t1;
+  const uint64_t rows = a1 > a0 ? (a1 - a0) * 256 : 0;
+  return (size_t)rows * 9 + (size_t)(t1 - t0 + 1) * 8 + 64;   // natA f32 | tgtA f32 | posn u8 | tile ids
+}
+
+hipError_t launch_make_scan8(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
+                             uint32_t ld8, int metric, int8_t* X8, float4* rowp8, float4* tilep8, uint8_t* perm8,
+                             float* tileg8, uint64_t sort_lo, uint64_t sort_hi, void* scratch,
+                             unsigned long long* n_unsafe, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const uint64_t t0 = row0 >> 8, t1 = (row0 + n + 255) >> 8;
+  // tiles wholly inside [sort_lo, sort_hi) AND inside the rows being written are ordered by step; the others keep the
+  // row order
+  const uint64_t s0 = (sort_lo + 255) >> 8, s1 = sort_hi >> 8;
+  uint64_t a0 = s0 > t0 ? s0 : t0, a1 = s1 < t1 ? s1 : t1;
+  if (a0 * 256 < row0) a0 = (row0 + 255) >> 8;
+  if (a1 * 256 > row0 + n) a1 = (row0 + n) >> 8;
   const uint64_t n_sorted = a1 > a0 ? a1 - a0 : 0;
-  if (hipError_t e = launch_tile_ids(tile_list, t0, t1, n_sorted ? a0 : t1, n_sorted ? a1 : t1, st); e != hipSuccess) return e;
-  if (n_sorted)
-    hipLaunchKernelGGL(sort_tiles8_kernel, dim3((uint32_t)n_sorted), dim3(256), 0, st, X8, rowp8, perm8, tileg8, tile_list,
-                       ld8 >> 6);
+  auto make = [&](uint64_t r0, uint64_t m, const float* tgt, const uint8_t* pos, uint64_t base) {
+    if (m == 0) return;
+    if (x_half) make_rows8((const __half*)X, r0, m, dims, ld, ld8, metric, X8, rowp8, n_unsafe, tgt, pos, base, st);
+    else make_rows8((const float*)X, r0, m, dims, ld, ld8, metric, X8, rowp8, n_unsafe, tgt, pos, base, st);
+  };
+  uint64_t* tile_list;
+  if (n_sorted) {
+    const uint64_t rows = n_sorted * 256, base = a0 * 256;
+    float* natA = (float*)scratch;
+    float* tgtA = natA + rows;
+    uint8_t* posn = (uint8_t*)(tgtA + rows);
+    tile_list = (uint64_t*)(((uintptr_t)(posn + rows) + 15) & ~(uintptr_t)15);
+    if (x_half) step_rows8((const __half*)X, base, rows, dims, ld, metric, natA, st);
+    else step_rows8((const float*)X, base, rows, dims, ld, metric, natA, st);
+    for (uint64_t c0 = 0; c0 < n_sorted; c0 += 1u << 30) {
+      const uint64_t m = n_sorted - c0 < (1u << 30) ? n_sorted - c0 : (1u << 30);
+      hipLaunchKernelGGL(rank_tiles8_kernel, dim3((uint32_t)m), dim3(256), 0, st, natA + c0 * 256, a0 + c0, perm8, tileg8,
+                         tgtA + c0 * 256, posn + c0 * 256);
+    }
+    make(row0, base - row0, nullptr, nullptr, 0);                       // rows before the ordered tiles
+    make(base, rows, tgtA, posn, base);                                 // the ordered tiles
+    make(a1 * 256, row0 + n - a1 * 256, nullptr, nullptr, 0);           // rows after them
+  } else {
+    tile_list = (uint64_t*)scratch;
+    make(row0, n, nullptr, nullptr, 0);
+  }
+  hipLaunchKernelGGL(tile_params8_kernel, dim3((uint32_t)(t1 - t0)), dim3(64), 0, st, rowp8, t0, tilep8);
   const uint64_t n_ident = (t1 - t0) - n_sorted;
-  if (n_ident)
+  if (n_ident) {
+    // ids of the tiles of [t0, t1) outside [a0, a1)
+    if (hipError_t e = launch_tile_ids(tile_list, t0, t1, n_sorted ? a0 : t1, n_sorted ? a1 : t1, st); e != hipSuccess) return e;
     hipLaunchKernelGGL(ident_tiles8_kernel, dim3((uint32_t)n_ident), dim3(256), 0, st, rowp8, perm8, tileg8,
-                       tile_list + n_sorted);
+                       tile_list + n_sorted, (uint64_t)0);
+  }
+  for (uint64_t c0 = 0; c0 < n_sorted; c0 += 1u << 30) {
+    const uint64_t m = n_sorted - c0 < (1u << 30) ? n_sorted - c0 : (1u << 30);
+    hipLaunchKernelGGL(ident_tiles8_kernel, dim3((uint32_t)m), dim3(256), 0, st, rowp8, perm8, tileg8,
+                       (const uint64_t*)nullptr, a0 + c0);
+  }
   return hipGetLastError();
 }
 
