@@ -1347,11 +1347,12 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   // How many candidates a query keeps is what the scan's epilogue pays for (every key collected is a trip through its
   // slow path, and the waves of a workgroup wait for each other at every stage: 1.25 M x 768 collected 470 keys per
   // query, 70 % of the epilogue's tests alarmed).  The rows a query cannot exclude grow with the index (60-75 on average
-  // at 10 M x 768, far fewer at 1 M), so the list's LOGICAL length k' follows the row count — 64 below 1.5 M rows, 128
-  // below 4 M, else the full width; rows of 1024 dims and more always get the full width (the bound is ~1.3e-2 in dot
-  // units whatever d while the scores' spread shrinks like 1/sqrt(d): 18 000 x 2048 needs its 256) — and, like the
-  // width, doubles when queries lose their certificate because the list was too short (knn_device_locked).
-  uint32_t kp_auto = s->n >= 4000000 ? 256u : (s->n >= 1500000 ? 128u : 64u);
+  // at 10 M x 768, fewer on a shard of 1 M), so the list's LOGICAL length k' follows the row count — 128 below 4 M rows,
+  // else the full width (64 was tried: no query lost at 1 - 1.25 M x 768 in 50 batches, 3 of 256 at 100 k x 768); rows
+  // of 1024 dims and more always get the full width (the bound is ~1.3e-2 in dot units whatever d while the scores'
+  // spread shrinks like 1/sqrt(d): 18 000 x 2048 needs its 256) — and, like the width, doubles when queries lose their
+  // certificate because the list was too short (knn_device_locked).
+  uint32_t kp_auto = s->n >= 4000000 ? 256u : 128u;
   if (s->dims >= 1024) kp_auto = width;
   const uint32_t kp_want = std::max(kp_auto, s->i8_kprime_min);
   const uint32_t kprime = kprime_env >= 64 ? (uint32_t)std::min<long>(kprime_env, (long)width) : std::min(kp_want, width);
@@ -1391,7 +1392,7 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   // more than half of the first pass in the epilogue's slow path).
   const uint64_t first_rows = (uint64_t)passes.front().plan.n_tiles * kTileRows16;
   const uint64_t first_keys = std::min<uint64_t>(
-      2048, passes.size() == 1 ? 4ull * kprime : std::max<uint64_t>(std::min<uint64_t>(512, 4ull * kprime), 2ull * rank_after(0)));
+      2048, passes.size() == 1 ? 4ull * kprime : std::max<uint64_t>(std::min<uint64_t>(512, 2ull * kprime), 2ull * rank_after(0)));
   const uint32_t sample_rank =
       (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, first_keys * kSampleTiles * kTileRows16 / first_rows));
   const ScanPlan p = passes.back().plan;  // (q_tiles, q_rows are the same for every pass)

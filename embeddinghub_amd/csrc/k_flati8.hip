@@ -383,16 +383,22 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       return;
     }
     const float4 tp = tp_cur;  // uniform: (max|A|, max|C|, max|D|, min B) of the tile's rows (loaded a tile ago)
-    // max |A_r| over this lane's 32 rows (tiles are stored ordered by |A_r|: the 32 differ by a few per cent)
+    // max |A_r| over this lane's 32 rows (tiles ordered by step: every row of the group has exactly this |A_r|)
     const float4 tg = tg_cur;
     const float gm = qd == 0 ? tg.x : (qd == 1 ? tg.y : (qd == 2 ? tg.z : tg.w));
+    const float rgm = (1.0f - 2e-6f) / gm;   // (gm = 0: a group of padding rows — +inf, nothing alarms unless K = -inf)
+    // The alarm level K of a (tile, query) is computed ONCE per wave — lane (qd, j15) takes query 16 qd + j15 of the
+    // wave's 64 — and handed to the four lanes that hold the query's accumulators by a lane permute.  -inf, +inf or > 0.
+    const float k_own = i8_alarm_k(tp, qp_lds[wc * 64 + lane_e], qinv_lds[wc * 64 + lane_e]);
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
-      // ---- phase 1: can ANY of the lane's 32 accumulators of this query belong to a candidate?  I |A_r| >= K needs
-      // max(I) max|A| >= K (K > 0: a negative I never qualifies; K = -inf: always) — an integer maximum, one convert,
-      // one multiply ----
-      const float4 qq = qp_lds[col0 + 16 * cb];
-      const float kq = i8_alarm_k(tp, qq, qinv_lds[col0 + 16 * cb]);  // -inf, +inf or > 0
+      // ---- phase 1: can ANY of the lane's 32 accumulators of this query belong to a candidate?  I |A_r| >= K with
+      // |A_r| = gm for the whole group (K > 0: a negative I never qualifies; K = -inf: always), i.e. I >= K / gm: ONE
+      // integer level per lane and query (rounded down: a superset, the hit path judges every key exactly) against the
+      // integer maximum ----
+      const float kq = __shfl(k_own, cb * 16 + j15, 64);
+      // (clamped before the conversion: -2.1e9 = always, 2.1e9 = never — |I| <= 2048 * 127^2)
+      const int ti = (int)fminf(fmaxf(kq * rgm, -2.1e9f), 2.1e9f);
       int m8[8];
 #pragma unroll
       for (int rb = 0; rb < 8; ++rb) {
@@ -400,29 +406,27 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
         m8[rb] = max(max(c[0], c[1]), max(c[2], c[3]));
       }
       const int im = max(max(max(m8[0], m8[1]), max(m8[2], m8[3])), max(max(m8[4], m8[5]), max(m8[6], m8[7])));
-      const float pm = (float)im * gm;
 #if EHX_I8_ABL & 2
-      if (pm >= kq) asm volatile("" ::: "memory");  // (the comparison stays, the slow path does not)
+      if (im >= ti) asm volatile("" ::: "memory");  // (the comparison stays, the slow path does not)
       continue;
 #endif
       EHX_CNT(0);
-      if (!__any(pm >= kq)) continue;
+      if (!__any(im >= ti)) continue;
       EHX_CNT(1);
-      // ---- phase 2: which accumulators?  First the row blocks whose own maximum reaches the threshold (the eight
-      // per-block maxima are at hand), then their four accumulators against the same level — in a tile ordered by step
-      // every row of the lane's group has |A_r| = gm, so this IS the row's own test (a tile in row order: a superset;
-      // the hit path judges every key by its exact lower bound anyway).  A 32-bit mask per lane (bit 4 rb + r), then one
-      // set bit per lane and trip. ----
+      // ---- phase 2: which accumulators?  First the row blocks whose own maximum reaches the level (the eight per-block
+      // maxima are at hand), then their four accumulators.  A 32-bit mask per lane (bit 4 rb + r), then one set bit per
+      // lane and trip. ----
+      const float4 qq = qp_lds[col0 + 16 * cb];
       const int ql = cb * 16 + j15;
       uint32_t pend = 0u;
 #pragma unroll
       for (int rb = 7; rb >= 0; --rb) {  // (nibble by nibble: the bit constants stay inline operands)
         uint32_t nib = 0u;
-        if (__any((float)m8[rb] * gm >= kq)) {
+        if (__any(m8[rb] >= ti)) {
           EHX_CNT(2);
           const i32x4 c = acc[rb][cb];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) nib |= ((float)c[r] * gm >= kq) ? (1u << r) : 0u;
+          for (int r = 0; r < 4; ++r) nib |= (c[r] >= ti) ? (1u << r) : 0u;
         }
         pend = (pend << 4) | nib;
       }

@@ -198,8 +198,9 @@ def test_a_space_whose_queries_keep_going_uncertified_widens_its_candidate_list(
         s.stats_reset()
         _check(s, X, Q, k, pyoracle.METRIC_COSINE)
         fallbacks.append(s.stats()["n_i8_fallback"])
-    # (round 4: a space this small starts with 64 candidates per query — the list's logical length follows the row
-    # count — and doubles them first: 64, 128, 256, then the list itself to 512 and 1024)
-    assert all(f >= 32 for f in fallbacks[:4]), fallbacks     # up to 512 keys: the cluster does not fit
+    # (round 4: a space this small starts with 128 candidates per query — the list's logical length follows the row
+    # count — and doubles them first: 128, 256, then the list itself to 512 and 1024)
+    assert all(f >= 32 for f in fallbacks[:3]), fallbacks     # up to 512 keys: the cluster does not fit
+    assert fallbacks[3] == 0, fallbacks
     assert fallbacks[4] == 0 and fallbacks[5] == 0, fallbacks  # 1024 keys: the int8 engine certifies every query itself
     s.drop()
