@@ -698,6 +698,13 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
   hipStream_t st = s->stream;
   const uint64_t end = id0 + count;
   // ---- levels of every new row (getRandomLevel: -log(U(0,1)) * mult, a fresh distribution object per draw) ----
+  // Nothing of this call is committed (level generator, h_levels, g_lists_used) before every allocation it needs has
+  // succeeded: a call that fails for memory leaves the space exactly as it found it, and a retry draws the same levels.
+  const std::default_random_engine rng_before = s->level_rng;
+  auto undo = [&](int code) {
+    s->level_rng = rng_before;
+    return code;
+  };
   std::vector<int32_t> h_lv(count);
   std::vector<uint32_t> h_upstart(count);
   uint64_t new_lists = 0;
@@ -710,14 +717,8 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
     new_lists += (uint64_t)level;
     if (level > top) top = level;
   }
-  if ((rc = graph_ensure_lists(s, s->g_lists_used + new_lists))) return rc;
-  s->g_lists_used += new_lists;
-  s->h_levels.insert(s->h_levels.end(), h_lv.begin(), h_lv.end());
-  // the new nodes' up_start entries and levels (their adjacency rows are still all-0xFF; nothing reaches a node
-  // before the round that links it)
-  if ((rc = s->dInsLevels.ensure(count))) return rc;
-  HIP_TRY(hipMemcpyAsync(s->dUpStart + id0, h_upstart.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(s->dInsLevels.p, h_lv.data(), count * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  if ((rc = graph_ensure_lists(s, s->g_lists_used + new_lists))) return undo(rc);
+  if ((rc = s->dInsLevels.ensure(count))) return undo(rc);
   // ---- round schedule ----
   const uint64_t round_cap = batch > 1 ? batch : 4096;
   // Rows of one round do not see each other, so a round never exceeds a small share of the graph it joins: 1/128, at
@@ -755,18 +756,25 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
   const uint32_t vis_words = (uint32_t)((s->cap + 31) / 32);
   const uint32_t vislog_cap = 32768;
   const uint64_t max_pairs = max_P * (uint64_t)(top + 1) * M;
-  if (max_pairs >= 0xFFFFFFFFull) return fail(EHX_EUNSUPPORTED, "graph build: round too large");
+  if (max_pairs >= 0xFFFFFFFFull) return undo(fail(EHX_EUNSUPPORTED, "graph build: round too large"));
   // (the bitmaps are zero when allocated and every search clears the bits it set: no per-round memset)
-  if ((rc = s->dVisited.ensure(max_P * vis_words, true))) return rc;
+  if ((rc = s->dVisited.ensure(max_P * vis_words, true))) return undo(rc);
+  if ((rc = s->dInsVislog.ensure(max_P * (uint64_t)vislog_cap))) return undo(rc);
+  if ((rc = s->dLinkHead.ensure(s->cap + s->g_lists_cap, true))) return undo(rc);  // all zero between rounds
+  if ((rc = s->dLinkNext.ensure(max_pairs))) return undo(rc);
+  if ((rc = s->dLinkTouched.ensure(max_pairs))) return undo(rc);
+  if ((rc = s->dLinkCount.ensure(n_rounds))) return undo(rc);
+  // ---- commit: from here on the rows are on their way into the graph ----
+  s->g_lists_used += new_lists;
+  s->h_levels.insert(s->h_levels.end(), h_lv.begin(), h_lv.end());
+  // the new nodes' up_start entries and levels (their adjacency rows are still all-0xFF; nothing reaches a node
+  // before the round that links it)
+  HIP_TRY(hipMemcpyAsync(s->dUpStart + id0, h_upstart.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(s->dInsLevels.p, h_lv.data(), count * sizeof(int32_t), hipMemcpyHostToDevice, st));
   if (s->vis_dirty) {  // a search that clears its bitmaps before its kernel left them marked
     HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, s->dVisited.n * sizeof(uint32_t), st));
     s->vis_dirty = false;
   }
-  if ((rc = s->dInsVislog.ensure(max_P * (uint64_t)vislog_cap))) return rc;
-  if ((rc = s->dLinkHead.ensure(s->cap + s->g_lists_cap, true))) return rc;  // all zero between rounds
-  if ((rc = s->dLinkNext.ensure(max_pairs))) return rc;
-  if ((rc = s->dLinkTouched.ensure(max_pairs))) return rc;
-  if ((rc = s->dLinkCount.ensure(n_rounds))) return rc;
   HIP_TRY(hipMemsetAsync(s->dLinkCount.p, 0, n_rounds * sizeof(uint32_t), st));
   InsertArgs a{};  // (zeroed: a null link_head / sel switches those outputs off in the kernels)
   a.X = s->x_half ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
@@ -1880,7 +1888,22 @@ int sharded_set_batch(ehx_space* p, size_t n, const char* const* keys, const siz
   }
   std::vector<uint64_t> before(G);
   for (size_t i = 0; i < G; ++i) before[i] = p->shards[i]->n;
+  // Capacity first, on every shard, before any shard writes a row: the allocation that fails a batch half way (an
+  // out-of-memory while one shard grows) then fails it before anything changed — graph shards cannot take rows back
+  // once they are linked.
   int rc = for_each_shard(p, [&](size_t i) -> int {
+    if (lids[i].empty()) return EHX_OK;
+    ehx_space* c = p->shards[i];
+    std::lock_guard<std::mutex> cg(c->wmu);
+    std::unique_lock<std::shared_mutex> wl(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t next_local = (next + G - 1 - i) / G;
+    int r = ensure_rows(c, next_local);
+    if (!r && c->params.mode == EHX_MODE_GRAPH) r = graph_ensure_arrays(c);
+    return r;
+  });
+  if (rc) return rc;
+  rc = for_each_shard(p, [&](size_t i) -> int {
     if (lids[i].empty()) return EHX_OK;
     ehx_space* c = p->shards[i];
     std::lock_guard<std::mutex> cg(c->wmu);
@@ -2037,15 +2060,29 @@ int ehx_init(const int* device_ids, int n_devices) {
       return fail(EHX_ENODEVICE, "device %d is %s; this engine is built for gfx950 only", dev, prop.gcnArchName);
     if (!n_cus) n_cus = prop.multiProcessorCount;
   }
-  // the shards of one space exchange their local top-k lists by peer copies over xGMI: open every pair
+  // The shards of one space exchange their local top-k lists by peer copies over xGMI: every ordered pair of the
+  // devices is opened EXPLICITLY, and a pair that cannot be opened fails the call, naming the two devices — a node whose
+  // links are down must not quietly run its exchange step through host memory (EHX_ALLOW_NO_PEER=1 accepts it: the
+  // copies then stage through the host, correct but slow).
+  const char* allow = getenv("EHX_ALLOW_NO_PEER");
+  const bool strict = !(allow && atoi(allow) != 0);
   for (int a : devs)
     for (int b : devs) {
       if (a == b) continue;
       int can = 0;
-      if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
-        if (hipSetDevice(a) == hipSuccess) (void)hipDeviceEnablePeerAccess(b, 0);
+      hipError_t pe = hipDeviceCanAccessPeer(&can, a, b);
+      if (pe == hipSuccess && can) {
+        pe = hipSetDevice(a);
+        if (pe == hipSuccess) pe = hipDeviceEnablePeerAccess(b, 0);
+        if (pe == hipErrorPeerAccessAlreadyEnabled) pe = hipSuccess;
+      } else if (pe == hipSuccess) {
+        pe = hipErrorPeerAccessUnsupported;
       }
-      (void)hipGetLastError();  // (already enabled / not supported: the copies then stage through the host)
+      (void)hipGetLastError();
+      if (pe != hipSuccess && strict)
+        return fail(EHX_ENODEVICE, "device %d cannot open peer access to device %d (%s): the shards' exchange step needs "
+                                   "it (EHX_ALLOW_NO_PEER=1 stages the copies through the host instead)",
+                    a, b, hipGetErrorString(pe));
     }
   HIP_TRY(hipSetDevice(devs[0]));
   E.devices = devs;

@@ -151,11 +151,19 @@ class DurableSpace:
     def freeze(self):
         # lock order everywhere: the store's lock BEFORE a space's (delete_space holds the store's lock and then takes
         # the space's; taking them the other way round here deadlocked a concurrent FreezeSpace / DeleteSpace)
-        with self._owner._mu:
-            with self._mu:
-                self._inner.freeze()
-                if self._owner._spaces.get(self._name) is self:  # (a stale handle of a deleted space records nothing)
-                    self._owner._catalog(_FREEZE, self._name, self.dims)
+        # ... but the store's lock is never HELD while waiting for a busy space (a long set_batch on this space — log
+        # append + engine write — would stall get_space / create_space / delete_space of every other space): the space's
+        # lock is tried for a moment under the store's, and if the space is busy both are let go before the next try.
+        while True:
+            with self._owner._mu:
+                if self._mu.acquire(timeout=0.02):
+                    try:
+                        self._inner.freeze()
+                        if self._owner._spaces.get(self._name) is self:  # (a stale handle of a deleted space records nothing)
+                            self._owner._catalog(_FREEZE, self._name, self.dims)
+                    finally:
+                        self._mu.release()
+                    return
 
     def __getattr__(self, name):  # get / nearest / keys_sorted / __len__ ... : straight through
         return getattr(self._inner, name)

@@ -145,7 +145,10 @@ typedef struct ehx_stats_t {
 /* Once per process (idempotent).  device_ids==NULL or n_devices==0 -> device 0.  Unsharded spaces live on the first
  * listed device; the shards of a space created with ehx_params.shards = G are spread over the whole list (one
  * process drives all of them: what a Go / C++ caller of this ABI uses on an 8-GPU node).  The one-process-per-GPU
- * form (torch.distributed + RCCL all-gather, embeddinghub_amd/sharded.py) lists one device per process. */
+ * form (torch.distributed + RCCL all-gather, embeddinghub_amd/sharded.py) lists one device per process.
+ * With more than one device listed, peer access is opened explicitly between every ordered pair (the shards' exchange
+ * step is a peer copy over xGMI); a pair that cannot be opened fails the call with EHX_ENODEVICE naming the two devices
+ * (environment EHX_ALLOW_NO_PEER=1: accept it, the copies then stage through host memory). */
 int ehx_init(const int* device_ids, int n_devices);
 int ehx_shutdown(void);
 int ehx_abi_version(void);
@@ -199,7 +202,14 @@ int ehx_knn_by_key(ehx_space* s, const char* key, size_t klen, uint32_t k, uint6
 
 /* ---- device-resident entry points (inputs/outputs already in HBM; `stream` is a hipStream_t
  *      passed as void*, NULL = default stream).  These are what a batching shim and bench.py
- *      call; ehx_knn above is ehx_knn_device plus the H2D/D2H copies. ---- */
+ *      call; ehx_knn above is ehx_knn_device plus the H2D/D2H copies.
+ *      Completion: the results are in place when `stream` reaches the point the call returned at — wait for the stream
+ *      (or an event recorded on it) before reading them.  Most paths have waited for the device themselves by the time
+ *      they return (every flat stage reads its verdict back); ONE query against a small flat shard (the exhaustive
+ *      canonical pass, EHX_SMALL_EXACT_BYTES) and graph searches return with work still queued on `stream`.  A writer
+ *      that rewrites rows in place waits for searches in flight on whatever stream they were given; a writer that only
+ *      appends does not need to (it touches rows beyond the row count the search was launched with, and growing the
+ *      arrays takes the space exclusively and drains the device first). ---- */
 int ehx_knn_device(ehx_space* s, void* stream, size_t n_queries, const float* d_queries, uint32_t k,
                    uint64_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count);
 /* k-way merge of per-shard results (RCCL all-gather output): lists laid out

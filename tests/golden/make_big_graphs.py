@@ -44,7 +44,8 @@ CONFIGS = {
     "s16_1m768": (1_000_000, 768, pyoracle.METRIC_COSINE, "manifold:16"),
     "s16_200k768": (200_000, 768, pyoracle.METRIC_COSINE, "manifold:16"),
 }
-NO_GRAPH_FILE = ("manifold1m768", "s16_1m768", "s16_200k768")
+NO_GRAPH_FILE = ("manifold1m768", "s16_1m768")   # (round 4: s16_200k768 keeps its graph — tests/test_graph_scale.py's
+                                                  # structured index with INDEPENDENT queries, recall 0.965 at ef = 40)
 EFS = (10, 100, 400)
 NQ, K = 256, 10
 
@@ -108,6 +109,8 @@ def make(name):
                                        qps_all_cores=round(qps_all, 1))
         print("[%s] ef=%d recall@10 %.4f n_dist/query %.0f" % (name, ef, recall, st["n_dist"] / NQ), flush=True)
     prof = os.path.join(ROOT, "profiles", "r03_cpu_hnsw_%s.json" % name)
+    if os.path.exists(prof) and os.environ.get("EHX_KEEP_PROFILE"):  # a re-run that only needs the graph file
+        prof = os.devnull
     with open(prof, "w") as f:  # the CPU baseline of the graph path, like for like (bench.py quotes these files)
         json.dump(meta, f, indent=1)
     if name in NO_GRAPH_FILE:

@@ -268,6 +268,28 @@ def test_gpus_2_launches_two_real_ranks():
     assert "launching 2 ranks" in r.stderr
 
 
+def test_gpus_4_dry_run_ranks_partition_gather_and_only_rank0_does_host_legs():
+    """the shape of the driver's scaling run, at 4 ranks — real launcher, four real processes, gloo
+    collectives, the product's sharded.py.  The shards are uneven (3003 rows over 4 ranks), every rank is handed its
+    batches as HOST buffers (double-buffered upload path), the merged answer is checked against the oracle over all
+    rows, rank 0 alone prints (and runs no single-GPU legs: no cpu_baseline, no graph legs, no config legs), and the
+    line reports the world size the process group itself returns."""
+    r = _run_bench_subprocess(SMALL + ["--gpus", "4", "--rows", "3003"], devices=4)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["config"]["world_size"] == 4 and out["scaling"] == "strong"
+    assert out["config"]["rows_per_rank"] == [750, 750, 750, 753] and sum(out["config"]["rows_per_rank"]) == 3003
+    assert "pinned host tensors" in out["config"]["timed_from"] and "row-shard x4" in out["config"]["parallelism"]
+    ex = out["exactness"]
+    assert ex["recall_at_10"] == 1.0 and ex["ids_identical_to_oracle"] and ex["dist_bytes_identical_to_oracle"]
+    assert ex["oracle_rows"] == 3003
+    for leg in ("cpu_baseline", "graph_path", "graph_path_structured", "configs", "single_query", "set_concurrent"):
+        assert leg not in out, leg
+    assert "device_resident_queries" in out        # (the same steps from HBM-resident batches, every rank)
+
+
 def test_gpus_2_on_a_one_gpu_box_fails_loudly():
     r = _run_bench_subprocess(SMALL + ["--gpus", "2"], devices=1)
     assert r.returncode != 0 and r.stdout.strip() == ""
