@@ -125,8 +125,9 @@ __device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* a, uint32_t 
 
 // LDS: q[ld] floats | R[ef_cap] u64 | S[64] u64 (sorted fresh keys) | batch[64] u64 | ids[64] u32 |
 //      F[ef_cap] u8 (slots of R a fresh key lands on, during a merge)
+//      then (two-wave form) hd[64] f32 (the helper wave's distances) | ctrl[4] u32
 size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap) {
-  return (size_t)ld * 4 + (size_t)ef_cap * 8 + 64 * 8 * 2 + 64 * 4 + (((size_t)ef_cap + 15) & ~(size_t)15);
+  return (size_t)ld * 4 + (size_t)ef_cap * 8 + 64 * 8 * 2 + 64 * 4 + (((size_t)ef_cap + 15) & ~(size_t)15) + 64 * 4 + 16;
 }
 
 // A/B builds: cap the registers so that this many waves share a SIMD (0 = the compiler's choice).  Measured in round 3:
@@ -135,13 +136,20 @@ size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap) {
 #ifndef EHX_GRAPH_WAVES
 #define EHX_GRAPH_WAVES 0
 #endif
-template <int METRIC01, bool SCALE>
+// WAVES = 2 (round 4, VERDICT r01-r03 "intra-query parallelism"): a HELPER wave per query.  At batch 1024 a SIMD holds
+// one query wave and long rows take two passes of 16 rows per expansion (27 fresh neighbours on average, one 4-lane
+// group per row): the row phase is ~70 % of an expansion at d = 768.  The helper takes rows 16.. of every distance batch
+// — the same 4-lane-group arithmetic on the same rows, so traversal, ids, distances and counters stay bit-identical —
+// and the two passes run side by side on two SIMDs.  Protocol: wave 0 publishes (ids_l, count), barrier, both compute,
+// barrier, wave 0 reads the helper's distances from LDS.  Everything else (R, visited, merge) is wave 0's alone.
+template <int METRIC01, bool SCALE, int WAVES>
 #if EHX_GRAPH_WAVES
 __attribute__((amdgpu_waves_per_eu(EHX_GRAPH_WAVES, EHX_GRAPH_WAVES)))
 #endif
-__global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
+__global__ __launch_bounds__(64 * WAVES) void graph_search_kernel(const GraphArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t qi = blockIdx.x;
   float* qs = (float*)smem;
   uint64_t* R = (uint64_t*)(smem + (size_t)a.ld * 4);
@@ -149,17 +157,36 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   uint64_t* batch = S + 64;
   uint32_t* ids_l = (uint32_t*)(batch + 64);
   uint8_t* F = (uint8_t*)(ids_l + 64);
+  float* hd = (float*)(F + (((size_t)a.ef_cap + 15) & ~(size_t)15));
+  volatile uint32_t* ctrl = (volatile uint32_t*)(hd + 64);
   uint32_t* vis = a.visited + (size_t)qi * a.vis_words;
   uint32_t* vlog = a.vislog + (size_t)qi * a.vislog_cap;
   uint32_t n_logged = 0;  // rows marked visited so far (wave-uniform)
-  for (uint32_t i = lane; i < a.ef_cap; i += 64) F[i] = 0;
+  if (wv == 0)
+    for (uint32_t i = lane; i < a.ef_cap; i += 64) F[i] = 0;
 
 #if EHX_G_COOP
-  for (uint32_t i = lane; i < a.ld; i += 64) qs[search_copy_pos(i)] = a.Q[(size_t)qi * a.ld + i];
+  for (uint32_t i = threadIdx.x; i < a.ld; i += 64 * WAVES) qs[search_copy_pos(i)] = a.Q[(size_t)qi * a.ld + i];
 #else
-  for (uint32_t i = lane; i < a.ld; i += 64) qs[i] = a.Q[(size_t)qi * a.ld + i];
+  for (uint32_t i = threadIdx.x; i < a.ld; i += 64 * WAVES) qs[i] = a.Q[(size_t)qi * a.ld + i];
 #endif
-  EHX_GSYNC();
+  if (WAVES > 1) __syncthreads();
+  else EHX_GSYNC();
+#if EHX_G_COOP
+  if (WAVES > 1 && wv == 1) {  // the helper wave: rows 16.. of every distance batch wave 0 publishes
+    for (;;) {
+      __syncthreads();  // A: ids_l and the count are published
+      const uint32_t cnt = ctrl[0];
+      if (cnt == 0xFFFFFFFFu) break;
+      if (cnt > 16) {
+        const float d = wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l + 16, cnt - 16, lane);
+        if ((uint32_t)lane < cnt - 16) hd[lane] = d;
+      }
+      __syncthreads();  // B: the distances are published
+    }
+    return;
+  }
+#endif
 
   unsigned long long n_dist = 0, n_hops0 = 0, n_hops_up = 0;
 
@@ -169,6 +196,14 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   // canonical distances of rows ids_l[0..count): 16 rows per pass, one 4-lane group per row reading the
   // search copy (canon_dist_group_t); lane p (< count) gets the distance of row p
   auto lane_dist = [&](uint32_t count) -> float {
+    if (WAVES > 1) {
+      if (lane == 0) ctrl[0] = count;
+      __syncthreads();  // A
+      float d = wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l, count < 16 ? count : 16, lane);
+      __syncthreads();  // B
+      if (lane >= 16 && (uint32_t)lane < count) d = hd[lane - 16];
+      return d;
+    }
     return wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l, count, lane);
   };
 #else
@@ -443,8 +478,14 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
     EHX_PROF(7)
   }
 
+  if (WAVES > 1) {  // release the helper wave
+    if (lane == 0) ctrl[0] = 0xFFFFFFFFu;
+    __syncthreads();
+  }
   // ---- leave the visited bitmap all-zero: clear the words of the logged rows (or everything, if the log overflowed)
-  __syncthreads();  // the log was written by other lanes, through global memory: a real fence, once per query
+  // (the log was written by other lanes, through global memory: a real fence, once per query)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   if (a.vislog_cap == 0) {
     // (A/B mode: the host clears the bitmaps with a memset before every launch)
   } else if (n_logged <= a.vislog_cap) {
@@ -474,12 +515,31 @@ __global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
 hipError_t launch_graph_search(const GraphArgs& a, hipStream_t st) {
   const size_t lds = graph_lds_bytes(a.ld, a.ef_cap);
   static DynLdsAttr attr;
-  const void* fns[3] = {(const void*)graph_search_kernel<0, false>, (const void*)graph_search_kernel<1, true>,
-                        (const void*)graph_search_kernel<1, false>};
-  if (hipError_t e = attr.ensure(fns, 3, lds); e != hipSuccess) return e;
-  if (a.metric == 0) hipLaunchKernelGGL((graph_search_kernel<0, false>), dim3(a.nq), dim3(64), lds, st, a);
-  else if (a.metric == 2) hipLaunchKernelGGL((graph_search_kernel<1, true>), dim3(a.nq), dim3(64), lds, st, a);
-  else hipLaunchKernelGGL((graph_search_kernel<1, false>), dim3(a.nq), dim3(64), lds, st, a);
+  const void* fns[6] = {(const void*)graph_search_kernel<0, false, 1>, (const void*)graph_search_kernel<1, true, 1>,
+                        (const void*)graph_search_kernel<1, false, 1>, (const void*)graph_search_kernel<0, false, 2>,
+                        (const void*)graph_search_kernel<1, true, 2>, (const void*)graph_search_kernel<1, false, 2>};
+  if (hipError_t e = attr.ensure(fns, 6, lds); e != hipSuccess) return e;
+  // The helper wave (EHX_GRAPH_HELPER=1) is OFF by default: measured on GPU-built indexes, same box, batch 1024
+  // (profiles/r04_j_graph_*_helper{0,1}.jsonl): 2 M x 768 ef 100 2.311 -> 2.257 ms, ef 400 7.83 -> 7.74 ms, 1 M x 384
+  // ef 200 2.094 -> 2.057 ms (-1..2 %), batch 2048 +1..3 %.  Splitting an expansion's row fetches over two waves does not
+  // shorten them: at 3-KB rows the kernel already moves 4.7-5.1 TB/s of RANDOM rows, 80-86 % of what the part delivers
+  // for that access pattern with every SIMD full of gather waves (scripts/ubench/gather_rows.hip: 5.9 TB/s) — the row
+  // phase is bound by the memory system, not by how many loads one wave keeps in flight.
+  static const int helper_env = [] {
+    const char* e = getenv("EHX_GRAPH_HELPER");
+    return e ? atoi(e) : 0;
+  }();
+  const bool pairable = a.dims <= 256 && (a.dims == 32 || a.dims == 64 || a.dims == 96 || a.dims == 128 || a.dims == 192 || a.dims == 256);
+  const bool helper = helper_env != 0 && !pairable && a.nq <= 2048;
+  if (helper) {
+    if (a.metric == 0) hipLaunchKernelGGL((graph_search_kernel<0, false, 2>), dim3(a.nq), dim3(128), lds, st, a);
+    else if (a.metric == 2) hipLaunchKernelGGL((graph_search_kernel<1, true, 2>), dim3(a.nq), dim3(128), lds, st, a);
+    else hipLaunchKernelGGL((graph_search_kernel<1, false, 2>), dim3(a.nq), dim3(128), lds, st, a);
+  } else {
+    if (a.metric == 0) hipLaunchKernelGGL((graph_search_kernel<0, false, 1>), dim3(a.nq), dim3(64), lds, st, a);
+    else if (a.metric == 2) hipLaunchKernelGGL((graph_search_kernel<1, true, 1>), dim3(a.nq), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((graph_search_kernel<1, false, 1>), dim3(a.nq), dim3(64), lds, st, a);
+  }
   return hipGetLastError();
 }
 
