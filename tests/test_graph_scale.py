@@ -4,11 +4,12 @@ recall@k").  The oracle-built graphs come from tests/golden/make_big_graphs.py (
 
   (a) the oracle's graph, IMPORTED: the engine's search must return the oracle's ids, distance bytes and counts for
       ef = 10 / 100 / 400 (the oracle's own results are stored next to the graph);
-      (the fourth configuration, man200k768, is STRUCTURED data — rows on a 32-dim manifold written through
-      ehx_set_batch in chunks like bench.py's structured leg; its queries are the ones that leg used in round 3, whose
-      generator seed coincides with a corpus chunk's: each is a corpus row's latent point under fresh noise, i.e. a
-      near-duplicate lookup — a regime with recall near 1 at every ef, which the identity and the recall-parity checks
-      below do not depend on; bench.py draws independent queries now);
+      (the fourth configuration, s16_200k768, is STRUCTURED data — rows on a 16-dim manifold + 5 % noise written
+      through ehx_set_batch in chunks like bench.py's structured leg, with that leg's INDEPENDENT queries (seeds
+      SEED_QUERY + 1000 + b): recall 0.74 / 0.88 / 0.965 / 0.998 / 1.0 at ef 10 / 20 / 40 / 100 / 200, so the +-0.005
+      gate of (b) is tested where recall is ~0.95 and still moving.  Rounds 2-3 used man200k768, whose queries were
+      corpus rows' latent points under fresh noise — a near-duplicate lookup with recall 0.97-0.99 at every ef;
+      VERDICT r03 #6);
   (b) the same rows BUILT ON THE GPU in rounds of 4096 (what every >= 1 M-row number of this repo uses; hnswlib's
       multi-threaded add_items is the reference analogue, sdk/python/offlinehub.py:89): recall@10 against the exact
       answer, at equal ef, within 0.005 of the oracle-built graph's (BASELINE.md §2 gate), over 4096 queries;
@@ -43,10 +44,15 @@ def _upper(z):
             for i, (n, l) in enumerate(zip(z["upper_node"], z["upper_level"]))}
 
 
+def _structured(meta):
+    return isinstance(meta["normalize"], str) and meta["normalize"].startswith("manifold")
+
+
 def _manifold(meta):
-    """bench.py's structured rows (run_structured_leg) and tests/golden/make_big_graphs.py's: z ~ N(0, I_32) times a fixed
-    random 32 x d matrix, plus 5 % isotropic noise, normalised"""
-    d, R = meta["dims"], 32
+    """bench.py's structured rows (run_structured_leg) and tests/golden/make_big_graphs.py's: z ~ N(0, I_R) times a fixed
+    random R x d matrix, plus 5 % isotropic noise, normalised ("manifold": R = 32, "manifold:R")"""
+    d = meta["dims"]
+    R = int(meta["normalize"].split(":")[1]) if ":" in meta["normalize"] else 32
     A = np.random.default_rng(20250213).standard_normal((R, d)).astype(np.float32) / np.sqrt(R)
 
     def gen(seed, rows):
@@ -62,7 +68,7 @@ def _fill(space, meta):
     """the configuration's rows into `space`: EHX-GAUSS-1 generated on the device, or the structured rows through
     ehx_set_batch in bench.py's chunks of 65536"""
     n = meta["rows"]
-    if meta["normalize"] == "manifold":
+    if _structured(meta):
         gen, chunk = _manifold(meta), 65536
         for i0 in range(0, n, chunk):
             m = min(chunk, n - i0)
@@ -72,9 +78,11 @@ def _fill(space, meta):
 
 
 def _queries(meta, nq):
-    if meta["normalize"] == "manifold":
+    if _structured(meta):
         gen = _manifold(meta)
-        return np.concatenate([gen(ehx.SEED_QUERY + b, 1024) for b in range((nq + 1023) // 1024)])[:nq]
+        # "manifold:R": independent queries (bench.py's q_seed0 = SEED_QUERY + 1000); "manifold": round 3's seeds
+        q0 = ehx.SEED_QUERY + (1000 if ":" in meta["normalize"] else 0)
+        return np.concatenate([gen(q0 + b, 1024) for b in range((nq + 1023) // 1024)])[:nq]
     return pyoracle.gen_rows(ehx.SEED_QUERY, 0, nq, meta["dims"], normalize=meta["normalize"])
 
 
@@ -83,7 +91,7 @@ def _recall(ids, truth):
     return float(np.mean([len(set(ids[i].tolist()) & set(truth[i].tolist())) / k for i in range(truth.shape[0])]))
 
 
-@pytest.mark.parametrize("name", ["cos20k768", "cos200k768", "l2_1m128", "man200k768"])
+@pytest.mark.parametrize("name", ["cos20k768", "cos200k768", "l2_1m128", "s16_200k768"])
 def test_oracle_graph_at_scale_imported_and_gpu_built(name):
     z, meta = _load(name)
     n, d, norm = meta["rows"], meta["dims"], meta["normalize"]
@@ -99,7 +107,7 @@ def test_oracle_graph_at_scale_imported_and_gpu_built(name):
     # the oracle ran on.  Identity with the oracle's stored results is demanded when the rows are the same bytes (always
     # for EHX-GAUSS-1, whose generator is bit-exact everywhere); otherwise the imported graph is still the oracle's
     # graph over rows that differ in their last bits, and at most 5 % of the queries may come out differently.
-    same_rows = meta["normalize"] != "manifold"
+    same_rows = not _structured(meta)
     if not same_rows and "rows_sha1" in meta:
         import hashlib
         gen, chunk = _manifold(meta), 65536
