@@ -240,6 +240,12 @@ struct ehx_space {
   int g_maxlevel = -1;
   DevBuf<uint32_t> dVisited;
   unsigned long long* hUncertPin = nullptr;  // pinned landing place of a batch's verdict (uncertified-query count)
+  // one query per call against a small flat shard: one launch, host-visible in / out (knn_host_direct)
+  char* hOnePin = nullptr;                   // host-coherent pinned: query | ids[64] | dist[64] | count | flag
+  DevBuf<uint64_t> dOnePart;                 // [n_blocks][64] workgroup lists
+  uint32_t* dOneTicket = nullptr;
+  uint32_t one_seq = 0;
+  std::atomic<uint64_t> n_one_launch{0};
   char* hSmallPin = nullptr;                 // pinned staging of small host calls: [queries | ids, distances, counts]
   DevBuf<uint64_t> dSmallOut;                // their results, one block (one device-to-host copy)
   // Host-pointer batches (ehx_knn with more than a handful of queries): every call in flight owns a SLOT — pinned
@@ -393,6 +399,10 @@ struct ehx_space {
     hUncertPin = nullptr;
     if (hSmallPin) (void)hipHostFree(hSmallPin);
     hSmallPin = nullptr;
+    if (hOnePin) (void)hipHostFree(hOnePin);
+    hOnePin = nullptr;
+    dOnePart.release();
+    fr(dOneTicket);
     for (auto& h : hslot) {
       if (h.pin) (void)hipHostFree(h.pin);
       h.pin = nullptr;
@@ -2800,6 +2810,77 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
   const size_t out_bytes = nk * (sizeof(uint64_t) + sizeof(float)) + n_queries * sizeof(uint32_t);
   if (qbytes <= kSmallCall && out_bytes <= kSmallCall) {
     std::lock_guard<std::mutex> sl(s->scratch_mu);
+    // ONE query against a small flat shard — the reference's request (server.cc:172-210; BASELINE configs[0]): a single
+    // launch reads the query from host-visible memory, scans every row in the oracle's arithmetic, and the last
+    // workgroup writes the answer into host-visible memory and raises a flag this thread spins on (k_flat.hip:
+    // single_query_kernel).  10 k x 128: ~130 us through the three-launch path -> see DESIGN §e.
+    static const uint64_t one_bytes = [] {
+      const char* e = getenv("EHX_SMALL_EXACT_BYTES");
+      return e ? strtoull(e, nullptr, 10) : (512ull << 20);
+    }();
+    static const bool one_on = [] {
+      const char* e = getenv("EHX_ONE_LAUNCH");
+      return e ? atoi(e) != 0 : true;
+    }();
+    if (one_on && n_queries == 1 && k <= 64 && s->params.mode == EHX_MODE_FLAT && s->scan_sel == EHX_SCAN_AUTO && s->n > 0 &&
+        s->ld <= 4096 && (uint64_t)s->n * s->ld * s->esz <= one_bytes) {
+      constexpr size_t kOneQ = 16384;   // query slot (ld <= 4096 floats)
+      if (!s->hOnePin) {
+        HIP_TRY(hipHostMalloc((void**)&s->hOnePin, kOneQ + 2048, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(s->hOnePin, 0, kOneQ + 2048);
+      }
+      if (!s->dOneTicket) {
+        HIP_TRY(hipMalloc((void**)&s->dOneTicket, sizeof(uint32_t)));
+        HIP_TRY(hipMemset(s->dOneTicket, 0, sizeof(uint32_t)));
+      }
+      const uint32_t rpb = (uint32_t)std::max<uint64_t>(64, ((s->n + 1023) / 1024 + 63) / 64 * 64);  // <= 1024 workgroups
+      const uint32_t n_blocks = (uint32_t)((s->n + rpb - 1) / rpb);
+      if ((rc = s->dOnePart.ensure((size_t)n_blocks * 64))) return rc;
+      if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev[3], 0));  // (device searches queued on other streams)
+      char* h = s->hOnePin;
+      memcpy(h, queries, qbytes);
+      SingleQueryArgs a;
+      a.q_in = (const float*)h;
+      a.X = s->dX;
+      a.inv_norm = s->dInv;
+      a.part = s->dOnePart.p;
+      a.ticket = s->dOneTicket;
+      a.out_ids = (uint64_t*)(h + kOneQ);
+      a.out_dist = (float*)(h + kOneQ + 512);
+      a.out_count = (uint32_t*)(h + kOneQ + 768);
+      a.done_flag = (uint32_t*)(h + kOneQ + 1024);
+      a.seq = ++s->one_seq ? s->one_seq : ++s->one_seq;   // (never 0: the buffer starts zeroed)
+      a.x_half = (uint32_t)s->x_half;
+      a.n = (uint32_t)s->n;
+      a.dims = s->dims;
+      a.ld = s->ld;
+      a.rows_per_block = rpb;
+      a.k = k;
+      a.metric = s->metric;
+      HIP_TRY(launch_single_query(a, n_blocks, s->stream));
+      volatile uint32_t* flag = (volatile uint32_t*)a.done_flag;
+      bool seen = false;
+      for (uint32_t spin = 0; spin < 4000000u; ++spin) {   // ~ tens of milliseconds at most, then ask the runtime
+        if (*flag == a.seq) {
+          seen = true;
+          break;
+        }
+        __builtin_ia32_pause();
+      }
+      if (!seen) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (*flag != a.seq) return fail(EHX_EINTERNAL, "single-query kernel finished without publishing its result");
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      memcpy(out_ids, a.out_ids, k * sizeof(uint64_t));
+      memcpy(out_dist, a.out_dist, k * sizeof(float));
+      out_count[0] = *a.out_count;
+      s->n_queries += 1;
+      s->n_exhaustive += 1;
+      s->n_one_launch += 1;
+      s->n_dist += s->n;
+      return EHX_OK;
+    }
     if ((rc = s->dQraw.ensure(n_queries * s->dims))) return rc;
     if (!s->hSmallPin) HIP_TRY(hipHostMalloc((void**)&s->hSmallPin, 2 * kSmallCall, hipHostMallocDefault));
     if ((rc = s->dSmallOut.ensure(kSmallCall / sizeof(uint64_t)))) return rc;

@@ -693,6 +693,21 @@ hipError_t launch_exhaustive(const float* Q, const void* X, int x_half, const fl
                              uint32_t ld, int metric, uint32_t rows_per_block, uint32_t n_blocks, uint32_t nq,
                              const uint64_t* floor, uint64_t* out, hipStream_t st);
 hipError_t launch_set_floor(const uint64_t* merged, uint32_t nq, uint64_t* floor, hipStream_t st);
+// one query from host-visible memory against a small shard in one launch (k_flat.hip: single_query_kernel)
+struct SingleQueryArgs {
+  const float* q_in;        // [dims] raw query (host-visible pinned memory, or device memory)
+  const void* X;            // rows, fp32 or fp16 (x_half)
+  const float* inv_norm;    // [cap] (cosine)
+  uint64_t* part;           // [n_blocks][64] scratch: every workgroup's best keys
+  uint32_t* ticket;         // device counter, 0 between calls
+  uint64_t* out_ids;        // [k]  host-visible
+  float* out_dist;          // [k]  host-visible
+  uint32_t* out_count;      // [1]  host-visible
+  uint32_t* done_flag;      // host-visible: set to `seq` when the results are in place
+  uint32_t seq, x_half, n, dims, ld, rows_per_block, k;
+  int metric;
+};
+hipError_t launch_single_query(const SingleQueryArgs& a, uint32_t n_blocks, hipStream_t st);
 
 // prepared queries: copy into the padded [q_rows][ld] buffer, L2-normalise for cosine
 hipError_t launch_prep_queries(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld,

@@ -276,6 +276,128 @@ __global__ __launch_bounds__(256) void exhaustive_kernel(const float* __restrict
   if (tid < 64) out[((size_t)j * gridDim.x + b) * 64 + tid] = best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ONE query from host memory against a small shard, in ONE launch (round 4; BASELINE configs[0], the reference's own
+// request shape: one NearestNeighbor RPC = one query, server.cc:172-210).  The three-launch exhaustive path took
+// ~130 us per ehx_knn call on 10 000 x 128 rows — two staged copies, three launches and a stream synchronisation, for
+// 5 MB of rows.  Here the query is read straight from host-visible pinned memory, every workgroup prepares it itself
+// (cosine: the canonical sequential-sum norm), computes the canonical distance of its rows and publishes its 64 best
+// keys; the LAST workgroup to finish (a ticket) merges the lists and writes ids, distances and the count straight into
+// host-visible memory, then raises a flag the host is spinning on: no copy, no synchronisation call.
+// ---------------------------------------------------------------------------------------------
+template <typename XT>
+__global__ __launch_bounds__(256) void single_query_kernel(const SingleQueryArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem1[];
+  float* qs = (float*)smem1;                       // [ld] prepared query
+  float* sq = qs + a.ld;                           // [ld] squares (cosine norm)
+  __shared__ uint64_t keys[64];
+  __shared__ uint64_t wbest[4][64];
+  __shared__ uint32_t last_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t b = blockIdx.x;
+  for (uint32_t i = tid; i < a.ld; i += 256) {
+    const float v = i < a.dims ? a.q_in[i] : 0.0f;
+    qs[i] = v;
+    sq[i] = ex_mul(v, v);
+  }
+  __syncthreads();
+  if (a.metric == 2) {
+    if (tid == 0) {  // ONE sequential sum, hnswlib-python's order (prep_query_row's arithmetic)
+      float sum = 0.0f;
+      uint32_t i = 0;
+      for (; i + 4 <= a.dims; i += 4) {
+        const float4 v = *(const float4*)(sq + i);
+        sum = ex_add(ex_add(ex_add(ex_add(sum, v.x), v.y), v.z), v.w);
+      }
+      for (; i < a.dims; ++i) sum = ex_add(sum, sq[i]);
+      sq[0] = ex_div(1.0f, ex_add(ex_sqrt(sum), 1e-30f));
+    }
+    __syncthreads();
+    const float inv = sq[0];
+    __syncthreads();
+    for (uint32_t i = tid; i < a.dims; i += 256) qs[i] = ex_mul(qs[i], inv);
+    __syncthreads();
+  }
+  const XT* X = (const XT*)a.X;
+  const int g = tid >> 2, sub = tid & 3;
+  const bool scale_x = a.metric == 2;
+  const uint32_t r0 = b * a.rows_per_block;
+  const uint32_t r1 = r0 + a.rows_per_block < a.n ? r0 + a.rows_per_block : a.n;
+  uint64_t best = kKeyInf;
+  for (uint32_t base = r0; base < r1; base += 64) {
+    const uint32_t id = base + (uint32_t)g;
+    float d = __builtin_inff();
+    if (id < r1) {
+      const float xs = scale_x ? a.inv_norm[id] : 1.0f;
+      d = canon_dist(a.metric == 0 ? 0 : 1, qs, X + (size_t)id * a.ld, xs, scale_x, a.dims, sub);
+    }
+    if (sub == 0) keys[g] = (id < r1 && d == d) ? (((uint64_t)f32_to_ordered(d) << 32) | id) : kKeyInf;  // NaN: no neighbour
+    __syncthreads();
+    if (tid < 64) {
+      const uint64_t key = wave_sort64(keys[tid], tid);
+      const uint64_t rv = __shfl(key, 63 - tid, 64);
+      const uint64_t m = best < rv ? best : rv;
+      best = wave_bitonic_merge64(m, tid);
+    }
+    __syncthreads();
+  }
+  if (tid < 64) a.part[(size_t)b * 64 + tid] = best;
+  __threadfence();   // this workgroup's list is visible device-wide before its ticket is
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = t == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last_s) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other workgroups' lists (other XCDs' L2s)
+  // the last workgroup merges the gridDim.x lists: wave w takes lists w, w + 4, ...; then wave 0 the four results
+  uint64_t mine = kKeyInf;
+  for (uint32_t c = (uint32_t)wv; c < gridDim.x; c += 4) {
+    const uint64_t v = __hip_atomic_load(a.part + (size_t)c * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__shfl(v, 0, 64) >= __shfl(mine, 63, 64)) continue;
+    const uint64_t rv = __shfl(v, 63 - lane, 64);
+    const uint64_t m = mine < rv ? mine : rv;
+    mine = wave_bitonic_merge64(m, lane);
+  }
+  wbest[wv][lane] = mine;
+  __syncthreads();
+  if (wv == 0) {
+    uint64_t fin = wbest[0][lane];
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) {
+      const uint64_t v = wbest[w2][lane];
+      const uint64_t rv = __shfl(v, 63 - lane, 64);
+      const uint64_t m = fin < rv ? fin : rv;
+      fin = wave_bitonic_merge64(m, lane);
+    }
+    const uint32_t nvalid = (uint32_t)__builtin_popcountll(__ballot(fin != kKeyInf));
+    const uint32_t cnt = nvalid < a.k ? nvalid : a.k;
+    if ((uint32_t)lane < a.k) {
+      const bool ok = (uint32_t)lane < cnt;
+      a.out_ids[lane] = ok ? (uint64_t)(uint32_t)fin : ~0ull;
+      a.out_dist[lane] = ok ? ordered_to_f32((uint32_t)(fin >> 32)) : __builtin_inff();
+    }
+    if (lane == 0) {
+      a.out_count[0] = cnt;
+      __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+    }
+    __threadfence_system();
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0) __hip_atomic_store(a.done_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+hipError_t launch_single_query(const SingleQueryArgs& a, uint32_t n_blocks, hipStream_t st) {
+  const size_t lds = (size_t)a.ld * 8;
+  static DynLdsAttr attr;
+  const void* fns[2] = {(const void*)single_query_kernel<float>, (const void*)single_query_kernel<__half>};
+  if (hipError_t e = attr.ensure(fns, 2, lds + 4096); e != hipSuccess) return e;
+  if (a.x_half) hipLaunchKernelGGL(single_query_kernel<__half>, dim3(n_blocks), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(single_query_kernel<float>, dim3(n_blocks), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
 // next page's floor = the 64th (last) key of this page; exhausted queries get INF (nothing above it)
 __global__ __launch_bounds__(256) void set_floor_kernel(const uint64_t* __restrict__ merged, uint32_t nq,
                                                         uint64_t* __restrict__ floor) {

@@ -383,3 +383,58 @@ def test_full_size_split_invariance_and_sample_vs_oracle():
     assert sdist.tobytes() == odist.tobytes()
     for s in (whole, lo, hi, sub):
         s.drop()
+
+
+# ---- one query per call: the reference's request shape (server.cc:172-210; BASELINE configs[0]) ------------------
+# A single query from host memory against a small flat shard takes ONE launch (k_flat.hip: single_query_kernel: the
+# query is read from host-visible memory, the last workgroup writes the answer back and raises a flag).  Everything the
+# three-launch path guaranteed must hold: the oracle's ids and distance bytes, counts when rows < k, NaN rows skipped,
+# rows visible as soon as their Set returned, in-place updates seen by the next call.
+@pytest.mark.parametrize("n,d,k", [(1, 3, 10), (5, 100, 10), (64, 128, 10), (1000, 33, 48), (10000, 128, 10),
+                                   (20000, 768, 10), (3000, 1536, 5), (70000, 64, 10)])
+@pytest.mark.parametrize("em,om", METRICS)
+@pytest.mark.parametrize("dtype", [ehx.DTYPE_F32, ehx.DTYPE_F16])
+def test_one_query_per_call_is_the_oracle(n, d, k, em, om, dtype):
+    rng = np.random.default_rng(n * 31 + d)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((12, d)).astype(np.float32)
+    Q[0] = X[n // 2]                                   # a stored row itself
+    s = ehx.Space.unique("one", d, metric=em, dtype=dtype)
+    s.set_batch(_keys(n), X)
+    Xs = X.astype(np.float16).astype(np.float32) if dtype == ehx.DTYPE_F16 else X
+    s.stats_reset()
+    for i in range(Q.shape[0]):
+        _check(s, Xs, Q[i:i + 1], k, om)
+    st = s.stats()
+    assert st["n_queries"] == Q.shape[0] and st["n_exhaustive"] == Q.shape[0] and st["n_uncertified"] == 0
+    # a batch in between (other engines, other buffers), then single queries again
+    _check(s, Xs, Q, k, om)
+    _check(s, Xs, Q[3:4], k, om)
+    # an in-place update and an append are seen by the very next call
+    X2 = Xs.copy()
+    X2[0] = np.float32(0.5) * Q[5]
+    s.set("k0", X2[0])
+    new = (Q[6] * np.float32(1.0001)).astype(np.float32)
+    s.set("fresh", new)
+    if dtype == ehx.DTYPE_F16:
+        X2[0] = X2[0].astype(np.float16).astype(np.float32)
+        new = new.astype(np.float16).astype(np.float32)
+    X2 = np.concatenate([X2, new[None, :]])
+    for i in (5, 6, 7):
+        _check(s, X2, Q[i:i + 1], k, om)
+    s.drop()
+
+
+def test_one_query_per_call_skips_nan_rows_and_handles_zero_queries():
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((300, 16)).astype(np.float32)
+    X[7, 2] = np.nan
+    X[11, 0] = np.inf
+    s = ehx.Space.unique("one-nan", 16, metric=ehx.METRIC_COSINE)
+    s.set_batch(_keys(300), X)
+    q = rng.standard_normal((1, 16)).astype(np.float32)
+    ids, dist, cnt = s.knn(q, 10)
+    assert cnt[0] == 10 and np.isfinite(dist).all() and 7 not in ids and 11 not in ids
+    ids, dist, cnt = s.knn(np.zeros((1, 16), np.float32), 10)       # a zero query: cosine distance 1 to everything
+    assert cnt[0] == 10
+    s.drop()
