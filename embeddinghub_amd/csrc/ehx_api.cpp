@@ -310,12 +310,30 @@ struct ehx_space {
   DevBuf<uint32_t> dUflags, dFbCnt, dFbIdx;
   DevBuf<uint64_t> dFbIds;
   unsigned long long* dUncert16 = nullptr;  // queries the filter pass could not certify
-  // int8 filter scratch: query tiles + parameters, per-pass thresholds, sample scores, pools, running best 256
-  DevBuf<int8_t> dQ8;
-  DevBuf<float4> dQp8;
-  DevBuf<float> dThr8, dSample8;
-  DevBuf<uint64_t> dPool, dMerged8;
-  DevBuf<uint32_t> dI8Ctl;  // [q_rows] pool counts | [q_rows] overflow flags | [256] lock-step counters
+  // int8 filter scratch: everything ONE in-flight batch of the int8 pipeline owns — prepared queries, query tiles +
+  // parameters, per-pass thresholds, sample scores, pools, running best list, verdict, timing events.  TWO sets: a host
+  // caller's batch can be enqueued behind another caller's on the space's stream while that one still waits for its
+  // verdict (knn_host_direct), so the scan kernels of consecutive batches run back to back with no host in between.
+  struct I8Set {
+    DevBuf<float> dQ;
+    DevBuf<int8_t> dQ8;
+    DevBuf<float4> dQp8;
+    DevBuf<float2> dQuv;
+    DevBuf<float> dThr8, dSample8;
+    DevBuf<uint64_t> dPool, dMerged8;
+    DevBuf<uint32_t> dI8Ctl;  // [q_rows] pool counts | [q_rows] overflow flags | [256] lock-step counters
+    DevBuf<uint32_t> dUflags;
+    unsigned long long* dUncert = nullptr;
+    unsigned long long* hUncertPin = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start | scan start | scan end | all enqueued work done
+    hipEvent_t verdict = nullptr;                            // blocking-sync: the verdict has landed in hUncertPin
+    bool ev_valid = false;
+    hipEvent_t ring[64][2] = {};
+    uint64_t ring_count = 0;
+    std::mutex mu;
+  };
+  I8Set i8set[2];
+  std::atomic<uint32_t> i8_next_set{0};
   std::atomic<uint64_t> n_filter_queries{0}, n_filter_fallback{0}, n_exhaustive{0}, n_uncertified_final{0};
   std::atomic<uint64_t> n_i8_queries{0}, n_i8_fallback{0};
   float* hStage = nullptr;  // pinned staging (Set / Get / query upload)
@@ -383,13 +401,33 @@ struct ehx_space {
     fr(dPerm8);
     dTileList.release();
     fr(dUnsafe8);
-    dQ8.release();
-    dQp8.release();
-    dThr8.release();
-    dSample8.release();
-    dPool.release();
-    dMerged8.release();
-    dI8Ctl.release();
+    for (auto& c : i8set) {
+      c.dQ.release();
+      c.dQ8.release();
+      c.dQp8.release();
+      c.dQuv.release();
+      c.dThr8.release();
+      c.dSample8.release();
+      c.dPool.release();
+      c.dMerged8.release();
+      c.dI8Ctl.release();
+      c.dUflags.release();
+      fr(c.dUncert);
+      if (c.hUncertPin) (void)hipHostFree(c.hUncertPin);
+      c.hUncertPin = nullptr;
+      for (auto& e : c.ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+      }
+      if (c.verdict) (void)hipEventDestroy(c.verdict);
+      c.verdict = nullptr;
+      c.ev_valid = false;
+      for (auto& pr : c.ring)
+        for (auto& e : pr) {
+          if (e) (void)hipEventDestroy(e);
+          e = nullptr;
+        }
+    }
     dGPack.release();
     dOutPack.release();
     if (xev) (void)hipEventDestroy(xev);
@@ -637,6 +675,15 @@ int ensure_rows(ehx_space* s, uint64_t rows) {
 }
 
 bool valid_space(ehx_space* s) { return s != nullptr; }
+
+// work enqueued on stream `st` from here on starts after every search of this space that is already in flight (whatever
+// stream it was given, whichever scratch set it runs in)
+int wait_searches_in_flight(ehx_space* s, hipStream_t st) {
+  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
+  for (auto& o : s->i8set)
+    if (o.ev_valid) HIP_TRY(hipStreamWaitEvent(st, o.ev[3], 0));
+  return EHX_OK;
+}
 
 // ---- graph mode: GPU-side insertion of rows [id0, id0+count) (already in HBM, stats computed) ----
 // hnswlib addPoint semantics (index.cc:36).  batch == 1: strictly sequential (the reference's
@@ -1053,7 +1100,10 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
     HIP_TRY(hipMalloc((void**)&s->dGraphCounters, kGraphCounters * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(s->dGraphCounters, 0, kGraphCounters * sizeof(unsigned long long)));
   }
-  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
+  {
+    int rcw = wait_searches_in_flight(s, st);
+    if (rcw) return rcw;
+  }
   HIP_TRY(hipEventRecord(s->ev[0], st));
   HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, q_rows, s->metric, s->dQ.p, st));
   GraphArgs a;
@@ -1196,7 +1246,10 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
   }
   // scratch buffers are shared by all callers: order this pipeline after the previous one even
   // when it was enqueued on a different stream
-  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
+  {
+    int rcw = wait_searches_in_flight(s, st);
+    if (rcw) return rcw;
+  }
   HIP_TRY(hipEventRecord(s->ev[0], st));
   HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, p.q_rows, s->metric, s->dQ.p, st));
   if (f16)
@@ -1327,9 +1380,11 @@ int resolve_engine(const ehx_space* s) {
 // cascade of collect passes, x4 in rows, each followed by select256 (running best 256 + the next threshold) ->
 // rerank256 (canonical distances of the k' = 128 best lower bounds, top-k, certificate).  Per-query verdicts land in
 // s->dUflags / s->dUncert16 like those of flat_pass.
-int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k, uint64_t* d_ids,
+// `set`: which of the space's two scratch sets (ehx_space::I8Set) this batch runs in; the caller holds that set's mutex.
+int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_queries, uint32_t k, uint64_t* d_ids,
                float* d_dist, uint32_t* d_count, bool count_stats) {
   Engine& E = engine();
+  ehx_space::I8Set& sc = s->i8set[set];
   static const uint32_t growth = [] {
     const char* g = getenv("EHX_I8_GROWTH");
     const long v = g ? atol(g) : 4;
@@ -1405,12 +1460,13 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
     return (uint32_t)std::min<double>(kprime, std::max<double>(16.0, std::ceil(kprime * f * safety)));
   };
   // The first pass runs under a threshold taken from the sample at a LOW rank, chosen for the number of keys the pass
-  // should collect: a single pass has to fill the list with room to spare (4 x its width); with more passes to come it
-  // only has to deliver the next threshold's rank (twice over, at least 512 keys: round 2 collected 1024 and spent
-  // more than half of the first pass in the epilogue's slow path).
+  // should collect: a single pass has to fill the list with room to spare (2 x its logical length — every key collected
+  // is a trip through the epilogue's slow path, and on a 20 000-row space 4 x meant a hit in 2.6 % of all pairs); with more
+  // passes to come it only has to deliver the next threshold's rank (twice over, at least min(512, 2 k') keys: round 2
+  // collected 1024 and spent more than half of the first pass in the epilogue's slow path).
   const uint64_t first_rows = (uint64_t)passes.front().plan.n_tiles * kTileRows16;
   const uint64_t first_keys = std::min<uint64_t>(
-      2048, passes.size() == 1 ? 4ull * kprime : std::max<uint64_t>(std::min<uint64_t>(512, 2ull * kprime), 2ull * rank_after(0)));
+      2048, passes.size() == 1 ? 2ull * kprime : std::max<uint64_t>(std::min<uint64_t>(512, 2ull * kprime), 2ull * rank_after(0)));
   const uint32_t sample_rank =
       (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, first_keys * kSampleTiles * kTileRows16 / first_rows));
   const ScanPlan p = passes.back().plan;  // (q_tiles, q_rows are the same for every pass)
@@ -1421,39 +1477,47 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
   }
   if (chunks_max > 256) return fail(EHX_EINTERNAL, "scan plan with %u chunks", chunks_max);
   int rc;
-  if ((rc = s->dQ.ensure((size_t)p.q_rows * s->ld))) return rc;
-  if ((rc = s->dQ8.ensure(scanq8_bytes(p.q_rows, s->ld8)))) return rc;
-  if ((rc = s->dQp8.ensure(p.q_rows))) return rc;
-  if ((rc = s->dQuv.ensure(p.q_rows))) return rc;
-  if ((rc = s->dThr8.ensure(p.q_rows))) return rc;
-  if ((rc = s->dSample8.ensure((size_t)kSampleTiles * kTileRows16 * p.q_rows))) return rc;
+  if ((rc = sc.dQ.ensure((size_t)p.q_rows * s->ld))) return rc;
+  if ((rc = sc.dQ8.ensure(scanq8_bytes(p.q_rows, s->ld8)))) return rc;
+  if ((rc = sc.dQp8.ensure(p.q_rows))) return rc;
+  if ((rc = sc.dQuv.ensure(p.q_rows))) return rc;
+  if ((rc = sc.dThr8.ensure(p.q_rows))) return rc;
+  if ((rc = sc.dSample8.ensure((size_t)kSampleTiles * kTileRows16 * p.q_rows))) return rc;
   if ((rc = s->dCand.ensure((size_t)grid_max * 512 * kCandSlots))) return rc;
-  if ((rc = s->dPool.ensure((size_t)p.q_rows * kPoolCap))) return rc;
-  if ((rc = s->dMerged8.ensure((size_t)p.q_rows * width))) return rc;
-  if ((rc = s->dI8Ctl.ensure((size_t)p.q_rows * 2 + 256))) return rc;
-  if ((rc = s->dUflags.ensure(p.q_rows))) return rc;
-  if (!s->dUncert16) {
-    HIP_TRY(hipMalloc((void**)&s->dUncert16, sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(s->dUncert16, 0, sizeof(unsigned long long)));
+  if ((rc = sc.dPool.ensure((size_t)p.q_rows * kPoolCap))) return rc;
+  if ((rc = sc.dMerged8.ensure((size_t)p.q_rows * width))) return rc;
+  if ((rc = sc.dI8Ctl.ensure((size_t)p.q_rows * 2 + 256))) return rc;
+  if ((rc = sc.dUflags.ensure(p.q_rows))) return rc;
+  if (!sc.dUncert) {
+    HIP_TRY(hipMalloc((void**)&sc.dUncert, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(sc.dUncert, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc((void**)&sc.hUncertPin, sizeof(unsigned long long), hipHostMallocDefault));
   }
-  uint32_t* pool_cnt = s->dI8Ctl.p;
-  uint32_t* ovf = s->dI8Ctl.p + p.q_rows;
-  uint32_t* sync = s->dI8Ctl.p + 2 * (size_t)p.q_rows;
-  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
-  HIP_TRY(hipEventRecord(s->ev[0], st));
-  HIP_TRY(launch_prep_queries_i8(d_queries, (uint32_t)nq, s->dims, s->ld, s->ld8, p.q_rows, s->metric, s->dQ.p,
-                                 s->dQ8.p, s->dQp8.p, s->dQuv.p, s->dThr8.p, s->dI8Ctl.p, st));
+  uint32_t* pool_cnt = sc.dI8Ctl.p;
+  uint32_t* ovf = sc.dI8Ctl.p + p.q_rows;
+  uint32_t* sync = sc.dI8Ctl.p + 2 * (size_t)p.q_rows;
+  if (!sc.ev[0]) {
+    for (auto& e : sc.ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& pr2 : sc.ring)
+      for (auto& e : pr2) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventCreateWithFlags(&sc.verdict, hipEventBlockingSync | hipEventDisableTiming));
+  }
+  // (a caller's stream other than the space's own: searches already in flight there and here finish first)
+  if ((rc = wait_searches_in_flight(s, st))) return rc;
+  HIP_TRY(hipEventRecord(sc.ev[0], st));
+  HIP_TRY(launch_prep_queries_i8(d_queries, (uint32_t)nq, s->dims, s->ld, s->ld8, p.q_rows, s->metric, sc.dQ.p,
+                                 sc.dQ8.p, sc.dQp8.p, sc.dQuv.p, sc.dThr8.p, sc.dI8Ctl.p, st));
   ScanArgsI8 a;
-  a.Q = s->dQ8.p;
+  a.Q = sc.dQ8.p;
   a.X = s->dX8;
   a.rowp = s->dRowp8;
   a.tilep = s->dTilep8;
   a.tileg = s->dTileg8;
   a.perm = s->dPerm8;
-  a.qparams = s->dQp8.p;
-  a.thr = s->dThr8.p;
+  a.qparams = sc.dQp8.p;
+  a.thr = sc.dThr8.p;
   a.cand = s->dCand.p;
-  a.pool = s->dPool.p;
+  a.pool = sc.dPool.p;
   a.pool_cnt = pool_cnt;
   a.ovf = ovf;
   a.pool_cap = kPoolCap;
@@ -1468,17 +1532,17 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
     a.xcd_map = pl.xcd_map;
     return launch_flat_scan_i8(a, st);
   };
-  hipEvent_t* pr = s->ring[s->ring_count % ehx_space::kRing];
-  HIP_TRY(hipEventRecord(s->ev[1], st));
+  hipEvent_t* pr = sc.ring[sc.ring_count % 64];
+  HIP_TRY(hipEventRecord(sc.ev[1], st));
   HIP_TRY(hipEventRecord(pr[0], st));
   {  // sample pass: lower bounds of the first 2048 rows -> thr[q] = the k'-th best of them
     ScanPlan sp = plan_scan((uint32_t)nq, kSampleTiles, k, E.n_cus);
-    a.dump = s->dSample8.p;
+    a.dump = sc.dSample8.p;
     a.sync = nullptr;
     HIP_TRY(scan(sp, 0));
     a.dump = nullptr;
-    HIP_TRY(launch_sample_select256(s->dSample8.p, kSampleTiles * kTileRows16, p.q_rows, (uint32_t)nq, sample_rank,
-                                    s->dThr8.p, st));
+    HIP_TRY(launch_sample_select256(sc.dSample8.p, kSampleTiles * kTileRows16, p.q_rows, (uint32_t)nq, sample_rank,
+                                    sc.dThr8.p, st));
   }
   for (size_t i = 0; i < passes.size(); ++i) {
     const bool last = i + 1 == passes.size();
@@ -1490,28 +1554,28 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
     HIP_TRY(scan(passes[i].plan, passes[i].tile0));
     if (last) {  // (the last select and the re-rank are outside the timed scan phase, like flat_pass's final merge)
       HIP_TRY(hipEventRecord(pr[1], st));
-      HIP_TRY(hipEventRecord(s->ev[2], st));
-      s->ring_count++;
+      HIP_TRY(hipEventRecord(sc.ev[2], st));
+      sc.ring_count++;
     }
-    HIP_TRY(launch_select256(s->dPool.p, pool_cnt, kPoolCap, (uint32_t)nq, rank_after(i), s->dMerged8.p, width, i > 0,
-                             s->dThr8.p, s->dQp8.p, st));
+    HIP_TRY(launch_select256(sc.dPool.p, pool_cnt, kPoolCap, (uint32_t)nq, rank_after(i), sc.dMerged8.p, width, i > 0,
+                             sc.dThr8.p, sc.dQp8.p, st));
   }
   Rerank256Args r;
-  r.Q = s->dQ.p;
+  r.Q = sc.dQ.p;
   r.X = s->dX;
   r.x_half = (uint32_t)s->x_half;
   r.inv_norm = s->dInv;
-  r.merged = s->dMerged8.p;
+  r.merged = sc.dMerged8.p;
   r.width = width;
   r.ovf = ovf;
-  r.quv = s->dQuv.p;
-  r.qparams = s->dQp8.p;
+  r.quv = sc.dQuv.p;
+  r.qparams = sc.dQp8.p;
   r.max_sumsq = s->dMaxSumsq;
   r.out_ids = d_ids;
   r.out_dist = d_dist;
   r.out_count = d_count;
-  r.n_uncertified = s->dUncert16;
-  r.uncert_flags = s->dUflags.p;
+  r.n_uncertified = sc.dUncert;
+  r.uncert_flags = sc.dUflags.p;
   r.nq = (uint32_t)nq;
   r.k = k;
   r.kprime = kprime;
@@ -1533,11 +1597,11 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
     std::vector<float2> uv(nq);
     std::vector<uint64_t> mg(nq * width);
     std::vector<float> od(nq * k);
-    HIP_TRY(hipMemcpy(fl.data(), s->dUflags.p, nq * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(fl.data(), sc.dUflags.p, nq * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(ov.data(), ovf, nq * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(qp.data(), s->dQp8.p, nq * sizeof(float4), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(uv.data(), s->dQuv.p, nq * sizeof(float2), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(mg.data(), s->dMerged8.p, nq * width * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(qp.data(), sc.dQp8.p, nq * sizeof(float4), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(uv.data(), sc.dQuv.p, nq * sizeof(float2), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mg.data(), sc.dMerged8.p, nq * width * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(od.data(), d_dist, nq * k * 4, hipMemcpyDeviceToHost));
     int shown = 0;
     for (size_t q = 0; q < nq && shown < 6; ++q) {
@@ -1548,8 +1612,8 @@ int flat_pass8(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, 
               qp[q].w, S(0), S(63), S(127), S(255), od[q * k + k - 1], uv[q].x, uv[q].y);
     }
   }
-  HIP_TRY(hipEventRecord(s->ev[3], st));
-  s->ev_valid = true;
+  HIP_TRY(hipEventRecord(sc.ev[3], st));
+  sc.ev_valid = true;
   if (count_stats) {
     s->n_queries += nq;
     s->n_dist += (uint64_t)nq * s->n;
@@ -1582,7 +1646,10 @@ int exhaustive_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_quer
     HIP_TRY(hipMalloc((void**)&s->dUncert16, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(s->dUncert16, 0, sizeof(unsigned long long)));
   }
-  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
+  {
+    int rcw = wait_searches_in_flight(s, st);
+    if (rcw) return rcw;
+  }
   HIP_TRY(hipEventRecord(s->ev[0], st));
   HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, (uint32_t)nq, s->metric, s->dQ.p, st));
   HIP_TRY(hipEventRecord(s->ev[1], st));
@@ -1631,8 +1698,12 @@ int exhaustive_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_quer
 //                                                              than the certification margin; kMaxExhaustive
 //                                                              queries per launch group, as many groups as needed)
 // One host round trip (8 bytes) per stage to read its verdict.
+// i8_failed (optional): the int8 stage of this very batch has already run — in one of the scratch sets, outside the
+// pipeline lock (knn_host_direct) — and left the answers of every other query in the output arrays; these queries
+// (i8_short of them because their candidate list was too short) continue with the next engine.
 int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k,
-                      uint64_t* d_ids, float* d_dist, uint32_t* d_count) {
+                      uint64_t* d_ids, float* d_dist, uint32_t* d_count, const std::vector<uint32_t>* i8_failed = nullptr,
+                      size_t i8_short = 0) {
   if (k == 0 || nq == 0) return EHX_OK;
   if (nq > (1u << 24)) return fail(EHX_EINVAL, "too many queries in one call: %zu", nq);
   if (s->params.mode == EHX_MODE_GRAPH) {
@@ -1698,10 +1769,16 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
       od = s->dFbDist.p;
       oc = s->dFbCnt.p;
     }
+    // (the int8 stage runs in scratch set 0 here, held for the stage and its verdict: host batches may be using both sets
+    // through knn_host_direct's pipelined path at the same time)
+    std::unique_lock<std::mutex> set_lock(s->i8set[0].mu, std::defer_lock);
+    if (kind == kI8) set_lock.lock();
     if (kind == kExhaustive) rc = exhaustive_pass(s, st, m, q, k, oi, od, oc);
-    else if (kind == kI8) rc = flat_pass8(s, st, m, q, k, oi, od, oc, count_stats);
+    else if (kind == kI8) rc = flat_pass8(s, 0, st, m, q, k, oi, od, oc, count_stats);
     else rc = flat_pass(s, st, m, q, k, oi, od, oc, kind == kFilter, count_stats);
     if (rc) return rc;
+    unsigned long long* d_unc = kind == kI8 ? s->i8set[0].dUncert : s->dUncert16;
+    const uint32_t* d_flags = kind == kI8 ? s->i8set[0].dUflags.p : s->dUflags.p;
     if (subset) {
       HIP_TRY(launch_scatter_results(oi, od, oc, s->dFbIdx.p, (uint32_t)m, k, d_ids, d_dist, d_count, st));
       HIP_TRY(hipEventRecord(s->ev[3], st));
@@ -1710,16 +1787,16 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     unc->clear();
     // (into PINNED host memory: a copy to pageable memory goes through a staging buffer and a copy kernel)
     if (!s->hUncertPin) HIP_TRY(hipHostMalloc((void**)&s->hUncertPin, sizeof(unsigned long long), hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(s->hUncertPin, s->dUncert16, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s->hUncertPin, d_unc, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const unsigned long long n_unc = *s->hUncertPin;
 #if defined(EHX_ABL) && EHX_ABL
     return EHX_OK;  // profiling builds with ablated (wrong-by-construction) kernels: time the first stage only
 #endif
     if (n_unc == 0) return EHX_OK;
-    HIP_TRY(hipMemsetAsync(s->dUncert16, 0, sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(d_unc, 0, sizeof(unsigned long long), st));
     std::vector<uint32_t> flags(m);
-    HIP_TRY(hipMemcpyAsync(flags.data(), s->dUflags.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(flags.data(), d_flags, m * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     n_short = 0;
     for (size_t j = 0; j < m; ++j)
@@ -1735,7 +1812,12 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   bool counted = false;
   const int eng = resolve_engine(s);
   if (eng == EHX_ENGINE_I8) {
-    if ((rc = stage(kI8, nullptr, true, &next))) return rc;
+    if (i8_failed) {
+      next = *i8_failed;
+      n_short = i8_short;
+    } else if ((rc = stage(kI8, nullptr, true, &next))) {
+      return rc;
+    }
     counted = true;
     s->n_i8_queries += nq;
     s->n_i8_fallback += next.size();
@@ -2508,7 +2590,10 @@ static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n, hipStream_t s
       return g ? atoi(g) != 0 : true;
     }();
     if (exclusive) {
-      if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));  // searches still in flight on other streams
+      {  // searches still in flight on other streams
+        int rcw = wait_searches_in_flight(s, st);
+        if (rcw) return rcw;
+      }
       r8 = row0 & ~(uint64_t)255;
       e8 = std::min<uint64_t>(round_up(row0 + n, 256), std::max<uint64_t>(n_after, row0 + n));
     }
@@ -2562,7 +2647,10 @@ static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t ws = s->wstream ? s->wstream : s->stream;
   // rows rewritten in place: in-flight device searches (enqueued without the lock being held any more) finish first
-  if (!append_only && s->ev_valid) HIP_TRY(hipStreamWaitEvent(ws, s->ev[3], 0));
+  if (!append_only) {
+    int rcw = wait_searches_in_flight(s, ws);
+    if (rcw) return rcw;
+  }
   const uint64_t old_n = s->n;
   int rc;
   if (append_only && next >= s->cap) {
@@ -2836,7 +2924,7 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
       const uint32_t rpb = (uint32_t)std::max<uint64_t>(64, ((s->n + 1023) / 1024 + 63) / 64 * 64);  // <= 1024 workgroups
       const uint32_t n_blocks = (uint32_t)((s->n + rpb - 1) / rpb);
       if ((rc = s->dOnePart.ensure((size_t)n_blocks * 64))) return rc;
-      if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev[3], 0));  // (device searches queued on other streams)
+      if ((rc = wait_searches_in_flight(s, s->stream))) return rc;  // (device searches queued on other streams)
       char* h = s->hOnePin;
       memcpy(h, queries, qbytes);
       SingleQueryArgs a;
@@ -2950,10 +3038,53 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
   memcpy(hs->pin, queries, qbytes);
   HIP_TRY(hipMemcpyAsync(hs->dq.p, hs->pin, qbytes, hipMemcpyHostToDevice, hs->st));
   HIP_TRY(hipEventRecord(hs->in_ev, hs->st));
-  {
+  // The int8 engine's first stage — all of a batch unless queries lose their certificate — runs in one of the space's two
+  // scratch sets WITHOUT the pipeline-wide lock: this call's launches queue up on the space's stream behind the other
+  // caller's while that one still waits for its verdict, so the scan kernels of consecutive batches run back to back with
+  // no host round trip (launches, verdict copy, thread wake-up: ~0.1 ms per batch) between them.  A batch that does lose
+  // queries is re-run through the full engine chain under the lock (rare; the chain also adapts the list's length).
+  static const bool pipe_on = [] {
+    const char* e = getenv("EHX_HOST_PIPELINE");
+    return e ? atoi(e) != 0 : true;
+  }();
+  bool done = false, have_failed = false;
+  std::vector<uint32_t> failed;
+  size_t n_short = 0;
+  if (pipe_on && s->params.mode == EHX_MODE_FLAT && k <= EHX_MAX_K && s->n > 0 && resolve_engine(s) == EHX_ENGINE_I8) {
+    const int set = (int)(s->i8_next_set.fetch_add(1, std::memory_order_relaxed) & 1u);   // consecutive batches alternate
+    ehx_space::I8Set& sc = s->i8set[set];
+    std::lock_guard<std::mutex> l(sc.mu);
+    HIP_TRY(hipStreamWaitEvent(s->stream, hs->in_ev, 0));
+    if ((rc = flat_pass8(s, set, s->stream, n_queries, hs->dq.p, k, d_ids, d_dist, d_cnt, false))) return rc;
+    HIP_TRY(hipMemcpyAsync(sc.hUncertPin, sc.dUncert, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipEventRecord(sc.verdict, s->stream));
+    HIP_TRY(hipEventRecord(hs->done_ev, s->stream));
+    HIP_TRY(hipEventSynchronize(sc.verdict));
+    s->n_queries += n_queries;
+    s->n_dist += (uint64_t)n_queries * s->n;
+    s->bytes_algo += s->n * (uint64_t)s->dims + (uint64_t)n_queries * s->dims * 4ull + (uint64_t)n_queries * k * 12ull;
+    if (*sc.hUncertPin == 0) {
+      done = true;
+      s->n_i8_queries += n_queries;
+    } else {  // which queries, and why: the engine chain continues with them (below, under the pipeline lock)
+      HIP_TRY(hipMemsetAsync(sc.dUncert, 0, sizeof(unsigned long long), s->stream));
+      std::vector<uint32_t> flags(n_queries);
+      HIP_TRY(hipMemcpyAsync(flags.data(), sc.dUflags.p, n_queries * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      for (size_t j = 0; j < n_queries; ++j)
+        if (flags[j]) {
+          failed.push_back((uint32_t)j);
+          n_short += flags[j] == 2u;
+        }
+      have_failed = true;
+    }
+  }
+  if (!done) {
     std::lock_guard<std::mutex> sl2(s->scratch_mu);
     HIP_TRY(hipStreamWaitEvent(s->stream, hs->in_ev, 0));
-    if ((rc = knn_device_locked(s, s->stream, n_queries, hs->dq.p, k, d_ids, d_dist, d_cnt))) return rc;
+    if ((rc = knn_device_locked(s, s->stream, n_queries, hs->dq.p, k, d_ids, d_dist, d_cnt, have_failed ? &failed : nullptr,
+                                n_short)))
+      return rc;
     HIP_TRY(hipEventRecord(hs->done_ev, s->stream));
   }
   char* ho = hs->pin + qbytes;
@@ -3381,19 +3512,34 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
     (void)u[0];
     if (u[1]) return fail(EHX_EINTERNAL, "scan kernel tripped its bounded-retry guard %llu times", u[1]);
   }
-  if (s->ev_valid) {
-    HIP_TRY(hipEventSynchronize(s->ev[3]));
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) out->last_scan_ms = ms;
-    if (hipEventElapsedTime(&ms, s->ev[0], s->ev[3]) == hipSuccess) out->last_total_ms = ms;
-    const uint64_t m = s->ring_count < (uint64_t)ehx_space::kRing ? s->ring_count : (uint64_t)ehx_space::kRing;
+  {
+    // scan times: the space's own ring (graph, fp16 / fp32 engines) and the rings of the int8 pipeline's two scratch sets
     double sum = 0;
     uint64_t got = 0;
-    for (uint64_t i = 0; i < m; ++i) {
-      if (hipEventElapsedTime(&ms, s->ring[i][0], s->ring[i][1]) == hipSuccess) {
-        sum += ms;
-        ++got;
-      }
+    float ms = 0;
+    if (s->ev_valid) {
+      HIP_TRY(hipEventSynchronize(s->ev[3]));
+      if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) out->last_scan_ms = ms;
+      if (hipEventElapsedTime(&ms, s->ev[0], s->ev[3]) == hipSuccess) out->last_total_ms = ms;
+      const uint64_t m = s->ring_count < (uint64_t)ehx_space::kRing ? s->ring_count : (uint64_t)ehx_space::kRing;
+      for (uint64_t i = 0; i < m; ++i)
+        if (hipEventElapsedTime(&ms, s->ring[i][0], s->ring[i][1]) == hipSuccess) {
+          sum += ms;
+          ++got;
+        }
+    }
+    for (auto& c : s->i8set) {
+      std::lock_guard<std::mutex> cl(c.mu);
+      if (!c.ev_valid) continue;
+      HIP_TRY(hipEventSynchronize(c.ev[3]));
+      if (hipEventElapsedTime(&ms, c.ev[1], c.ev[2]) == hipSuccess) out->last_scan_ms = ms;
+      if (hipEventElapsedTime(&ms, c.ev[0], c.ev[3]) == hipSuccess) out->last_total_ms = ms;
+      const uint64_t m = c.ring_count < 64 ? c.ring_count : 64;
+      for (uint64_t i = 0; i < m; ++i)
+        if (hipEventElapsedTime(&ms, c.ring[i][0], c.ring[i][1]) == hipSuccess) {
+          sum += ms;
+          ++got;
+        }
     }
     out->scan_launches = got;
     out->scan_ms_mean = got ? sum / (double)got : 0.0;
@@ -3450,6 +3596,10 @@ int ehx_stats_reset(ehx_space* s) {
   s->n_i8_queries = 0;
   s->n_i8_fallback = 0;
   s->ring_count = 0;
+  for (auto& c : s->i8set) {
+    std::lock_guard<std::mutex> cl(c.mu);
+    c.ring_count = 0;
+  }
   if (s->dUncert) HIP_TRY(hipMemset(s->dUncert, 0, 2 * sizeof(unsigned long long)));
   if (s->dGraphCounters) HIP_TRY(hipMemset(s->dGraphCounters, 0, kGraphCounters * sizeof(unsigned long long)));
   return EHX_OK;
