@@ -1,11 +1,11 @@
-// flat_scan_i8_kernel — the exhaustive scan as an INT8 matrix-core FILTER (v_mfma_i32_32x32x32_i8: twice the
-// fp16 matrix rate on half the bytes, EXACT int32 accumulation) in front of the canonical fp32 re-rank.  Like the
-// fp16 filter (k_flat16.hip) it only decides which rows become candidates, with a certified LOWER BOUND of every
+// flat_scan_i8_kernel — the exhaustive scan as an INT8 matrix-core FILTER (v_mfma_i32_16x16x64_i8 since round 4, 32x32x32
+// before: twice the fp16 matrix rate on half the bytes, EXACT int32 accumulation) in front of the canonical fp32 re-rank.
+// Like the fp16 filter (k_flat16.hip) it only decides which rows become candidates, with a certified LOWER BOUND of every
 // row's score, so the answer stays the exact fp32 answer (rerank256_kernel certifies each query; what it cannot
 // certify falls to the fp16 filter, the fp32 scan and finally the exhaustive canonical pass).
 //
 // The scan copy (k_misc.hip: make_scan8): every row normalised to unit length (x^ = x / n_r) and quantised with
-// its own scale,  x^ = s_r * xi + dx,  xi int8,  s_r = max|x^| / 127,  e_r >= |dx|;  queries likewise
+// its own scale,  x^ = s_r * xi + dx,  xi int8,  s_r >= max|x^| / 127,  e_r >= |dx|;  queries likewise
 // (s_q, qi, e_q).  The integer dot product I = <qi, xi> is exact, so with dot^ = <q^, x^>
 //     dot^  <=  U = s_q s_r I + e_q (1.0001 + e_r) + 1.0001 e_r          (Cauchy-Schwarz on the two residuals)
 // and every metric of the engine is affine in dot^ with a non-positive slope (table in k_flat16.hip):
@@ -13,35 +13,36 @@
 // with the row parameters (A, B, C, D) = (a_r s_r, b_r(1-1e-6), a_r(1.0001 + e_r), a_r(1.0001 e_r + slack)) computed
 // when the row is written (slack: the fp32 evaluation of this expression, the filter's own norms — make_scan8).
 //
-// Kernel shape: that of the fp16 filter, byte for byte — workgroup = 8 waves (two per SIMD), tile 256 rows x 256
-// queries, wave tile 128 x 64 = 4x2 MFMA blocks; a stage row is 64 bytes = 64 k-values (two k-steps of 32), X stage
-// 16 KiB + Q stage 16 KiB, ring of 4 stages filled three stages ahead by global->LDS DMA from the stage-blocked
-// scan copy; one counted s_waitcnt + one raw s_barrier per stage.  Half the stages of the fp16 scan per tile.
+// Kernel shape: workgroup = 8 waves (two per SIMD), tile 256 rows x 256 queries, wave tile 128 x 64 = 8 x 4 MFMA blocks
+// of 16 x 16; a stage row is 64 bytes = ONE k-step of 64, X stage 16 KiB + Q stage 16 KiB, ring of 4 stages filled
+// three stages ahead by global->LDS DMA from the stage-blocked scan copy; one counted s_waitcnt + one raw s_barrier per
+// stage (details at the kernel).
 //
-// Epilogue.  The lists of the fp16 kernel (sorted, compacted, thresholds tightened in flight) do not pay here: the
-// int8 bound (~1.5e-2 in dot units, vs 1.2e-3) needs k' = 128 candidates per query, so hits are ~4x as frequent
-// while a tile takes half the time.  Instead the threshold of a (query, pass) is FIXED — the k'-th best lower bound
-// of the rows scanned by the earlier passes (select256_kernel) — and a pass simply collects every (row, query) whose
-// lower bound is not above it:
-//   phase 1  per 32x32 block one integer max per lane (v_max3_i32 tree) against an integer alarm level derived from
-//            the tile's parameter extremes (tile_params8) — no row parameters, no float conversion;
-//   phase 2  (blocks with an alarm) a 16-bit mask per lane of the accumulators at or above the alarm level; each
-//            trip of a short loop takes one set bit per lane, evaluates S_lower with that row's parameters and
-//            appends (score, id, query) to the wave's own staging buffer in LDS (128 entries);
-//   a staging buffer that runs full is flushed to the queries' POOLS in HBM (one global atomicAdd per entry); what is
-//   left is flushed when the workgroup is done.  The hot path touches LDS only: a global store or atomic per hit would
-//   put foreign entries into the vmcnt queue the stage loop counts on (loads and stores may retire out of order with
-//   respect to each other), so the flush — rare — drains the queue instead.  A pool that overflows (adversarial row
-//   order: every row beats a stale threshold) only flags its query — the next engine of the chain answers it.
-// A cascade of passes x4 in rows keeps the hits at ~3 k' per query and pass.
+// Epilogue.  The threshold of a (query, pass) is FIXED — the k'-th best lower bound of the rows scanned by the earlier
+// passes (select256_kernel) — and a pass collects every (row, query) whose lower bound is not above it:
+//   phase 1  per query of the lane (four per lane), ONE integer maximum over the lane's 32 accumulators against ONE
+//            integer level: the rows of a full tile are stored ordered by quantisation step and share one |A| per
+//            32-row lane group (k_misc.hip), so I |A_r| >= K_q is I >= floor(K_q / |A|), exactly; K_q comes from the
+//            tile's parameter extremes (tile_params8), once per wave, handed round by a lane permute;
+//   phase 2  (a lane reached its level) the row blocks whose own maximum reaches it, their accumulators as a 32-bit
+//            mask per lane; each trip of a short loop takes one set bit per lane, evaluates S_lower with that row's
+//            parameters (the one LDS round trip of the path) and stages (score, position, query) in the wave's own
+//            buffer in LDS (128 entries; the fill count is a wave-uniform register, slots by ballot + lane prefix);
+//   a staging buffer that runs full is flushed to the queries' POOLS in HBM (one global atomicAdd per entry, the
+//   position mapped to the row id through perm8); what is left is flushed when the workgroup is done.  The hot path
+//   touches LDS only: a global store or atomic per hit would put foreign entries into the vmcnt queue the stage loop
+//   counts on (loads and stores may retire out of order with respect to each other), so the flush — rare — drains the
+//   queue instead.  A pool that overflows (adversarial row order: every row beats a stale threshold) only flags its
+//   query — the next engine of the chain answers it.
+// A cascade of passes x4 in rows keeps the hits at ~2-3 k' per query and pass.
 //
-// Lock-step (optional, ScanArgsI8::sync): the q_tiles workgroups that stream the same row chunk sit on one XCD and
+// Lock-step (optional, ScanArgsI8::sync, OFF): the q_tiles workgroups that stream the same row chunk sit on one XCD and
 // share its L2, but nothing keeps them together, and once they drift apart by more than the L2 holds every one of
-// them fetches the rows from HBM again (the fp16 scan measured 3.1x the algorithmic traffic).  Each workgroup
+// them fetches the rows from HBM again (round 4's kernel: 1.2-1.5 x the algorithmic traffic).  Each workgroup
 // announces every finished ring revolution on a per-chunk counter and does not run more than ~2 revolutions ahead
 // of its slowest sibling; the poll is an asynchronous 4-byte global->LDS load issued a revolution before its value
-// is looked at, so the steady state costs one atomic and one LDS read per revolution.  The wait is bounded (a
-// sibling that is not resident must not hang the launch): after the bound the workgroup stops synchronising.
+// is looked at.  The wait is bounded (a sibling that is not resident must not hang the launch).  It removes the
+// re-reads (1.03 x) and costs 60 % of the scan time on the round-4 kernel.
 #include "ehx_kernels.h"
 #include "k_scan_common.h"
 
