@@ -1425,7 +1425,14 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   // of 1024 dims and more always get the full width (the bound is ~1.3e-2 in dot units whatever d while the scores'
   // spread shrinks like 1/sqrt(d): 18 000 x 2048 needs its 256) — and, like the width, doubles when queries lose their
   // certificate because the list was too short (knn_device_locked).
+  // Short rows need fewer still: the bound is a smaller share of the scores' spread (0.15 sigma at d = 128 against 0.36
+  // at d = 768), and on short rows the hit path is what a tile's time is made of (two stages of matrix work per tile at
+  // d = 128).  Measured, 46 000 queries each, 0 fallbacks (profiles/r04_p_kprime_short_rows.jsonl): 6.25 M x 128 k' 256 /
+  // 128 / 64 = 1.380 / 1.277 / 1.238 ms per batch, 1 M x 128 0.447 (128) / 0.414 (64); 4 M x 384 and 10 M x 256 are fine
+  // with 128 (1.762 against 1.825, 2.620 against 2.722 ms) and lose queries by the hundred with 64.
   uint32_t kp_auto = s->n >= 4000000 ? 256u : 128u;
+  if (s->dims <= 128) kp_auto = 64u;
+  else if (s->dims < 512) kp_auto = 128u;
   if (s->dims >= 1024) kp_auto = width;
   const uint32_t kp_want = std::max(kp_auto, s->i8_kprime_min);
   const uint32_t kprime = kprime_env >= 64 ? (uint32_t)std::min<long>(kprime_env, (long)width) : std::min(kp_want, width);
