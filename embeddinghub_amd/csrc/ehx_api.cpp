@@ -208,6 +208,10 @@ struct ehx_space {
   float* dInv = nullptr;     // [cap] (cosine)
   float* dMaxSumsq = nullptr;  // device scalar: largest |x|^2 ever written (certification margin, cert_margin)
   float* dXs = nullptr;      // [cap][ld] graph mode: the search copy (permuted blocks, cosine rows normalised)
+  bool x_perm = false;       // graph mode, fp32 rows (round 4): the rows are stored ONCE — dX holds them in the search
+                             // copy's block order, RAW; dXs is the same pointer; cosine rows are scaled by inv_norm on
+                             // the fly in the kernels (GraphArgs / InsertArgs .xscale); Get undoes the permutation
+  DevBuf<uint64_t> dPermIds; // rows of a batch written in place (non-contiguous ids), for launch_permute_blocks
   uint64_t cap = 0, n = 0;
   // fp16-MFMA filter scan (k_flat16.hip): unit-normalised binary16 scan copy of the rows
   bool has16 = false;          // the space keeps the fp16 scan copy (maintained on every write, whatever use16 says)
@@ -386,8 +390,10 @@ struct ehx_space {
       if (p) (void)hipFree(p);
       p = nullptr;
     };
+    if (dXs == (float*)dX) dXs = nullptr;  // (single-copy graph spaces: the same allocation)
     fr(dX);
     fr(dXs);
+    dPermIds.release();
     fr(dRowp);
     fr(dInv);
     fr(dMaxSumsq);
@@ -641,7 +647,7 @@ int grow(ehx_space* s, uint64_t rows) {
     s->dRowp8 = nr8;
     s->dTilep8 = nt8;
   }
-  if (s->params.mode == EHX_MODE_GRAPH) {
+  if (s->params.mode == EHX_MODE_GRAPH && !s->x_perm) {
     float* nxs = nullptr;
     if (hipMalloc((void**)&nxs, want * s->ld * sizeof(float)) != hipSuccess) {
       (void)hipFree(nx);
@@ -660,6 +666,7 @@ int grow(ehx_space* s, uint64_t rows) {
   if (s->dRowp) (void)hipFree(s->dRowp);
   if (s->dInv) (void)hipFree(s->dInv);
   s->dX = nx;
+  if (s->x_perm) s->dXs = (float*)nx;  // one allocation: the rows ARE the search copy
   s->dRowp = nr;
   s->dInv = ni;
   s->cap = want;
@@ -834,9 +841,10 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
   }
   HIP_TRY(hipMemsetAsync(s->dLinkCount.p, 0, n_rounds * sizeof(uint32_t), st));
   InsertArgs a{};  // (zeroed: a null link_head / sel switches those outputs off in the kernels)
-  a.X = s->x_half ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
+  a.X = (s->x_half || s->x_perm) ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
   a.Xs = s->dXs;
   a.inv_norm = s->dInv;
+  a.xscale = (s->x_perm && s->metric == EHX_METRIC_COSINE) ? s->dInv : nullptr;
   a.adj0 = s->dAdj0;
   a.up_start = s->dUpStart;
   a.up_lists = s->dUpLists;
@@ -913,9 +921,10 @@ int graph_update(ehx_space* s, uint32_t id) {
   const int level = s->h_levels[id];
   int rc;
   InsertArgs a{};  // (zeroed: a null link_head / sel switches those outputs off in the kernels)
-  a.X = s->x_half ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
+  a.X = (s->x_half || s->x_perm) ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
   a.Xs = s->dXs;
   a.inv_norm = s->dInv;
+  a.xscale = (s->x_perm && s->metric == EHX_METRIC_COSINE) ? s->dInv : nullptr;
   a.adj0 = s->dAdj0;
   a.up_start = s->dUpStart;
   a.up_lists = s->dUpLists;
@@ -1108,9 +1117,10 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, q_rows, s->metric, s->dQ.p, st));
   GraphArgs a;
   a.Q = s->dQ.p;
-  a.X = s->x_half ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
+  a.X = (s->x_half || s->x_perm) ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
   a.Xs = s->dXs;
   a.inv_norm = s->dInv;
+  a.xscale = (s->x_perm && s->metric == EHX_METRIC_COSINE) ? s->dInv : nullptr;
   a.adj0 = s->dAdj0;
   a.up_start = s->dUpStart;
   a.up_lists = s->dUpLists;
@@ -2216,6 +2226,18 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
   s->x_half = dtype == EHX_DTYPE_F16;
   s->esz = s->x_half ? 2 : sizeof(float);
   if (params) s->params = *params;
+  {
+    // Single-copy storage of a graph space's rows (round 4): free for L2^2 and inner product (the search copy of those
+    // rows WAS a permuted duplicate), so it is what they get.  A cosine space's search copy holds the NORMALISED rows;
+    // with one copy the kernels form x * inv_norm on the fly — bit-identical, half the HBM (10 M x 768: 61 -> 31 GB), but
+    // measured 7-14 % slower at d = 768 (one wave per SIMD: every extra instruction of the row walk is on the critical
+    // path; profiles/r04_q_*, r04_r_*) — so cosine keeps both copies unless EHX_GRAPH_ONE_COPY=1 asks for the memory.
+    // EHX_GRAPH_TWO_COPIES=1: every graph space as in rounds 1-3 (A/B).
+    const char* two = getenv("EHX_GRAPH_TWO_COPIES");
+    const char* one = getenv("EHX_GRAPH_ONE_COPY");
+    const bool want = metric != EHX_METRIC_COSINE || (one && atoi(one) != 0);
+    s->x_perm = params && params->mode == EHX_MODE_GRAPH && !s->x_half && want && !(two && atoi(two) != 0);
+  }
   if (parent) s->params.shards = params->shards;
   if (s->params.mode != EHX_MODE_FLAT && s->params.mode != EHX_MODE_GRAPH)
     return fail(EHX_EINVAL, "unknown mode %u", s->params.mode);
@@ -2577,7 +2599,7 @@ static int sync_stream(ehx_space* s, hipStream_t st) {
 // of [row0, row0 + n) lies beyond the published row count.  n_after: the row count once this write is published.
 static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n, hipStream_t st, bool exclusive, uint64_t n_after) {
   if (!st) st = s->stream;
-  if (s->dXs && n)
+  if (s->dXs && !s->x_perm && n)
     HIP_TRY(launch_make_search_copy(s->dX, s->x_half, s->dInv, row0, n, s->ld, s->metric, s->dXs, st));
   if ((!s->has16 && !s->has8) || n == 0) return EHX_OK;  // (kept current whatever engine is selected right now)
   unsigned long long u = 0, u8 = 0;
@@ -2702,9 +2724,26 @@ static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>
     }
   }
   // (the stream is waited for below, before the commit: both halves are free again when this call returns)
+  if (s->x_perm) {
+    // single-copy graph space: the rows just written go into the search copy's block order, in place, exactly once
+    // each (the permutation is its own inverse: a row written twice in this batch is permuted once)
+    bool run = true;
+    for (size_t i = 1; i < n && run; ++i) run = ids[i] == ids[0] + i;
+    if (run) {
+      HIP_TRY(launch_permute_blocks((float*)s->dX, s->ld, ids[0], n, nullptr, ws));
+    } else {
+      std::vector<uint64_t> uniq(ids.begin(), ids.begin() + n);
+      std::sort(uniq.begin(), uniq.end());
+      uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+      if ((rc = s->dPermIds.ensure(uniq.size()))) return rc;
+      HIP_TRY(hipMemcpyAsync(s->dPermIds.p, uniq.data(), uniq.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ws));
+      HIP_TRY(hipStreamSynchronize(ws));  // (the list lives on this stack frame)
+      HIP_TRY(launch_permute_blocks((float*)s->dX, s->ld, 0, uniq.size(), s->dPermIds.p, ws));
+    }
+  }
   // per-row statistics over the touched id range (idempotent for untouched rows in between)
   HIP_TRY(launch_row_stats(s->dX, s->x_half, min_id, max_id - min_id + 1, s->dims, s->ld, s->metric, s->dInv,
-                           s->dRowp, s->dMaxSumsq, ws));
+                           s->dRowp, s->dMaxSumsq, ws, s->x_perm ? 1 : 0));
   if ((rc = refresh_scan16(s, min_id, max_id - min_id + 1, ws, !append_only, next))) return rc;
   if ((rc = sync_stream(s, ws))) return rc;
   // commit: the rows are resident and described — publish the keys and the new row count
@@ -2835,6 +2874,12 @@ int ehx_get_by_id(ehx_space* s, uint64_t id, float* out_vec) {
     std::vector<_Float16> h(s->dims);
     HIP_TRY(hipMemcpy(h.data(), s->xrow(id), (size_t)s->dims * 2, hipMemcpyDeviceToHost));
     for (uint32_t c = 0; c < s->dims; ++c) out_vec[c] = (float)h[c];
+    return EHX_OK;
+  }
+  if (s->x_perm) {  // single-copy graph space: the row is stored in the search copy's block order — undo it here
+    std::vector<float> h(s->ld);
+    HIP_TRY(hipMemcpy(h.data(), s->xrow(id), (size_t)s->ld * sizeof(float), hipMemcpyDeviceToHost));
+    for (uint32_t c = 0; c < s->dims; ++c) out_vec[c] = h[search_copy_pos(c)];
     return EHX_OK;
   }
   HIP_TRY(hipMemcpy(out_vec, s->xrow(id), (size_t)s->dims * sizeof(float), hipMemcpyDeviceToHost));
@@ -3313,9 +3358,10 @@ int fill_synthetic_locked(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n
     tmp.release();
   } else {
     HIP_TRY(launch_gen_rows(seed, row0, n_rows, s->dims, s->ld, normalize, (float*)s->xrow(s->n), s->stream, stride));
+    if (s->x_perm) HIP_TRY(launch_permute_blocks((float*)s->dX, s->ld, s->n, n_rows, nullptr, s->stream));
   }
   HIP_TRY(launch_row_stats(s->dX, s->x_half, s->n, n_rows, s->dims, s->ld, s->metric, s->dInv, s->dRowp, s->dMaxSumsq,
-                           s->stream));
+                           s->stream, s->x_perm ? 1 : 0));
   HIP_TRY(hipStreamSynchronize(s->stream));
   if ((rc = refresh_scan16(s, s->n, n_rows, nullptr, true, s->n + n_rows))) return rc;
   const uint64_t old_n = s->n;

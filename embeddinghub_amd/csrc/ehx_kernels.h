@@ -280,8 +280,24 @@ __device__ __forceinline__ float canon_dist_lane_t(const float* __restrict__ q, 
 // per block it loads ONE float4 — the group reads the block as one coalesced 64-byte piece — and adds
 // its four products to its partial sum in order.  q is the query permuted the same way (LDS).  All four
 // lanes of the group must be active; every lane returns the full result.  Same register ring as above.
-template <int METRIC01>
-__device__ __forceinline__ void canon_group_step(const float4 xv, const float4 qv, float& p, int ncomp = 4) {
+// SCALE (round 4, single-copy graph spaces: the rows are stored raw and permuted, not normalised): every element of
+// the row is multiplied by xs first — hnswlib-python's stored normalised row x * inv_norm, one rounding per element,
+// formed on the fly; the products with the query then see exactly the values the normalised copy held.
+template <int METRIC01, bool SCALE = false>
+__device__ __forceinline__ void canon_group_step(float4 xv, const float4 qv, float& p, int ncomp = 4, float xs = 1.0f) {
+  if (SCALE) {
+    // two packed multiplies (v_pk_mul_f32: IEEE, one rounding per element like the scalar form): with one wave per
+    // SIMD every issued instruction of the row walk is on the critical path
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 sc = {xs, xs};
+    f32x2 lo = {xv.x, xv.y}, hi = {xv.z, xv.w};
+    lo = lo * sc;
+    hi = hi * sc;
+    xv.x = lo.x;
+    xv.y = lo.y;
+    xv.z = hi.x;
+    xv.w = hi.y;
+  }
   if (METRIC01 == 0) {
     const float d0 = ex_sub(qv.x, xv.x), d1 = ex_sub(qv.y, xv.y), d2 = ex_sub(qv.z, xv.z), d3 = ex_sub(qv.w, xv.w);
     p = ex_add(p, ex_mul(d0, d0));
@@ -299,9 +315,9 @@ __device__ __forceinline__ void canon_group_step(const float4 xv, const float4 q
 // position of element m of a row inside the search copy / the permuted query
 __host__ __device__ inline uint32_t search_copy_pos(uint32_t m) { return (m & ~15u) + ((m & 3u) << 2) + ((m >> 2) & 3u); }
 
-template <int METRIC01>
+template <int METRIC01, bool SCALE = false>
 __device__ __forceinline__ float canon_dist_group_t(const float* __restrict__ qp, const float* __restrict__ xs, int sub,
-                                                    uint32_t dims) {
+                                                    uint32_t dims, float xscale = 1.0f) {
   uint32_t body;
   if ((dims & 15u) == 0 || (dims & 3u) == 0) body = dims;
   else if (dims > 16) body = dims & ~15u;
@@ -317,7 +333,7 @@ __device__ __forceinline__ float canon_dist_group_t(const float* __restrict__ qp
 #define EHX_GRP_LOAD(R, B)                                        \
   _Pragma("unroll") for (int i_ = 0; i_ < BL; ++i_) R[i_] = x4[((size_t)(B) * BL + i_) * 4];
 #define EHX_GRP_ACC(R, B)                                         \
-  _Pragma("unroll") for (int i_ = 0; i_ < BL; ++i_) canon_group_step<METRIC01>(R[i_], q4[((size_t)(B) * BL + i_) * 4], p);
+  _Pragma("unroll") for (int i_ = 0; i_ < BL; ++i_) canon_group_step<METRIC01, SCALE>(R[i_], q4[((size_t)(B) * BL + i_) * 4], p, 4, xscale);
   uint32_t b = 0;
   if (nblk >= 2) {
     EHX_GRP_LOAD(r0, 0)
@@ -347,15 +363,15 @@ __device__ __forceinline__ float canon_dist_group_t(const float* __restrict__ qp
     uint32_t t = nblk * BL;  // 16-float blocks after the last full ring block (fewer than kLaneBlk), four at a time
     for (; t + 4 <= n16; t += 4) {
       const float4 t0 = x4[t * 4], t1 = x4[(t + 1) * 4], t2 = x4[(t + 2) * 4], t3 = x4[(t + 3) * 4];
-      canon_group_step<METRIC01>(t0, q4[t * 4], p);
-      canon_group_step<METRIC01>(t1, q4[(t + 1) * 4], p);
-      canon_group_step<METRIC01>(t2, q4[(t + 2) * 4], p);
-      canon_group_step<METRIC01>(t3, q4[(t + 3) * 4], p);
+      canon_group_step<METRIC01, SCALE>(t0, q4[t * 4], p, 4, xscale);
+      canon_group_step<METRIC01, SCALE>(t1, q4[(t + 1) * 4], p, 4, xscale);
+      canon_group_step<METRIC01, SCALE>(t2, q4[(t + 2) * 4], p, 4, xscale);
+      canon_group_step<METRIC01, SCALE>(t3, q4[(t + 3) * 4], p, 4, xscale);
     }
-    for (; t < n16; ++t) canon_group_step<METRIC01>(x4[t * 4], q4[t * 4], p);
+    for (; t < n16; ++t) canon_group_step<METRIC01, SCALE>(x4[t * 4], q4[t * 4], p, 4, xscale);
     // the 4-float pieces of a last, partial block (body % 16 / 4 of them): components 0..rem4-1
     const int rem4 = (int)((body & 15u) >> 2);
-    if (rem4) canon_group_step<METRIC01>(x4[n16 * 4], q4[n16 * 4], p, rem4);
+    if (rem4) canon_group_step<METRIC01, SCALE>(x4[n16 * 4], q4[n16 * 4], p, rem4, xscale);
   }
   // horizontal sum in SSE-lane order: ((p0 + p1) + p2) + p3, formed by every lane of the group
   const float t0 = __shfl(p, 0, 4), t1 = __shfl(p, 1, 4), t2 = __shfl(p, 2, 4), t3 = __shfl(p, 3, 4);
@@ -364,11 +380,12 @@ __device__ __forceinline__ float canon_dist_group_t(const float* __restrict__ qp
     float tail = 0.0f;
     for (uint32_t m = body; m < dims; ++m) {
       const uint32_t pos = search_copy_pos(m);
+      const float xv = SCALE ? ex_mul(xs[pos], xscale) : xs[pos];
       if (METRIC01 == 0) {
-        const float diff = ex_sub(qp[pos], xs[pos]);
+        const float diff = ex_sub(qp[pos], xv);
         tail = ex_add(tail, ex_mul(diff, diff));
       } else {
-        tail = ex_add(tail, ex_mul(qp[pos], xs[pos]));
+        tail = ex_add(tail, ex_mul(qp[pos], xv));
       }
     }
     if (METRIC01 != 0 && body) return ex_sub(ex_add(ex_sub(1.0f, res), ex_sub(1.0f, tail)), 1.0f);  // see canon_dist
@@ -381,9 +398,10 @@ __device__ __forceinline__ float canon_dist_group_t(const float* __restrict__ qp
 // Two rows of exactly 16 * N16 floats by one 4-lane group, all 2 * N16 loads of the lane in flight before the first
 // product (a 128-dim row is ONE ring block of canon_dist_group_t: with more than 16 fresh neighbours the second pass
 // would wait a second memory round trip).  Same arithmetic and order per row as canon_dist_group_t.
-template <int METRIC01, int N16>
+template <int METRIC01, int N16, bool SCALE = false>
 __device__ __forceinline__ void canon_dist_group_pair(const float* __restrict__ qp, const float* __restrict__ xa,
-                                                      const float* __restrict__ xb, int sub, float& res_a, float& res_b) {
+                                                      const float* __restrict__ xb, int sub, float& res_a, float& res_b,
+                                                      float sa = 1.0f, float sb = 1.0f) {
   const float4* a4 = (const float4*)xa + sub;
   const float4* b4 = (const float4*)xb + sub;
   const float4* q4 = (const float4*)qp + sub;
@@ -394,9 +412,9 @@ __device__ __forceinline__ void canon_dist_group_pair(const float* __restrict__ 
   for (int i = 0; i < N16; ++i) rb[i] = b4[i * 4];
   float pa = 0.0f, pb = 0.0f;
 #pragma unroll
-  for (int i = 0; i < N16; ++i) canon_group_step<METRIC01>(ra[i], q4[i * 4], pa);
+  for (int i = 0; i < N16; ++i) canon_group_step<METRIC01, SCALE>(ra[i], q4[i * 4], pa, 4, sa);
 #pragma unroll
-  for (int i = 0; i < N16; ++i) canon_group_step<METRIC01>(rb[i], q4[i * 4], pb);
+  for (int i = 0; i < N16; ++i) canon_group_step<METRIC01, SCALE>(rb[i], q4[i * 4], pb, 4, sb);
   const float a0 = __shfl(pa, 0, 4), a1 = __shfl(pa, 1, 4), a2 = __shfl(pa, 2, 4), a3 = __shfl(pa, 3, 4);
   const float b0 = __shfl(pb, 0, 4), b1 = __shfl(pb, 1, 4), b2 = __shfl(pb, 2, 4), b3 = __shfl(pb, 3, 4);
   res_a = ex_add(ex_add(ex_add(a0, a1), a2), a3);
@@ -412,9 +430,12 @@ __device__ __forceinline__ void canon_dist_group_pair(const float* __restrict__ 
 // (canon_dist_group_t); rows of 32 / 64 / 96 / 128 / 192 / 256 dims go 32 per pass, two per group, with the loads
 // of both rows in flight together (canon_dist_group_pair) — at 128 dims and 27 fresh neighbours per expansion that is
 // one memory round trip per expansion instead of two (6.25 M x 128-class workloads: -20 % kernel time).
-template <int METRIC01>
-__device__ __forceinline__ float wave_group_dists(const float* __restrict__ qs, const float* __restrict__ Xs, uint32_t ld,
-                                                  uint32_t dims, const uint32_t* ids_l, uint32_t count, int lane) {
+// xscale (optional): per-row scale applied to the row's elements on the fly (single-copy graph spaces, cosine:
+// inv_norm) — nullptr: the rows are used as stored.
+template <int METRIC01, bool SCALE>
+__device__ __forceinline__ float wave_group_dists_t(const float* __restrict__ qs, const float* __restrict__ Xs, uint32_t ld,
+                                                    uint32_t dims, const uint32_t* ids_l, uint32_t count, int lane,
+                                                    const float* __restrict__ xscale) {
   float mine = __builtin_inff();
   const bool pairable = dims <= 256 && (dims == 32 || dims == 64 || dims == 96 || dims == 128 || dims == 192 || dims == 256);
   if (pairable && count > 16) {
@@ -423,16 +444,18 @@ __device__ __forceinline__ float wave_group_dists(const float* __restrict__ qs, 
       float res_a = __builtin_inff(), res_b = __builtin_inff();
       if (ra < count) {
         const bool have_b = rb < count;  // a missing second row: the first one again, result dropped
-        const float* xa = Xs + (size_t)ids_l[ra] * ld;
-        const float* xb = Xs + (size_t)ids_l[have_b ? rb : ra] * ld;
+        const uint32_t ia = ids_l[ra], ib = ids_l[have_b ? rb : ra];
+        const float sa = SCALE ? xscale[ia] : 1.0f, sb = SCALE ? xscale[ib] : 1.0f;
+        const float* xa = Xs + (size_t)ia * ld;
+        const float* xb = Xs + (size_t)ib * ld;
         const int sub = lane & 3;
         switch (dims) {
-          case 32: canon_dist_group_pair<METRIC01, 2>(qs, xa, xb, sub, res_a, res_b); break;
-          case 64: canon_dist_group_pair<METRIC01, 4>(qs, xa, xb, sub, res_a, res_b); break;
-          case 96: canon_dist_group_pair<METRIC01, 6>(qs, xa, xb, sub, res_a, res_b); break;
-          case 128: canon_dist_group_pair<METRIC01, 8>(qs, xa, xb, sub, res_a, res_b); break;
-          case 192: canon_dist_group_pair<METRIC01, 12>(qs, xa, xb, sub, res_a, res_b); break;
-          default: canon_dist_group_pair<METRIC01, 16>(qs, xa, xb, sub, res_a, res_b); break;
+          case 32: canon_dist_group_pair<METRIC01, 2, SCALE>(qs, xa, xb, sub, res_a, res_b, sa, sb); break;
+          case 64: canon_dist_group_pair<METRIC01, 4, SCALE>(qs, xa, xb, sub, res_a, res_b, sa, sb); break;
+          case 96: canon_dist_group_pair<METRIC01, 6, SCALE>(qs, xa, xb, sub, res_a, res_b, sa, sb); break;
+          case 128: canon_dist_group_pair<METRIC01, 8, SCALE>(qs, xa, xb, sub, res_a, res_b, sa, sb); break;
+          case 192: canon_dist_group_pair<METRIC01, 12, SCALE>(qs, xa, xb, sub, res_a, res_b, sa, sb); break;
+          default: canon_dist_group_pair<METRIC01, 16, SCALE>(qs, xa, xb, sub, res_a, res_b, sa, sb); break;
         }
         if (!have_b) res_b = __builtin_inff();
       }
@@ -444,11 +467,25 @@ __device__ __forceinline__ float wave_group_dists(const float* __restrict__ qs, 
   for (uint32_t base = 0; base < count; base += 16) {
     const uint32_t r = base + ((uint32_t)lane >> 2);
     float res = __builtin_inff();
-    if (r < count) res = canon_dist_group_t<METRIC01>(qs, Xs + (size_t)ids_l[r] * ld, lane & 3, dims);
+    if (r < count) {
+      const uint32_t id = ids_l[r];
+      // (the scale is requested FIRST, as an ordered load: it is the oldest entry of the load queue when the first
+      // product needs it — sunk below the row's ring loads it would be the youngest, and waiting for it would drain
+      // the ring)
+      const float xsc = SCALE ? __hip_atomic_load(xscale + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 1.0f;
+      res = canon_dist_group_t<METRIC01, SCALE>(qs, Xs + (size_t)id * ld, lane & 3, dims, xsc);
+    }
     const float got = __shfl(res, (lane & 15) << 2, 64);
     if (((uint32_t)lane & ~15u) == base && (uint32_t)lane < count) mine = got;
   }
   return mine;
+}
+template <int METRIC01>
+__device__ __forceinline__ float wave_group_dists(const float* __restrict__ qs, const float* __restrict__ Xs, uint32_t ld,
+                                                  uint32_t dims, const uint32_t* ids_l, uint32_t count, int lane,
+                                                  const float* __restrict__ xscale = nullptr) {
+  if (METRIC01 == 1 && xscale) return wave_group_dists_t<METRIC01, true>(qs, Xs, ld, dims, ids_l, count, lane, xscale);
+  return wave_group_dists_t<METRIC01, false>(qs, Xs, ld, dims, ids_l, count, lane, nullptr);
 }
 
 // runtime-dispatch form (metric: 0 = L2^2, 1 = 1 - inner product; scale_x: cosine rows) used by the
@@ -723,8 +760,11 @@ hipError_t launch_scatter_results(const uint64_t* ids, const float* dist, const 
 
 // per-row statistics for rows [row0, row0+n): inv_norm (cosine), rowp (a,b) for the scan epilogue;
 // *max_sumsq (optional) is raised to the largest |x|^2 seen (the certification margin's norm bound)
+// perm: the fp32 rows are stored block-permuted (single-copy graph spaces); the sums keep the logical order
 hipError_t launch_row_stats(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
-                            int metric, float* inv_norm, float2* rowp, float* max_sumsq, hipStream_t st);
+                            int metric, float* inv_norm, float2* rowp, float* max_sumsq, hipStream_t st, int perm = 0);
+// single-copy graph spaces: rows [row0, row0 + n) (or rows ids[0..n)) into the search copy's block order, in place
+hipError_t launch_permute_blocks(float* X, uint32_t ld, uint64_t row0, uint64_t n, const uint64_t* ids, hipStream_t st);
 // rowp for padding rows [row0, row0+n): (0, +inf)
 hipError_t launch_rowp_pad(float2* rowp, uint64_t row0, uint64_t n, hipStream_t st);
 // graph mode: rows [row0, row0+n) of the search copy (16-float blocks permuted for the four SSE partial
@@ -749,6 +789,7 @@ struct GraphArgs {
   const float* X;           // rows [cap][ld]
   const float* Xs;          // search copy [cap][ld] (launch_make_search_copy)
   const float* inv_norm;    // cosine
+  const float* xscale = nullptr;  // single-copy graph spaces, cosine: Xs holds RAW permuted rows, scaled by inv_norm on the fly
   const uint32_t* adj0;     // [n][M0], pad 0xFFFFFFFF, stored order
   const uint32_t* up_start; // [n]: first upper list of the node (levels 1..L consecutive) or ~0
   const uint32_t* up_lists; // [*][M], pad 0xFFFFFFFF
@@ -793,6 +834,7 @@ struct InsertArgs {
   const float* X;
   const float* Xs;         // search copy (launch_make_search_copy)
   const float* inv_norm;
+  const float* xscale;     // single-copy graph spaces, cosine: Xs holds RAW permuted rows, scaled by inv_norm on the fly (else nullptr)
   uint32_t* adj0;          // [cap][M0]
   uint32_t* up_start;      // [cap]
   uint32_t* up_lists;      // [*][M]

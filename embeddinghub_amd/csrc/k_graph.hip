@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * WAVES) void graph_search_kernel(const GraphArg
       const uint32_t cnt = ctrl[0];
       if (cnt == 0xFFFFFFFFu) break;
       if (cnt > 16) {
-        const float d = wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l + 16, cnt - 16, lane);
+        const float d = wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l + 16, cnt - 16, lane, a.xscale);
         if ((uint32_t)lane < cnt - 16) hd[lane] = d;
       }
       __syncthreads();  // B: the distances are published
@@ -199,12 +199,12 @@ __global__ __launch_bounds__(64 * WAVES) void graph_search_kernel(const GraphArg
     if (WAVES > 1) {
       if (lane == 0) ctrl[0] = count;
       __syncthreads();  // A
-      float d = wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l, count < 16 ? count : 16, lane);
+      float d = wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l, count < 16 ? count : 16, lane, a.xscale);
       __syncthreads();  // B
       if (lane >= 16 && (uint32_t)lane < count) d = hd[lane - 16];
       return d;
     }
-    return wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l, count, lane);
+    return wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l, count, lane, a.xscale);
   };
 #else
   auto lane_dist = [&](uint32_t count) -> float {

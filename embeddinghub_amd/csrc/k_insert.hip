@@ -68,15 +68,20 @@ __device__ __forceinline__ uint32_t lb_lds(const uint64_t* a, uint32_t n, uint64
 // inputs of SSE partial sum j in order).  Piece j of a block therefore feeds partial sum j with its four products one
 // after the other: the same additions in the same order as walking the raw rows 16 bytes at a time, and the kernels
 // here need neither the raw rows nor their norms (fp16 row storage: the search copy is made from the rounded rows).
+// sa / sb: per-row scales applied to the elements on the fly (single-copy graph spaces, cosine: the rows are stored
+// raw; x * inv_norm is the normalised row hnswlib-python stores, one rounding per element).  1.0f: the rows as stored
+// (a multiplication by one is exact).
 __device__ __forceinline__ float row_row_dist(int metric01, const float* __restrict__ xa, const float* __restrict__ xb,
-                                              uint32_t dims) {
+                                              uint32_t dims, float sa = 1.0f, float sb = 1.0f) {
   uint32_t body;
   if ((dims & 15u) == 0 || (dims & 3u) == 0) body = dims;
   else if (dims > 16) body = dims & ~15u;
   else if (dims > 4) body = dims & ~3u;
   else body = 0;
   float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  auto step = [&](const float4 a, const float4 b, float& acc, int ncomp) {
+  auto step = [&](float4 a, float4 b, float& acc, int ncomp) {
+    a.x = ex_mul(a.x, sa); a.y = ex_mul(a.y, sa); a.z = ex_mul(a.z, sa); a.w = ex_mul(a.w, sa);
+    b.x = ex_mul(b.x, sb); b.y = ex_mul(b.y, sb); b.z = ex_mul(b.z, sb); b.w = ex_mul(b.w, sb);
     if (metric01 == 0) {
       const float d0 = ex_sub(a.x, b.x), d1 = ex_sub(a.y, b.y), d2 = ex_sub(a.z, b.z), d3 = ex_sub(a.w, b.w);
       acc = ex_add(acc, ex_mul(d0, d0));
@@ -120,11 +125,12 @@ __device__ __forceinline__ float row_row_dist(int metric01, const float* __restr
     float tail = 0.0f;
     for (uint32_t m = body; m < dims; ++m) {
       const uint32_t pos = search_copy_pos(m);
+      const float va = ex_mul(xa[pos], sa), vb = ex_mul(xb[pos], sb);
       if (metric01 == 0) {
-        const float d = ex_sub(xa[pos], xb[pos]);
+        const float d = ex_sub(va, vb);
         tail = ex_add(tail, ex_mul(d, d));
       } else {
-        tail = ex_add(tail, ex_mul(xa[pos], xb[pos]));
+        tail = ex_add(tail, ex_mul(va, vb));
       }
     }
     if (metric01 != 0 && body) return ex_sub(ex_add(ex_sub(1.0f, res), ex_sub(1.0f, tail)), 1.0f);  // see canon_dist
@@ -154,7 +160,8 @@ __device__ __forceinline__ uint32_t select_heuristic(const InsertArgs& a, const 
     bool bad = false;
     if ((uint32_t)lane < nk) {
       const uint32_t rid = (uint32_t)(kept[lane] & 0xFFFFFFFFull) >> 1;
-      const float d = row_row_dist(metric01, a.Xs + (size_t)rid * a.ld, a.Xs + (size_t)cid * a.ld, a.dims);
+      const float d = row_row_dist(metric01, a.Xs + (size_t)rid * a.ld, a.Xs + (size_t)cid * a.ld, a.dims,
+                                   a.xscale ? a.xscale[rid] : 1.0f, a.xscale ? a.xscale[cid] : 1.0f);
       bad = d < dq;
     }
     if (!__any(bad)) {
@@ -189,14 +196,17 @@ __global__ __launch_bounds__(64) void insert_search_kernel(const InsertArgs a) {
   const int metric01 = a.metric == 0 ? 0 : 1;
   // the query is the new row itself, prepared the way hnswlib stores it: its search-copy row (normalised for
   // cosine, permuted like every row the distance passes read)
-  for (uint32_t i = lane; i < a.ld; i += 64) qs[i] = a.Xs[(size_t)me * a.ld + i];
+  {
+    const float qsc = a.xscale ? a.xscale[me] : 1.0f;   // (single-copy graph spaces: the stored row is raw)
+    for (uint32_t i = lane; i < a.ld; i += 64) qs[i] = ex_mul(a.Xs[(size_t)me * a.ld + i], qsc);
+  }
   EHX_ISYNC();
 
   // canonical distances of rows ids_l[0..count) to the new row: 4-lane groups reading the search copy in coalesced
   // 64-byte pieces (wave_group_dists, as k_graph.hip); lane p gets row p
   auto lane_dist = [&](uint32_t count) -> float {
     return metric01 == 0 ? wave_group_dists<0>(qs, a.Xs, a.ld, a.dims, ids_l, count, lane)
-                         : wave_group_dists<1>(qs, a.Xs, a.ld, a.dims, ids_l, count, lane);
+                         : wave_group_dists<1>(qs, a.Xs, a.ld, a.dims, ids_l, count, lane, a.xscale);
   };
   auto list_of = [&](uint32_t node, int level, uint32_t* width) -> const uint32_t* {
     if (level == 0) {
@@ -409,7 +419,8 @@ __device__ __forceinline__ void link_incoming(const InsertArgs& a, uint32_t* lst
   }
   // full: candidates = {new} u list with distances to s, heuristic with the level's max degree
   auto key_of = [&](uint32_t id) {
-    const float d = row_row_dist(metric01, a.Xs + (size_t)id * a.ld, a.Xs + (size_t)s * a.ld, a.dims);
+    const float d = row_row_dist(metric01, a.Xs + (size_t)id * a.ld, a.Xs + (size_t)s * a.ld, a.dims,
+                                 a.xscale ? a.xscale[id] : 1.0f, a.xscale ? a.xscale[s] : 1.0f);
     return ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)id << 1);
   };
   if (cnt < 64) {
@@ -552,7 +563,8 @@ __global__ __launch_bounds__(64) void update_neigh_kernel(const InsertArgs a, co
     uint64_t key = kKeyInf;
     if ((uint32_t)lane < n_here) {
       const uint32_t id = cand_ids[base + lane];
-      const float d = row_row_dist(metric01, a.Xs + (size_t)s * a.ld, a.Xs + (size_t)id * a.ld, a.dims);
+      const float d = row_row_dist(metric01, a.Xs + (size_t)s * a.ld, a.Xs + (size_t)id * a.ld, a.dims,
+                                   a.xscale ? a.xscale[s] : 1.0f, a.xscale ? a.xscale[id] : 1.0f);
       key = ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)id << 1);
     }
     key = wsort64(key, lane);

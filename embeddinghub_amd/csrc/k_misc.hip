@@ -97,16 +97,37 @@ hipError_t launch_prep_queries(const float* q_in, uint32_t nq, uint32_t dims, ui
   return hipGetLastError();
 }
 
+// the same sequential sum over a row stored block-permuted (single-copy graph spaces: element m sits at
+// search_copy_pos(m)) — the ORDER of the additions is the logical one
+__device__ __forceinline__ float seq_sumsq_perm(const float* __restrict__ x, uint32_t dims) {
+  float s = 0.0f;
+  uint32_t i = 0;
+  for (; i + 8 <= dims; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = x[search_copy_pos(i + j)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s = ex_add(s, ex_mul(v[j], v[j]));
+  }
+  for (; i < dims; ++i) {
+    const float v = x[search_copy_pos(i)];
+    s = ex_add(s, ex_mul(v, v));
+  }
+  return s;
+}
+
 template <typename XT>
 __global__ __launch_bounds__(256) void row_stats_kernel(const XT* __restrict__ X, uint64_t row0,
                                                         uint64_t n, uint32_t dims, uint32_t ld, int metric,
                                                         float* __restrict__ inv_norm,
                                                         float2* __restrict__ rowp,
-                                                        unsigned int* __restrict__ max_sumsq) {
+                                                        unsigned int* __restrict__ max_sumsq, int perm) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t r = row0 + i;
-  const float s = seq_sumsq(X + r * ld, dims);
+  float s;
+  if constexpr (sizeof(XT) == 4) s = perm ? seq_sumsq_perm((const float*)(X + r * ld), dims) : seq_sumsq(X + r * ld, dims);
+  else s = seq_sumsq(X + r * ld, dims);
   // largest |x|^2 ever written to the space (bit pattern of a non-negative float orders like the float;
   // NaN / Inf rows park it at +Inf): the re-rank's certification margin needs a bound of every row's norm
   if (max_sumsq) atomicMax(max_sumsq, (s == s) ? __float_as_uint(s) : 0x7F800000u);
@@ -122,15 +143,45 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const XT* __restrict__ X
 }
 
 hipError_t launch_row_stats(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
-                            int metric, float* inv_norm, float2* rowp, float* max_sumsq, hipStream_t st) {
+                            int metric, float* inv_norm, float2* rowp, float* max_sumsq, hipStream_t st, int perm) {
   if (n == 0) return hipSuccess;
   const uint32_t grid = (uint32_t)((n + 255) / 256);
   if (x_half)
     hipLaunchKernelGGL(row_stats_kernel<__half>, dim3(grid), dim3(256), 0, st, (const __half*)X, row0, n, dims, ld,
-                       metric, inv_norm, rowp, (unsigned int*)max_sumsq);
+                       metric, inv_norm, rowp, (unsigned int*)max_sumsq, 0);
   else
     hipLaunchKernelGGL(row_stats_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)X, row0, n, dims, ld,
-                       metric, inv_norm, rowp, (unsigned int*)max_sumsq);
+                       metric, inv_norm, rowp, (unsigned int*)max_sumsq, perm);
+  return hipGetLastError();
+}
+
+// ---- single-copy graph spaces: the rows are stored ONCE, in the search copy's block order, raw -------------------
+// Within every 16-float block element 4 i + j moves to 4 j + i (search_copy_pos: a 4 x 4 transpose, its own inverse).
+// In place: one thread per block.  ids (optional): the rows to permute (rows written in place); else rows
+// [row0, row0 + n).  Applied exactly once to a freshly written row — a second application would undo it.
+__global__ __launch_bounds__(256) void permute_blocks_kernel(float* __restrict__ X, uint32_t ld, uint64_t row0, uint64_t n,
+                                                             const uint64_t* __restrict__ ids) {
+  const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t bpr = ld >> 4;   // 16-float blocks per row (ld % 32 == 0)
+  if (e >= n * bpr) return;
+  const uint64_t i = e / bpr;
+  const uint64_t r = ids ? ids[i] : row0 + i;
+  float4* b = (float4*)(X + r * ld + (size_t)(e % bpr) * 16);
+  const float4 v0 = b[0], v1 = b[1], v2 = b[2], v3 = b[3];
+  b[0] = make_float4(v0.x, v1.x, v2.x, v3.x);
+  b[1] = make_float4(v0.y, v1.y, v2.y, v3.y);
+  b[2] = make_float4(v0.z, v1.z, v2.z, v3.z);
+  b[3] = make_float4(v0.w, v1.w, v2.w, v3.w);
+}
+
+hipError_t launch_permute_blocks(float* X, uint32_t ld, uint64_t row0, uint64_t n, const uint64_t* ids, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const uint64_t max_rows = kMaxWorkItems / (ld >> 4);
+  for (uint64_t r0 = 0; r0 < n; r0 += max_rows) {
+    const uint64_t m = n - r0 < max_rows ? n - r0 : max_rows;
+    hipLaunchKernelGGL(permute_blocks_kernel, dim3((uint32_t)((m * (ld >> 4) + 255) / 256)), dim3(256), 0, st, X, ld,
+                       row0 + r0, m, ids ? ids + r0 : nullptr);
+  }
   return hipGetLastError();
 }
 

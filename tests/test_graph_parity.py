@@ -325,3 +325,53 @@ def test_update_in_place_every_metric_and_row_type(em, om, dtype):
         assert b.get("k%d" % i).tobytes() == rnd(upd).tobytes()
         _same_graph(b, h)
     b.drop()
+
+
+# ---- single-copy graph storage (round 4) ------------------------------------------------
+# An fp32 graph space stores its rows ONCE, in the search copy's block order, raw; cosine rows are scaled by 1/|x| on
+# the fly in the kernels.  What must hold: Get returns the bytes that were Set (vectorstore_test.go:107-113), for every
+# metric, for row lengths that are not a multiple of the 16-float block, after in-place updates, and for a batch that
+# writes the same key twice; and the search on the oracle's graph stays the oracle's (the tests above, which all run on
+# such spaces).
+@pytest.mark.parametrize("em,om", METRICS)
+@pytest.mark.parametrize("d", [3, 16, 33, 100, 128, 768])
+def test_single_copy_graph_space_get_is_byte_exact_and_search_is_the_oracles(d, em, om, monkeypatch):
+    # (L2 and inner-product graph spaces are single-copy by default; cosine keeps its normalised search copy unless
+    # EHX_GRAPH_ONE_COPY=1 — read when the space is created — trades 7-14 % of the search rate for half the HBM)
+    monkeypatch.setenv("EHX_GRAPH_ONE_COPY", "1")
+    rng = np.random.default_rng(d * 7 + em)
+    n = 600
+    X = rng.standard_normal((n, d)).astype(np.float32) * np.float32(3.0)
+    s = ehx.Space.unique("g1copy", d, metric=em, mode=ehx.MODE_GRAPH)
+    keys = ["k%d" % i for i in range(n)]
+    s.set_batch(keys[:400], X[:400])              # one contiguous batch
+    for i in range(400, 420):                     # single-row Sets
+        s.set(keys[i], X[i])
+    s.set_batch(keys[420:], X[420:])
+    for i in (0, 1, 15, 16, 399, 400, 419, 420, n - 1):
+        assert s.get(keys[i]).tobytes() == X[i].tobytes(), i
+    # in-place updates: scattered ids in one batch, and the same key twice in one batch (the last one wins)
+    upd = rng.standard_normal((5, d)).astype(np.float32)
+    s.set_batch(["k7", "k300", "k7", "k599", "k8"], upd)
+    X[7], X[300], X[599], X[8] = upd[2], upd[1], upd[3], upd[4]
+    for i in (6, 7, 8, 9, 299, 300, 301, 598, 599):
+        assert s.get(keys[i]).tobytes() == X[i].tobytes(), i
+    # the sequential GPU build is the oracle's graph (test_sequential_gpu_build_is_the_oracles_graph at larger sizes);
+    # here: a fresh space, rows written once, search against the oracle's HNSW built over the same rows
+    g = ehx.Space.unique("g1copy-b", d, metric=em, mode=ehx.MODE_GRAPH)
+    g.set_batch(keys, X)
+    h = pyoracle.Hnsw(d, om, n)
+    h.add_rows(X)
+    Q = rng.standard_normal((40, d)).astype(np.float32)
+    for ef in (10, 64):
+        g.set_ef(ef)
+        h.set_ef(ef)
+        ids, dist, cnt = g.knn(Q, 10)
+        for i in range(Q.shape[0]):
+            o_ids, o_dist = h.search(Q[i], 10)
+            assert list(ids[i, :len(o_ids)]) == list(o_ids), (ef, i)
+            assert dist[i, :len(o_dist)].tobytes() == o_dist.tobytes(), (ef, i)
+    st = g.stats()
+    assert st["n_rows"] == n
+    s.drop()
+    g.drop()
