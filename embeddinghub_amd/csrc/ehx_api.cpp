@@ -2227,16 +2227,15 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
   s->esz = s->x_half ? 2 : sizeof(float);
   if (params) s->params = *params;
   {
-    // Single-copy storage of a graph space's rows (round 4): free for L2^2 and inner product (the search copy of those
-    // rows WAS a permuted duplicate), so it is what they get.  A cosine space's search copy holds the NORMALISED rows;
-    // with one copy the kernels form x * inv_norm on the fly — bit-identical, half the HBM (10 M x 768: 61 -> 31 GB), but
-    // measured 7-14 % slower at d = 768 (one wave per SIMD: every extra instruction of the row walk is on the critical
-    // path; profiles/r04_q_*, r04_r_*) — so cosine keeps both copies unless EHX_GRAPH_ONE_COPY=1 asks for the memory.
-    // EHX_GRAPH_TWO_COPIES=1: every graph space as in rounds 1-3 (A/B).
+    // Single-copy storage of a graph space's rows (round 4): the search copy — rows in the 4 x 4 block order the graph
+    // kernels read — is the ONLY copy.  Free for L2^2 and inner product (their search copy was a permuted duplicate).
+    // A cosine space's search copy used to hold the NORMALISED rows; with one copy the kernels form x * inv_norm on the
+    // fly — bit-identical results, half the HBM (10 M x 768: 61 -> 31 GB).  The scale must be REQUESTED BEFORE the
+    // row's ring loads (ehx_kernels.h, wave_group_dists_t): sunk below them it is the youngest load when the first
+    // product needs it and the wait drains the ring — that cost 13 % at 2 M x 768 (profiles/r04_r_*); requested first
+    // the cost is 2 % (profiles/r04_s_*, r04_t_*).  EHX_GRAPH_TWO_COPIES=1: raw rows + search copy as in rounds 1-3.
     const char* two = getenv("EHX_GRAPH_TWO_COPIES");
-    const char* one = getenv("EHX_GRAPH_ONE_COPY");
-    const bool want = metric != EHX_METRIC_COSINE || (one && atoi(one) != 0);
-    s->x_perm = params && params->mode == EHX_MODE_GRAPH && !s->x_half && want && !(two && atoi(two) != 0);
+    s->x_perm = params && params->mode == EHX_MODE_GRAPH && !s->x_half && !(two && atoi(two) != 0);
   }
   if (parent) s->params.shards = params->shards;
   if (s->params.mode != EHX_MODE_FLAT && s->params.mode != EHX_MODE_GRAPH)

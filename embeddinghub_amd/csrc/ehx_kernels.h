@@ -283,21 +283,19 @@ __device__ __forceinline__ float canon_dist_lane_t(const float* __restrict__ q, 
 // SCALE (round 4, single-copy graph spaces: the rows are stored raw and permuted, not normalised): every element of
 // the row is multiplied by xs first — hnswlib-python's stored normalised row x * inv_norm, one rounding per element,
 // formed on the fly; the products with the query then see exactly the values the normalised copy held.
+// x * xs per element as two packed multiplies (v_pk_mul_f32: IEEE, one rounding per element like the scalar form)
+__device__ __forceinline__ float4 scale_f4(float4 xv, float xs) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 sc = {xs, xs};
+  f32x2 lo = {xv.x, xv.y}, hi = {xv.z, xv.w};
+  lo = lo * sc;
+  hi = hi * sc;
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
 template <int METRIC01, bool SCALE = false>
 __device__ __forceinline__ void canon_group_step(float4 xv, const float4 qv, float& p, int ncomp = 4, float xs = 1.0f) {
-  if (SCALE) {
-    // two packed multiplies (v_pk_mul_f32: IEEE, one rounding per element like the scalar form): with one wave per
-    // SIMD every issued instruction of the row walk is on the critical path
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 sc = {xs, xs};
-    f32x2 lo = {xv.x, xv.y}, hi = {xv.z, xv.w};
-    lo = lo * sc;
-    hi = hi * sc;
-    xv.x = lo.x;
-    xv.y = lo.y;
-    xv.z = hi.x;
-    xv.w = hi.y;
-  }
+  if (SCALE) xv = scale_f4(xv, xs);
   if (METRIC01 == 0) {
     const float d0 = ex_sub(qv.x, xv.x), d1 = ex_sub(qv.y, xv.y), d2 = ex_sub(qv.z, xv.z), d3 = ex_sub(qv.w, xv.w);
     p = ex_add(p, ex_mul(d0, d0));
@@ -332,8 +330,18 @@ __device__ __forceinline__ float canon_dist_group_t(const float* __restrict__ qp
   const float4* q4 = (const float4*)qp + sub;
 #define EHX_GRP_LOAD(R, B)                                        \
   _Pragma("unroll") for (int i_ = 0; i_ < BL; ++i_) R[i_] = x4[((size_t)(B) * BL + i_) * 4];
-#define EHX_GRP_ACC(R, B)                                         \
-  _Pragma("unroll") for (int i_ = 0; i_ < BL; ++i_) canon_group_step<METRIC01, SCALE>(R[i_], q4[((size_t)(B) * BL + i_) * 4], p, 4, xscale);
+  // (SCALE: the ring block's query pieces are read from LDS together, ahead of its products — left to the scheduler,
+  // the scaled walk reads one piece, waits for it, multiplies, and pays the LDS latency once per 16-float block)
+#define EHX_GRP_ACC(R, B)                                                                                            \
+  if (SCALE) {                                                                                                       \
+    float4 qv_[BL];                                                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < BL; ++i_) qv_[i_] = q4[((size_t)(B) * BL + i_) * 4];                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < BL; ++i_) R[i_] = scale_f4(R[i_], xscale);                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < BL; ++i_) canon_group_step<METRIC01, false>(R[i_], qv_[i_], p, 4, 1.0f); \
+  } else {                                                                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < BL; ++i_)                                                                \
+      canon_group_step<METRIC01, false>(R[i_], q4[((size_t)(B) * BL + i_) * 4], p, 4, 1.0f);                         \
+  }
   uint32_t b = 0;
   if (nblk >= 2) {
     EHX_GRP_LOAD(r0, 0)
@@ -445,7 +453,8 @@ __device__ __forceinline__ float wave_group_dists_t(const float* __restrict__ qs
       if (ra < count) {
         const bool have_b = rb < count;  // a missing second row: the first one again, result dropped
         const uint32_t ia = ids_l[ra], ib = ids_l[have_b ? rb : ra];
-        const float sa = SCALE ? xscale[ia] : 1.0f, sb = SCALE ? xscale[ib] : 1.0f;
+        const float sa = SCALE ? __hip_atomic_load(xscale + ia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 1.0f;
+        const float sb = SCALE ? __hip_atomic_load(xscale + ib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 1.0f;
         const float* xa = Xs + (size_t)ia * ld;
         const float* xb = Xs + (size_t)ib * ld;
         const int sub = lane & 3;

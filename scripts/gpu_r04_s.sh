@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 4, session s: cosine single-copy search with the scale requested first (ordered load) against two copies
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+O=gpurun_out
+( EHX_GRAPH_ONE_COPY=1 timeout 600 python -m pytest tests/test_graph_parity.py -m gpu -x -q --timeout=500 2>&1 | tail -4 ) > $O/r04_s_pytest_tail.txt; tail -2 $O/r04_s_pytest_tail.txt
+run() {  # label, env, args
+  env $2 timeout 400 python scripts/bench_graph.py $3 --gpu-build --build-batch 4096 --batches 1024 --reps 5 2>/dev/null | tee -a $O/r04_s_graph_copies.jsonl | python -c "
+import sys, json
+for l in sys.stdin:
+    try: r = json.loads(l)
+    except Exception: continue
+    print('$1', r['workload'][:60], 'ef', r['workload'].split('ef=')[-1], 'kernel_ms', r['kernel_ms'], 'n_dist', r['n_dist_per_query'], 'frac', r['roofline']['frac'])
+"
+}
+: > $O/r04_s_graph_copies.jsonl
+run "cosine one copy" "EHX_GRAPH_ONE_COPY=1" "--rows 2000000 --dims 768 --metric cosine --efs 100,400"
+run "cosine two copies" "EHX_GRAPH_ONE_COPY=0" "--rows 2000000 --dims 768 --metric cosine --efs 100,400"

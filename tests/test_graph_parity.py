@@ -336,9 +336,9 @@ def test_update_in_place_every_metric_and_row_type(em, om, dtype):
 @pytest.mark.parametrize("em,om", METRICS)
 @pytest.mark.parametrize("d", [3, 16, 33, 100, 128, 768])
 def test_single_copy_graph_space_get_is_byte_exact_and_search_is_the_oracles(d, em, om, monkeypatch):
-    # (L2 and inner-product graph spaces are single-copy by default; cosine keeps its normalised search copy unless
-    # EHX_GRAPH_ONE_COPY=1 — read when the space is created — trades 7-14 % of the search rate for half the HBM)
-    monkeypatch.setenv("EHX_GRAPH_ONE_COPY", "1")
+    # (every fp32 graph space is single-copy by default; EHX_GRAPH_TWO_COPIES=1 — read when the space is created —
+    # restores raw rows + search copy)
+    monkeypatch.delenv("EHX_GRAPH_TWO_COPIES", raising=False)
     rng = np.random.default_rng(d * 7 + em)
     n = 600
     X = rng.standard_normal((n, d)).astype(np.float32) * np.float32(3.0)
