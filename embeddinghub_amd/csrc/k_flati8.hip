@@ -85,6 +85,18 @@ static_assert(kTileRows16 == 256 && kTileQ == 256, "kernel geometry is hard-wire
 #ifndef EHX_I8_COUNT
 #define EHX_I8_COUNT 0
 #endif
+// EHX_I8_FUSED (round 4 experiment, NOT in the shipped library: build with EHX_DEFS=-DEHX_I8_FUSED=1, then the
+// environment variable EHX_I8_FUSED=0/1 switches at run time): the epilogue of tile t-1 runs INSIDE the first stage of
+// tile t, row block by row block, its vector instructions between that stage's MFMAs ("fused epilogue" in the kernel).
+// Bit-identical results (243 parity tests, equal id checksums) and 1-5 % SLOWER on every shape measured on one box
+// (profiles/r04_v_ab_flat.jsonl: 10 M x 768 6.25 -> 6.33 ms, 1.25 M x 768 1.14 -> 1.17, 6.25 M x 128 1.19 -> 1.22,
+// 4 M x 384 1.73 -> 1.81): the instructions of the epilogue do not hide behind the MFMAs of their own SIMD (two waves
+// per SIMD already alternate on the matrix pipe with one filler per gap; four more per gap cost issue time), and where
+// the clock is power-limited (1.7 GHz at d = 768) overlap cannot shorten what is an energy bill.  Kept as a switch
+// because it is the obvious next idea and the measurement says no.
+#ifndef EHX_I8_FUSED
+#define EHX_I8_FUSED 0
+#endif
 #if EHX_I8_COUNT
 #define EHX_CNT(I) do { if (lane == 0) atomicAdd((unsigned long long*)a.cand + (I), 1ull); } while (0)
 #else
@@ -209,7 +221,7 @@ size_t scan_i8_lds_bytes() { return kLdsBytesI8; }
 // registers each; a stage row's 64 bytes are ONE k-step: lane l holds bytes [16 (l >> 4), +16) of row / query l & 15 of
 // its block — one ds_read_b128 per block and stage, twelve per stage as before.  Every block gets exactly one MFMA
 // per stage.  An accumulator block holds, per lane, rows 4 (l >> 4) + 0..3 of its 16 rows for query l & 15.
-template <bool DUMP, bool REV>
+template <bool DUMP, bool REV, bool FUSE>
 __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanArgsI8 a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -264,7 +276,10 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   const uint32_t tile_begin = a.tile0 + chunk * a.tiles_per_chunk;
   uint32_t tile_end = tile_begin + a.tiles_per_chunk;
   if (tile_end > a.tile0 + a.n_tiles) tile_end = a.tile0 + a.n_tiles;
-  const uint32_t my_tiles = tile_end > tile_begin ? tile_end - tile_begin : 0u;
+  // (uniform by construction; said so, or the loop bound lives in a vector register — and, this kernel being out of
+  // them, in scratch, reloaded behind an s_waitcnt vmcnt(0) once per tile)
+  const uint32_t my_tiles =
+      (uint32_t)__builtin_amdgcn_readfirstlane((int)(tile_end > tile_begin ? tile_end - tile_begin : 0u));
   const uint32_t ktiles = a.ld / kRowBI8;  // stages per tile (a.ld % 64 == 0)
 
   // ---- DMA duty of this wave: 1-KiB pieces w and w+8 of the X stage block and of the Q stage block (linear
@@ -458,6 +473,110 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     }
   };
 
+  // =============================== fused epilogue (EHX_I8_FUSED) ===============================
+  // The tile epilogue above sits between two tiles: ~160 vector instructions per wave during which the matrix pipe of
+  // its SIMD idles (both waves of a SIMD are there at the same time — the stage barriers keep them in step), 10 % of a
+  // 768-dim tile and more than half of a 128-dim one.  Fused form: when tile t is done only its four LEVELS are
+  // computed (epi_levels: ti4[cb], one per query of the lane); the accumulators are looked at during the FIRST stage of
+  // tile t+1, whose MFMAs start every block from zero and overwrite it: just before row block rb's four MFMAs, the
+  // lane's 16 accumulators of that row block are compared with their levels (EHX_E1: max, max3, compare per block,
+  // issued between the MFMAs of row block rb-1) and, if any lane of the wave has an alarm, judged exactly
+  // (epi_row_slow: the same hit path as above, the candidates of one 16-row block at a time — their registers are
+  // named statically, no select over the eight row blocks).  Same alarms, same hits; only the order in which a wave
+  // stages them differs (pools are sets).  Only row block 0's test and the levels remain outside the MFMA stream.
+  int ti4[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};  // (no tile waiting: nothing alarms)
+  uint32_t epi_tile_row0 = 0u, epi_rp_off = kRowpOffI8;
+  bool epi_al = false;
+  auto epi_levels = [&](uint32_t t) {  // tile t is complete; its parameters are tp_cur / tg_cur, its rows' in rp_slot
+    epi_tile_row0 = (tile_begin + t) * kTileRows16;
+    epi_rp_off = kRowpOffI8 + rp_slot * 4096u;
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int j15 = lane_e & 15, qd = lane_e >> 4;
+    const float4 tg = tg_cur;
+    const float gm = qd == 0 ? tg.x : (qd == 1 ? tg.y : (qd == 2 ? tg.z : tg.w));
+    // (v_rcp_f32 is good to 1 ulp: three roundings against a margin of 2e-6 — the level still errs low)
+    const float rgm = (1.0f - 2e-6f) * __builtin_amdgcn_rcpf(gm);
+    const float k_own = i8_alarm_k(tp_cur, qp_lds[wc * 64 + lane_e], qinv_lds[wc * 64 + lane_e]);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      // (ds_bpermute directly: __shfl derives its address from the lane id, a loop invariant the compiler then keeps
+      // alive across the stage loop — in scratch)
+      const float kq = __int_as_float(__builtin_amdgcn_ds_bpermute((cb * 16 + j15) << 2, __float_as_int(k_own)));
+      ti4[cb] = (int)fminf(fmaxf(kq * rgm, -2.1e9f), 2.1e9f);
+    }
+  };
+  auto epi_row_slow = [&](const i32x4 (&c)[4], const int rb) {
+    EHX_CNT(1);
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int j15 = lane_e & 15, qd = lane_e >> 4;
+    const uint32_t rbase = (uint32_t)(wr * 128) + 4u * (uint32_t)qd + 16u * (uint32_t)rb;
+    uint32_t pend = 0u;  // bit 4 cb + r
+#pragma unroll
+    for (int cb = 3; cb >= 0; --cb) {
+      uint32_t nib = 0u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nib |= (c[cb][r] >= ti4[cb]) ? (1u << r) : 0u;
+      pend = (pend << 4) | nib;
+    }
+    while (__any(pend != 0u)) {
+      EHX_CNT(3);
+      const bool hi = pend != 0u;
+      int v = 0;
+      uint32_t cbv = 0u, r = 0u;
+      if (hi) {
+        const int b = __builtin_ctz(pend);
+        pend &= pend - 1u;
+        cbv = (uint32_t)b >> 2;
+        r = (uint32_t)b & 3u;
+        i32x4 c4 = c[0];
+#pragma unroll
+        for (int cb = 1; cb < 4; ++cb) {
+          const bool pick = cbv == (uint32_t)cb;
+          c4[0] = pick ? c[cb][0] : c4[0];
+          c4[1] = pick ? c[cb][1] : c4[1];
+          c4[2] = pick ? c[cb][2] : c4[2];
+          c4[3] = pick ? c[cb][3] : c4[3];
+        }
+        v = r == 0u ? c4[0] : (r == 1u ? c4[1] : (r == 2u ? c4[2] : c4[3]));
+      }
+      const int ql = (int)(cbv * 16u) + j15;
+      const float4 qq = qp_lds[wc * 64 + ql];
+      i8_hit(v, hi, rbase + r, epi_tile_row0, epi_rp_off, qq, ql, w, a.n, stg_n);
+    }
+  };
+#if EHX_I8_ABL & 1
+#define EHX_E1(RB, CB) do { } while (0)
+#define EHX_EGO(RB) do { } while (0)
+#else
+#define EHX_E1(RB, CB)                                                                       \
+  do {                                                                                       \
+    const i32x4 c_ = acc[RB][CB];                                                            \
+    epi_al |= max(max(c_[0], c_[1]), max(c_[2], c_[3])) >= ti4[CB];                          \
+  } while (0)
+#if EHX_I8_ABL & 2
+#define EHX_EGO(RB)                                       \
+  do {                                                    \
+    if (__any(epi_al)) asm volatile("" ::: "memory");     \
+    epi_al = false;                                       \
+  } while (0)
+#else
+#define EHX_EGO(RB)                                       \
+  do {                                                    \
+    EHX_CNT(0);                                           \
+    if (__any(epi_al)) epi_row_slow(acc[RB], RB);         \
+    epi_al = false;                                       \
+  } while (0)
+#endif
+#endif
+  // every row block of the waiting tile, outside any stage (the last tile of the chunk)
+  auto epi_all_rows = [&]() {
+#define EHX_EROW(RB) do { EHX_E1(RB, 0); EHX_E1(RB, 1); EHX_E1(RB, 2); EHX_E1(RB, 3); EHX_EGO(RB); } while (0)
+    EHX_EROW(0); EHX_EROW(1); EHX_EROW(2); EHX_EROW(3); EHX_EROW(4); EHX_EROW(5); EHX_EROW(6); EHX_EROW(7);
+#undef EHX_EROW
+  };
+
   // ---- lock-step with the sibling workgroups of this chunk (see the header) ----
   uint32_t* const sync_ctr = (a.sync && a.xcd_map && a.q_tiles > 1) ? a.sync + chunk : nullptr;
   bool sync_on = sync_ctr != nullptr && !DUMP;
@@ -571,6 +690,65 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
                      EHX_SDMA_Q1(sd));                                                                   \
   } while (0)
 
+  // Fused first stage of a tile (EHX_I8_FUSED): the stage body with every block's first MFMA (from zero), row block
+  // rb+1's alarm test between the MFMAs of row block rb, and the (rare) exact judgement of a row block right before
+  // its accumulators are overwritten.
+#define EHX_STAGE16_FUSED(BC, BN, AN, BNX, DX0, DQ0, DX1, DQ1)                                           \
+  do {                                                                                                   \
+    EHX_E1(0, 0); EHX_E1(0, 1); EHX_E1(0, 2); EHX_E1(0, 3); EHX_EGO(0); EHX_SB();                        \
+    EHX_MFZ(BC, 0, 0); DX0; EHX_E1(1, 0);                  EHX_SB();                                     \
+    EHX_MFZ(BC, 0, 1);      EHX_E1(1, 1);                  EHX_SB();                                     \
+    EHX_MFZ(BC, 0, 2); DQ0; EHX_E1(1, 2);                  EHX_SB();                                     \
+    EHX_MFZ(BC, 0, 3);      EHX_E1(1, 3);                  EHX_SB();                                     \
+    EHX_EGO(1);                                            EHX_SB();                                     \
+    EHX_MFZ(BC, 1, 0); DX1; EHX_E1(2, 0);                  EHX_SB();                                     \
+    EHX_MFZ(BC, 1, 1);      EHX_E1(2, 1);                  EHX_SB();                                     \
+    EHX_MFZ(BC, 1, 2); DQ1; EHX_E1(2, 2);                  EHX_SB();                                     \
+    EHX_MFZ(BC, 1, 3);      EHX_E1(2, 3);                  EHX_SB();                                     \
+    EHX_EGO(2);                                            EHX_SB();                                     \
+    EHX_MFZ(BC, 2, 0);      EHX_E1(3, 0);                  EHX_SB();                                     \
+    EHX_MFZ(BC, 2, 1);      EHX_E1(3, 1);                  EHX_SB();                                     \
+    EHX_MFZ(BC, 2, 2);      EHX_E1(3, 2);                  EHX_SB();                                     \
+    EHX_MFZ(BC, 2, 3);      EHX_E1(3, 3);                  EHX_SB();                                     \
+    EHX_EGO(3);                                            EHX_SB();                                     \
+    EHX_MFZ(BC, 3, 0);      EHX_E1(4, 0);                  EHX_SB();                                     \
+    EHX_MFZ(BC, 3, 1);      EHX_E1(4, 1);                  EHX_SB();                                     \
+    EHX_MFZ(BC, 3, 2);      EHX_E1(4, 2);                  EHX_SB();                                     \
+    EHX_MFZ(BC, 3, 3);      EHX_E1(4, 3);                  EHX_SB();                                     \
+    EHX_EGO(4);                                            EHX_SB();                                     \
+    wait_vmcnt<8>();                                                                                     \
+    EHX_STAGE_BARRIER();                                                                                 \
+    EHX_SB();                                                                                            \
+    EHX_MFZ(BC, 4, 0); BN[0] = EHX_FR(smem + (BNX));        EHX_E1(5, 0); EHX_SB();                      \
+    EHX_MFZ(BC, 4, 1); BN[1] = EHX_FR(smem + (BNX) + 1024); EHX_E1(5, 1); EHX_SB();                      \
+    EHX_MFZ(BC, 4, 2); BN[2] = EHX_FR(smem + (BNX) + 2048); EHX_E1(5, 2); EHX_SB();                      \
+    EHX_MFZ(BC, 4, 3); BN[3] = EHX_FR(smem + (BNX) + 3072); EHX_E1(5, 3); EHX_SB();                      \
+    EHX_EGO(5);                                            EHX_SB();                                     \
+    EHX_MFZ(BC, 5, 0); fa[0] = EHX_FR(smem + (AN));         EHX_E1(6, 0); EHX_SB();                      \
+    EHX_MFZ(BC, 5, 1); fa[1] = EHX_FR(smem + (AN) + 1024);  EHX_E1(6, 1); EHX_SB();                      \
+    EHX_MFZ(BC, 5, 2); fa[2] = EHX_FR(smem + (AN) + 2048);  EHX_E1(6, 2); EHX_SB();                      \
+    EHX_MFZ(BC, 5, 3); fa[3] = EHX_FR(smem + (AN) + 3072);  EHX_E1(6, 3); EHX_SB();                      \
+    EHX_EGO(6);                                            EHX_SB();                                     \
+    EHX_MFZ(BC, 6, 0); fa[4] = EHX_FR(smem + (AN) + 4096);  EHX_E1(7, 0); EHX_SB();                      \
+    EHX_MFZ(BC, 6, 1); fa[5] = EHX_FR(smem + (AN) + 5120);  EHX_E1(7, 1); EHX_SB();                      \
+    EHX_MFZ(BC, 6, 2);                                      EHX_E1(7, 2); EHX_SB();                      \
+    EHX_MFZ(BC, 6, 3);                                      EHX_E1(7, 3); EHX_SB();                      \
+    EHX_EGO(7);                                            EHX_SB();                                     \
+    EHX_MFZ(BC, 7, 0); fa[6] = EHX_FR(smem + (AN) + 6144); EHX_SB();                                     \
+    EHX_MFZ(BC, 7, 1);                                     EHX_SB();                                     \
+    EHX_MFZ(BC, 7, 2);                                     EHX_SB();                                     \
+    EHX_MFZ(BC, 7, 3);                                     EHX_SB();                                     \
+    fa[7] = EHX_FR(smem + (AN) + 7168);                    EHX_SB();                                     \
+  } while (0)
+#define EHX_STAGE16_FUSED_CT(S, BC, BN)                                                                  \
+  do {                                                                                                   \
+    constexpr uint32_t sn = (uint32_t)(((S) + 1) & 3) * kStageI8;                                        \
+    constexpr int sd = ((S) + 3) & 3;                                                                    \
+    EHX_STAGE16_FUSED(BC, BN, a_off + sn, b_off + sn, EHX_SDMA_X0(sd), EHX_SDMA_Q0(sd), EHX_SDMA_X1(sd), \
+                      EHX_SDMA_Q1(sd));                                                                  \
+  } while (0)
+  constexpr bool kFused = FUSE && !DUMP;
+
   // Two loops over the same stage body.  REV (a tile is a whole number of ring revolutions, ld % 256 == 0: d = 768, 1536,
   // 1024, 512, 256 ...): the ring slot of every stage is a compile-time constant.  Otherwise (d = 128, 384, 640 ...):
   // one loop over single stages whose slot is a scalar.
@@ -608,7 +786,8 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       ++q;
     };
     for (uint32_t t = 0; t < my_tiles; ++t) {
-      EHX_STAGE16_CT(0, EHX_MFZ, fb0, fb1);
+      if constexpr (kFused) EHX_STAGE16_FUSED_CT(0, fb0, fb1);
+      else EHX_STAGE16_CT(0, EHX_MFZ, fb0, fb1);
       EHX_STAGE16_CT(1, EHX_MF, fb1, fb0);
       EHX_STAGE16_CT(2, EHX_MF, fb0, fb1);
       EHX_STAGE16_CT(3, EHX_MF, fb1, fb0);
@@ -620,9 +799,13 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
         EHX_STAGE16_CT(3, EHX_MF, fb1, fb0);
         after_revolution();
       }
+      if constexpr (kFused) {
+        epi_levels(t);  // (the accumulators are judged inside the next tile's first stage, or after the loop)
+      } else {
 #if !(EHX_I8_ABL & 1)
-      epilogue(t);
+        epilogue(t);
 #endif
+      }
       // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
       // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
       qsrc = qbase + 3 * kStageI8;
@@ -637,6 +820,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
         EHX_DMA(rd, 0, voff, rsrc);
       }
     }
+    if constexpr (kFused) epi_all_rows();  // the chunk's last tile
   } else {
     // One flat loop over the stages of the chunk; a tile is `ktiles` of them (ld / 64: any number).  The tile boundary
     // work hangs off a counter and may fall anywhere in a revolution: nothing in the ring depends on where a tile starts
@@ -648,72 +832,104 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     rsrc += kTileRows16 * 16;
     if (w < 4) EHX_DMA(rdst, 4096, voff, rsrc);
     uint32_t ks = 0, t = 0, slot = 0;
-#pragma unroll 1
-    for (uint32_t st = 0; st < total_stages; ++st) {
-      {
-        const uint32_t sn = ((slot + 1u) & 3u) << 14, sd = ((slot + 3u) & 3u) << 14;
-        const uint32_t dx0 = xdst + sd, dq0 = qdst + sd;
-        const uint32_t an_ = a_off + sn, bn_ = b_off + sn;
+    // (FUSE needs tiles of two stages or more — the launcher sees to it: the row parameters of the tile after next are
+    // copied over the previous tile's at the end of a tile, and only a later stage barrier of the same tile guarantees
+    // that every wave has finished judging the previous one)
+    constexpr bool fuse = kFused;
+    // one stage whose ring slot is a run-time value: STAGE is the stage body to use (first stage of a tile or not)
 #define EHX_RT_DX0 EHX_SDMA(dx0, voff, xsrc)
 #define EHX_RT_DQ0 EHX_SDMA(dq0, voff, qsrc)
 #define EHX_RT_DX1 EHX_SDMA(dx0 + 8192u, voff8, xsrc)
 #define EHX_RT_DQ1 EHX_SDMA(dq0 + 8192u, voff8, qsrc)
-        if (ks == 0u) EHX_STAGE16_BODY(EHX_MFZ, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1);
-        else EHX_STAGE16_BODY(EHX_MF, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1);
+#define EHX_RT_STAGE(STAGE)                                                                  \
+  do {                                                                                       \
+    const uint32_t sn = ((slot + 1u) & 3u) << 14, sd = ((slot + 3u) & 3u) << 14;             \
+    const uint32_t dx0 = xdst + sd, dq0 = qdst + sd;                                         \
+    const uint32_t an_ = a_off + sn, bn_ = b_off + sn;                                       \
+    STAGE;                                                                                   \
+    xsrc += kStageI8;                                                                        \
+    qsrc += kStageI8;                                                                        \
+    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) fb0[cb] = fb1[cb];                      \
+    slot = (slot + 1u) & 3u;                                                                 \
+    if (sync_on && w == 0 && slot == 0u) after_revolution_rt(st >> 2);                       \
+    ++st;                                                                                    \
+  } while (0)
+    auto after_revolution_rt = [&](const uint32_t q) {
+      // revolution q is done.  The snapshot taken after revolution q-1 (landed long ago: four stage waits have
+      // passed) must show every sibling through revolution q-2; then announce q and take the next snapshot.
+      const uint32_t seen = __builtin_amdgcn_readfirstlane(sync_lds[0]);
+      const uint32_t need = q >= 2 ? a.q_tiles * (q - 1) : 0u;
+      if (seen < need) {
+        uint32_t spins = 0;
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <
+               need) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > 4000u) {  // a sibling is not resident (or died): never hang, just stop synchronising
+            sync_on = false;
+            break;
+          }
+        }
+      }
+      if (lane == 0) __hip_atomic_fetch_add(sync_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1"
+                   :
+                   : "s"(sync_m0), "v"(sync_voff), "s"(sync_ctr)
+                   : "memory");
+    };
+    auto tile_done = [&]() {  // t: the tile that has just been completed
+      if constexpr (fuse) {
+        epi_levels(t);
+      } else {
+#if !(EHX_I8_ABL & 1)
+        epilogue(t);
+#endif
+      }
+      ++t;
+      // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
+      // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
+      qsrc = qbase + 3 * kStageI8;
+      rsrc += kTileRows16 * 16;
+      tp_cur = ldc(tilep_c, t);  // (past the last tile: the array's padding entries)
+      tg_cur = ldc(tgp, (size_t)t * 4);
+      // tile t+1 (counting the new t) goes to the slot tile t-2 used: every wave left that epilogue long ago
+      const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 1) % 3 == (t - 2) % 3
+      rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
+      if (w < 4) {
+        const uint32_t rd = rdst + rp_next * 4096u;
+        EHX_DMA(rd, 0, voff, rsrc);
+      }
+    };
+    uint32_t st = 0;
+    if constexpr (fuse) {
+      // tile by tile: the first stage (with the previous tile's epilogue inside) and the others are separate code — one
+      // loop over both forms behind a branch cost the accumulators their fixed registers (copies and scratch)
+#pragma unroll 1
+      for (uint32_t tt = 0; tt < my_tiles; ++tt) {
+        EHX_RT_STAGE(EHX_STAGE16_FUSED(fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
+#pragma unroll 1
+        for (ks = 1; ks < ktiles; ++ks)
+          EHX_RT_STAGE(EHX_STAGE16_BODY(EHX_MF, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
+        tile_done();
+      }
+    } else {
+#pragma unroll 1
+      while (st < total_stages) {
+        if (ks == 0u)
+          EHX_RT_STAGE(EHX_STAGE16_BODY(EHX_MFZ, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
+        else
+          EHX_RT_STAGE(EHX_STAGE16_BODY(EHX_MF, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
+        if (++ks == ktiles) {
+          ks = 0;
+          tile_done();
+        }
+      }
+    }
+#undef EHX_RT_STAGE
 #undef EHX_RT_DX0
 #undef EHX_RT_DQ0
 #undef EHX_RT_DX1
 #undef EHX_RT_DQ1
-        xsrc += kStageI8;
-        qsrc += kStageI8;
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) fb0[cb] = fb1[cb];
-      }
-      slot = (slot + 1u) & 3u;
-      if (sync_on && w == 0 && slot == 0u) {
-        // revolution q is done.  The snapshot taken after revolution q-1 (landed long ago: four stage waits have
-        // passed) must show every sibling through revolution q-2; then announce q and take the next snapshot.
-        const uint32_t q = st >> 2;
-        const uint32_t seen = __builtin_amdgcn_readfirstlane(sync_lds[0]);
-        const uint32_t need = q >= 2 ? a.q_tiles * (q - 1) : 0u;
-        if (seen < need) {
-          uint32_t spins = 0;
-          while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <
-                 need) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > 4000u) {  // a sibling is not resident (or died): never hang, just stop synchronising
-              sync_on = false;
-              break;
-            }
-          }
-        }
-        if (lane == 0) __hip_atomic_fetch_add(sync_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1"
-                     :
-                     : "s"(sync_m0), "v"(sync_voff), "s"(sync_ctr)
-                     : "memory");
-      }
-      if (++ks == ktiles) {
-        ks = 0;
-#if !(EHX_I8_ABL & 1)
-        epilogue(t);
-#endif
-        ++t;
-        // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
-        // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
-        qsrc = qbase + 3 * kStageI8;
-        rsrc += kTileRows16 * 16;
-        tp_cur = ldc(tilep_c, t);  // (past the last tile: the array's padding entries)
-        tg_cur = ldc(tgp, (size_t)t * 4);
-        // tile t+1 (counting the new t) goes to the slot tile t-2 used: every wave left that epilogue long ago
-        const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 1) % 3 == (t - 2) % 3
-        rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
-        if (w < 4) {
-          const uint32_t rd = rdst + rp_next * 4096u;
-          EHX_DMA(rd, 0, voff, rsrc);
-        }
-      }
-    }
+    if constexpr (fuse) epi_all_rows();  // the chunk's last tile
   }
   }  // my_tiles > 0
 #undef EHX_MF
@@ -727,6 +943,10 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 #undef EHX_SDMA_Q1
 #undef EHX_STAGE16_CT
 #undef EHX_STAGE16_BODY
+#undef EHX_STAGE16_FUSED_CT
+#undef EHX_STAGE16_FUSED
+#undef EHX_E1
+#undef EHX_EGO
 #undef EHX_STAGE_BARRIER
 #undef EHX_MFZ
 #undef EHX_DMA_X0
@@ -745,19 +965,38 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
 
 hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st) {
   static DynLdsAttr attr;
-  const void* fns[4] = {(const void*)flat_scan_i8_kernel<false, true>, (const void*)flat_scan_i8_kernel<true, true>,
-                        (const void*)flat_scan_i8_kernel<false, false>, (const void*)flat_scan_i8_kernel<true, false>};
-  if (hipError_t e = attr.ensure(fns, 4, kLdsBytesI8); e != hipSuccess) return e;
+  const void* fns[] = {(const void*)flat_scan_i8_kernel<false, true, false>, (const void*)flat_scan_i8_kernel<false, false, false>,
+                       (const void*)flat_scan_i8_kernel<true, true, false>, (const void*)flat_scan_i8_kernel<true, false, false>,
+#if EHX_I8_FUSED
+                       (const void*)flat_scan_i8_kernel<false, true, true>, (const void*)flat_scan_i8_kernel<false, false, true>,
+#endif
+  };
+  if (hipError_t e = attr.ensure(fns, (int)(sizeof(fns) / sizeof(fns[0])), kLdsBytesI8); e != hipSuccess) return e;
   if (a.ld == 0 || a.ld % kRowBI8) return hipErrorInvalidValue;
   const uint32_t grid = a.q_tiles * a.n_chunks;
   const bool rev = a.ld % (4 * kRowBI8) == 0;  // whole ring revolutions per tile: the compile-time-slot loop
-  if (a.dump) {
-    if (rev) hipLaunchKernelGGL((flat_scan_i8_kernel<true, true>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
-    else hipLaunchKernelGGL((flat_scan_i8_kernel<true, false>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
-  } else {
-    if (rev) hipLaunchKernelGGL((flat_scan_i8_kernel<false, true>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
-    else hipLaunchKernelGGL((flat_scan_i8_kernel<false, false>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
+#define EHX_LAUNCH_I8(D, R, F) \
+  hipLaunchKernelGGL((flat_scan_i8_kernel<D, R, F>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a)
+#if EHX_I8_FUSED
+  // the epilogue inside the next tile's first stage: tiles of at least two stages (see the kernel), never the sample pass
+  static const bool fused_on = [] {
+    const char* e = getenv("EHX_I8_FUSED");
+    return !(e && atoi(e) == 0);
+  }();
+  if (fused_on && !a.dump && a.ld >= 2 * kRowBI8) {
+    if (rev) EHX_LAUNCH_I8(false, true, true);
+    else EHX_LAUNCH_I8(false, false, true);
+    return hipGetLastError();
   }
+#endif
+  if (a.dump) {
+    if (rev) EHX_LAUNCH_I8(true, true, false);
+    else EHX_LAUNCH_I8(true, false, false);
+  } else {
+    if (rev) EHX_LAUNCH_I8(false, true, false);
+    else EHX_LAUNCH_I8(false, false, false);
+  }
+#undef EHX_LAUNCH_I8
   return hipGetLastError();
 }
 
