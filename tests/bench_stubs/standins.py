@@ -200,6 +200,7 @@ def install(mp=None, real_sharded=False):
     mp.setattr(torch.cuda, "is_available", lambda: True)
     mp.setattr(torch.cuda, "set_device", lambda d: None)
     mp.setattr(torch.cuda, "synchronize", lambda *a: None)
+    mp.setattr(torch.cuda, "mem_get_info", lambda *a: (200 << 30, 288 << 30))
     mp.setattr(torch.cuda, "device_count", lambda: n_dev)
     mp.setattr(torch.cuda, "current_stream",
                lambda *a: types.SimpleNamespace(cuda_stream=0, synchronize=lambda: None, wait_event=lambda e: None))
