@@ -907,6 +907,16 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
     }
   }
   HIP_TRY(hipStreamSynchronize(st));
+  // A bulk build gives its scratch back: one visited bitmap per insertion in flight is cap / 8 bytes each — 5.1 GB for
+  // rounds of 4096 rows on a 10 M-row index, four times what a 1024-query search batch needs (it re-allocates its own,
+  // zeroed, at its first call: ~1 ms).  Streamed Sets (small calls) keep theirs.
+  if (end - id0 >= 65536 && s->dVisited.n * sizeof(uint32_t) > (1ull << 30)) {
+    s->dVisited.release();
+    s->dInsVislog.release();
+    s->dLinkNext.release();
+    s->dLinkTouched.release();
+    s->vis_dirty = false;
+  }
   return EHX_OK;
 }
 
