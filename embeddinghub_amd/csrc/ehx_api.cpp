@@ -910,7 +910,14 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
   // A bulk build gives its scratch back: one visited bitmap per insertion in flight is cap / 8 bytes each — 5.1 GB for
   // rounds of 4096 rows on a 10 M-row index, four times what a 1024-query search batch needs (it re-allocates its own,
   // zeroed, at its first call: ~1 ms).  Streamed Sets (small calls) keep theirs.
-  if (end - id0 >= 65536 && s->dVisited.n * sizeof(uint32_t) > (1ull << 30)) {
+  // (EHX_BUILD_SCRATCH_KEEP=<bytes>: what a build may keep, whatever its size — tests release at small sizes with 0)
+  static const long long keep_env = [] {
+    const char* e = getenv("EHX_BUILD_SCRATCH_KEEP");
+    return e ? atoll(e) : -1ll;
+  }();
+  const bool give_back = keep_env >= 0 ? s->dVisited.n * sizeof(uint32_t) > (unsigned long long)keep_env
+                                       : (end - id0 >= 65536 && s->dVisited.n * sizeof(uint32_t) > (1ull << 30));
+  if (give_back) {
     s->dVisited.release();
     s->dInsVislog.release();
     s->dLinkNext.release();

@@ -155,6 +155,56 @@ def test_batched_gpu_build_recall_parity_with_oracle():
     s.drop()
 
 
+def test_bulk_build_gives_its_scratch_back_and_the_space_keeps_working():
+    """A bulk build releases its per-insertion visited bitmaps and link scratch when it returns (ehx_api.cpp
+    graph_insert: from 1 GiB on by default — 5 GB at 10 M rows; EHX_BUILD_SCRATCH_KEEP=0 forces it here).  Afterwards:
+    searches allocate their own bitmaps, a second bulk Set allocates fresh scratch, sequential Sets and updates work —
+    and every answer equals that of a space that kept its scratch (the library reads the variable once per process, so
+    the comparison is against the CPU oracle's recall on the same rows and against the exact scan)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np
+import embeddinghub_amd as ehx
+from oracle import pyoracle
+n, d, nq, k = 20000, 64, 128, 10
+X = pyoracle.gen_rows(ehx.SEED_CORPUS, 0, n, d)
+Q = pyoracle.gen_rows(ehx.SEED_QUERY, 0, nq, d)
+s = ehx.Space.unique("gscratch", d, metric=ehx.METRIC_L2SQ, mode=ehx.MODE_GRAPH, initial_capacity=n + 4096, build_batch=1024)
+keys = ["r%d" % i for i in range(n)]
+s.set_batch(keys[:12000], X[:12000])       # bulk rounds, scratch released at the end
+s.set_ef(200)
+ids, dist, cnt = s.knn(Q, k)               # the search allocates its own bitmaps
+assert (cnt == k).all()
+s.set_batch(keys[12000:], X[12000:])       # second bulk Set: fresh scratch, released again
+s.set("extra", X[5] * np.float32(0.5))     # sequential insert
+s.set("r7", X[8])                          # update in place
+assert np.array_equal(s.get("r7"), X[8]) and len(s) == n + 1
+X2 = X.copy(); X2[7] = X[8]
+X2 = np.concatenate([X2, (X[5] * np.float32(0.5))[None]])
+truth, _, _ = pyoracle.exhaustive(X2, Q, k, pyoracle.METRIC_L2)
+ids, dist, cnt = s.knn(Q, k)
+r = np.mean([len(set(ids[i]) & set(truth[i])) / k for i in range(nq)])
+l0, lv, upper, ep, ml = s.graph_export()
+assert (l0[:n, 0] >= 1).all() and (l0[:, 0] <= 32).all()
+print("RECALL %.4f" % r)
+s.drop()
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    recalls = []
+    for keep in ("0", None):
+        env = dict(os.environ, PYTHONPATH=root)
+        if keep is None:
+            env.pop("EHX_BUILD_SCRATCH_KEEP", None)
+        else:
+            env["EHX_BUILD_SCRATCH_KEEP"] = keep
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        recalls.append(float([l for l in out.stdout.splitlines() if l.startswith("RECALL")][0].split()[1]))
+    assert recalls[0] >= 0.5 and abs(recalls[0] - recalls[1]) <= 0.02, recalls
+
+
 @pytest.mark.parametrize("M", [8, 32])
 @pytest.mark.parametrize("em,om", [(ehx.METRIC_L2SQ, pyoracle.METRIC_L2), (ehx.METRIC_COSINE, pyoracle.METRIC_COSINE)])
 def test_other_degrees_M8_and_M32(M, em, om):
