@@ -18,6 +18,11 @@
 // three stages ahead by global->LDS DMA from the stage-blocked scan copy; one counted s_waitcnt + one raw s_barrier per
 // stage (details at the kernel).
 //
+// Short rows (round 4; a tile of at most four stages: ld <= 192 in the run-time-slot loop): the query tile's stage
+// blocks are the same for every row tile, so they are copied into the Q ring's four slots ONCE and stay there (QRES);
+// a stage then copies its two X pieces per wave only — half the DMA instructions (each costs 60-180 cycles of issue
+// time among MFMAs) and half the L2 -> LDS bytes.  EHX_I8_QRES=0 in the environment: the ring for both, as before.
+//
 // Epilogue.  The threshold of a (query, pass) is FIXED — the k'-th best lower bound of the rows scanned by the earlier
 // passes (select256_kernel) — and a pass collects every (row, query) whose lower bound is not above it:
 //   phase 1  per query of the lane (four per lane), ONE integer maximum over the lane's 32 accumulators against ONE
@@ -221,8 +226,9 @@ size_t scan_i8_lds_bytes() { return kLdsBytesI8; }
 // registers each; a stage row's 64 bytes are ONE k-step: lane l holds bytes [16 (l >> 4), +16) of row / query l & 15 of
 // its block — one ds_read_b128 per block and stage, twelve per stage as before.  Every block gets exactly one MFMA
 // per stage.  An accumulator block holds, per lane, rows 4 (l >> 4) + 0..3 of its 16 rows for query l & 15.
-template <bool DUMP, bool REV, bool FUSE>
+template <bool DUMP, bool REV, bool FUSE, bool QRES = false>
 __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanArgsI8 a) {
+  static_assert(!QRES || (!REV && !FUSE && !DUMP), "QRES: the run-time-slot loop of the plain scan only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -587,10 +593,30 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   if (my_tiles > 0) {  // (a chunk past the end of the pass has nothing to scan and must not touch memory)
   // ---- prologue: row parameters of tile 0, stages 0..2 into ring slots 0..2 ----
   if (w < 4) EHX_DMA(rdst, 0, voff, rsrc);
-  EHX_DMA_X0(0); EHX_DMA_Q0(0); EHX_DMA_X1(0); EHX_DMA_Q1(0);
-  EHX_DMA_X0(1); EHX_DMA_Q0(1); EHX_DMA_X1(1); EHX_DMA_Q1(1);
-  EHX_DMA_X0(2); EHX_DMA_Q0(2); EHX_DMA_X1(2); EHX_DMA_Q1(2);
-  wait_vmcnt<8>();  // stage 0 (and the row parameters, older) landed <=> at most stages 1, 2 in flight
+  // QRES (short rows: a tile is at most four stages, ld <= 256): the query tile's stage blocks — the same for every
+  // row tile — are copied ONCE into the four slots of the Q ring and stay there; a stage then copies its two X pieces
+  // per wave only (half the DMA instructions, half the L2 -> LDS bytes), and the query fragments of stage ks of a
+  // tile are read from slot ks.  The counted wait of a stage is 4 instead of 8 (two pieces per stage and wave).
+  constexpr int kStageWait = QRES ? 4 : 8;
+  if constexpr (QRES) {
+    for (uint32_t ks = 0; ks < ktiles; ++ks) {
+      const uint32_t qd0 = qdst + (ks << 14);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(qd0), "v"(voff), "s"(qsrc) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   :
+                   : "s"(qd0 + 8192u), "v"(voff8), "s"(qsrc)
+                   : "memory");
+      qsrc += kStageI8;
+    }
+    EHX_DMA_X0(0); EHX_DMA_X1(0); xsrc += kStageI8;
+    EHX_DMA_X0(1); EHX_DMA_X1(1); xsrc += kStageI8;
+    EHX_DMA_X0(2); EHX_DMA_X1(2); xsrc += kStageI8;
+  } else {
+    EHX_DMA_X0(0); EHX_DMA_Q0(0); EHX_DMA_X1(0); EHX_DMA_Q1(0);
+    EHX_DMA_X0(1); EHX_DMA_Q0(1); EHX_DMA_X1(1); EHX_DMA_Q1(1);
+    EHX_DMA_X0(2); EHX_DMA_Q0(2); EHX_DMA_X1(2); EHX_DMA_Q1(2);
+  }
+  wait_vmcnt<kStageWait>();  // stage 0 (and what is older: row parameters, the resident query tile) landed
   lds_barrier_i8();  // B_0
 #if EHX_I8_ABL & 4
   wait_vmcnt<0>();
@@ -660,7 +686,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     M0(BC, 3, 3);                                          EHX_SB();                                     \
     /* stage barrier: the next stage landed and is visible; nobody reads the slot the stage after the    \
        next two will be copied into */                                                                   \
-    wait_vmcnt<8>();                                                                                     \
+    wait_vmcnt<kStageWait>();                                                                            \
     EHX_STAGE_BARRIER();                                                                                 \
     EHX_SB();                                                                                            \
     M0(BC, 4, 0); BN[0] = EHX_FR(smem + (BNX));           EHX_SB();                                     \
@@ -716,7 +742,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     EHX_MFZ(BC, 3, 2);      EHX_E1(4, 2);                  EHX_SB();                                     \
     EHX_MFZ(BC, 3, 3);      EHX_E1(4, 3);                  EHX_SB();                                     \
     EHX_EGO(4);                                            EHX_SB();                                     \
-    wait_vmcnt<8>();                                                                                     \
+    wait_vmcnt<kStageWait>();                                                                            \
     EHX_STAGE_BARRIER();                                                                                 \
     EHX_SB();                                                                                            \
     EHX_MFZ(BC, 4, 0); BN[0] = EHX_FR(smem + (BNX));        EHX_E1(5, 0); EHX_SB();                      \
@@ -838,17 +864,20 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     constexpr bool fuse = kFused;
     // one stage whose ring slot is a run-time value: STAGE is the stage body to use (first stage of a tile or not)
 #define EHX_RT_DX0 EHX_SDMA(dx0, voff, xsrc)
-#define EHX_RT_DQ0 EHX_SDMA(dq0, voff, qsrc)
+#define EHX_RT_DQ0 do { if constexpr (!QRES) EHX_SDMA(dq0, voff, qsrc); } while (0)
 #define EHX_RT_DX1 EHX_SDMA(dx0 + 8192u, voff8, xsrc)
-#define EHX_RT_DQ1 EHX_SDMA(dq0 + 8192u, voff8, qsrc)
+#define EHX_RT_DQ1 do { if constexpr (!QRES) EHX_SDMA(dq0 + 8192u, voff8, qsrc); } while (0)
+  // (QRES: the next stage's query fragments come from the resident slot of ITS index inside its tile)
 #define EHX_RT_STAGE(STAGE)                                                                  \
   do {                                                                                       \
     const uint32_t sn = ((slot + 1u) & 3u) << 14, sd = ((slot + 3u) & 3u) << 14;             \
     const uint32_t dx0 = xdst + sd, dq0 = qdst + sd;                                         \
-    const uint32_t an_ = a_off + sn, bn_ = b_off + sn;                                       \
+    const uint32_t ksn_ = ks + 1u == ktiles ? 0u : ks + 1u;                                  \
+    const uint32_t an_ = a_off + sn, bn_ = b_off + (QRES ? (ksn_ << 14) : sn);               \
+    (void)dq0;                                                                               \
     STAGE;                                                                                   \
     xsrc += kStageI8;                                                                        \
-    qsrc += kStageI8;                                                                        \
+    if constexpr (!QRES) qsrc += kStageI8;                                                   \
     _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) fb0[cb] = fb1[cb];                      \
     slot = (slot + 1u) & 3u;                                                                 \
     if (sync_on && w == 0 && slot == 0u) after_revolution_rt(st >> 2);                       \
@@ -905,6 +934,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       // loop over both forms behind a branch cost the accumulators their fixed registers (copies and scratch)
 #pragma unroll 1
       for (uint32_t tt = 0; tt < my_tiles; ++tt) {
+        ks = 0;
         EHX_RT_STAGE(EHX_STAGE16_FUSED(fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
 #pragma unroll 1
         for (ks = 1; ks < ktiles; ++ks)
@@ -967,6 +997,7 @@ hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st) {
   static DynLdsAttr attr;
   const void* fns[] = {(const void*)flat_scan_i8_kernel<false, true, false>, (const void*)flat_scan_i8_kernel<false, false, false>,
                        (const void*)flat_scan_i8_kernel<true, true, false>, (const void*)flat_scan_i8_kernel<true, false, false>,
+                       (const void*)flat_scan_i8_kernel<false, false, false, true>,
 #if EHX_I8_FUSED
                        (const void*)flat_scan_i8_kernel<false, true, true>, (const void*)flat_scan_i8_kernel<false, false, true>,
 #endif
@@ -989,11 +1020,18 @@ hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st) {
     return hipGetLastError();
   }
 #endif
+  // short rows (a tile of at most four stages): the query tile resident in LDS (QRES in the kernel); EHX_I8_QRES=0: off
+  static const bool qres_on = [] {
+    const char* e = getenv("EHX_I8_QRES");
+    return !(e && atoi(e) == 0);
+  }();
   if (a.dump) {
     if (rev) EHX_LAUNCH_I8(true, true, false);
     else EHX_LAUNCH_I8(true, false, false);
   } else {
     if (rev) EHX_LAUNCH_I8(false, true, false);
+    else if (qres_on && a.ld <= 4 * kRowBI8)
+      hipLaunchKernelGGL((flat_scan_i8_kernel<false, false, false, true>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
     else EHX_LAUNCH_I8(false, false, false);
   }
 #undef EHX_LAUNCH_I8
