@@ -332,11 +332,13 @@ struct ehx_space {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start | scan start | scan end | all enqueued work done
     hipEvent_t verdict = nullptr;                            // blocking-sync: the verdict has landed in hUncertPin
     bool ev_valid = false;
+    uint64_t ev_seq = 0;     // value of ehx_space::ev_counter when ev[] was last recorded (ehx_stats: which set is newest)
     hipEvent_t ring[64][2] = {};
     uint64_t ring_count = 0;
     std::mutex mu;
   };
   I8Set i8set[2];
+  std::atomic<uint64_t> ev_counter{0};
   std::atomic<uint32_t> i8_next_set{0};
   std::atomic<uint64_t> n_filter_queries{0}, n_filter_fallback{0}, n_exhaustive{0}, n_uncertified_final{0};
   std::atomic<uint64_t> n_i8_queries{0}, n_i8_fallback{0};
@@ -344,6 +346,7 @@ struct ehx_space {
   size_t hStageBytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool ev_valid = false;
+  uint64_t ev_seq = 0;
   // ring of (start, stop) event pairs around the scan kernel: per-launch durations for the roofline
   static constexpr int kRing = 64;
   hipEvent_t ring[kRing][2] = {};
@@ -1176,6 +1179,7 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   s->ring_count++;
   HIP_TRY(hipEventRecord(s->ev[3], st));
   s->ev_valid = true;
+  s->ev_seq = ++s->ev_counter;
   s->n_queries += nq;
   return EHX_OK;
 }
@@ -1384,6 +1388,7 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
   HIP_TRY(launch_rerank(r, st));
   HIP_TRY(hipEventRecord(s->ev[3], st));
   s->ev_valid = true;
+  s->ev_seq = ++s->ev_counter;
   if (count_stats) {
     s->n_queries += nq;
     s->n_dist += (uint64_t)nq * s->n;
@@ -1648,6 +1653,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   }
   HIP_TRY(hipEventRecord(sc.ev[3], st));
   sc.ev_valid = true;
+  sc.ev_seq = ++s->ev_counter;
   if (count_stats) {
     s->n_queries += nq;
     s->n_dist += (uint64_t)nq * s->n;
@@ -1719,6 +1725,7 @@ int exhaustive_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_quer
   }
   HIP_TRY(hipEventRecord(s->ev[3], st));
   s->ev_valid = true;
+  s->ev_seq = ++s->ev_counter;
   s->n_dist += (uint64_t)nq * s->n * pages;
   return EHX_OK;
 }
@@ -3586,8 +3593,10 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
     double sum = 0;
     uint64_t got = 0;
     float ms = 0;
+    uint64_t newest = 0;  // last_scan_ms / last_total_ms: of the event set that was recorded LAST
     if (s->ev_valid) {
       HIP_TRY(hipEventSynchronize(s->ev[3]));
+      newest = s->ev_seq;
       if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) out->last_scan_ms = ms;
       if (hipEventElapsedTime(&ms, s->ev[0], s->ev[3]) == hipSuccess) out->last_total_ms = ms;
       const uint64_t m = s->ring_count < (uint64_t)ehx_space::kRing ? s->ring_count : (uint64_t)ehx_space::kRing;
@@ -3601,8 +3610,11 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
       std::lock_guard<std::mutex> cl(c.mu);
       if (!c.ev_valid) continue;
       HIP_TRY(hipEventSynchronize(c.ev[3]));
-      if (hipEventElapsedTime(&ms, c.ev[1], c.ev[2]) == hipSuccess) out->last_scan_ms = ms;
-      if (hipEventElapsedTime(&ms, c.ev[0], c.ev[3]) == hipSuccess) out->last_total_ms = ms;
+      if (c.ev_seq > newest) {
+        newest = c.ev_seq;
+        if (hipEventElapsedTime(&ms, c.ev[1], c.ev[2]) == hipSuccess) out->last_scan_ms = ms;
+        if (hipEventElapsedTime(&ms, c.ev[0], c.ev[3]) == hipSuccess) out->last_total_ms = ms;
+      }
       const uint64_t m = c.ring_count < 64 ? c.ring_count : 64;
       for (uint64_t i = 0; i < m; ++i)
         if (hipEventElapsedTime(&ms, c.ring[i][0], c.ring[i][1]) == hipSuccess) {
