@@ -126,3 +126,61 @@ def test_engine_agreement_helpers_over_ten_batches():
     dst2[3, 4] = torch.nextafter(dst2[3, 4], torch.tensor(2.0))       # one distance off by one ulp
     data[7] = (ids, dst2, cnt)
     assert bench.first_disagreement(step, kept, torch, lambda: None) == 7
+
+
+def test_host_callers_are_long_lived_threads_that_split_the_batches_and_report_every_call():
+    """bench.HostCallers: `callers` threads started once, thread t serves batches t, t + callers, ... of every run() in
+    order; call_ms / call_summary describe the LAST run; an exception in a caller thread is re-raised by run(); close()
+    ends the threads."""
+    import threading
+
+    class Space:
+        def __init__(self):
+            self.calls = []          # (thread name, batch marker)
+            self.fail_on = None
+            self.lock = threading.Lock()
+
+        def knn_into(self, Q, k, ids, dist, cnt):
+            b = int(Q[0, 0])
+            if self.fail_on == b:
+                raise RuntimeError("boom %d" % b)
+            with self.lock:
+                self.calls.append((threading.current_thread().name, b))
+            ids[:] = b
+
+    hq = [np.full((4, 8), b, np.float32) for b in range(6)]
+    sp = Space()
+    hc = bench.HostCallers(sp, hq, 3, 2)
+    try:
+        names0 = {t.name for t in hc._threads}
+        assert len(names0) == 2
+        el = hc.run([0, 1, 2, 3, 4])
+        assert el > 0
+        by_thread = {}
+        for name, b in sp.calls:
+            by_thread.setdefault(name, []).append(b)
+        assert sorted(by_thread.values()) == [[0, 2, 4], [1, 3]]          # t, t + 2, ... in order, one thread each
+        assert set(by_thread) == names0                                   # ... the threads that were started once
+        assert [s_["calls"] for s_ in hc.call_summary()] == [3, 2]
+        assert int(hc.out[0][0][0, 0]) == 4 and int(hc.out[1][0][0, 0]) == 3   # every thread's own output arrays
+        sp.calls.clear()
+        hc.run([5])                                                       # fewer batches than threads: one sits out
+        assert [b for _, b in sp.calls] == [5] and {n for n, _ in sp.calls} <= names0
+        assert [s_["calls"] for s_ in hc.call_summary()] == [1]           # (of the last run only)
+        sp.fail_on = 1
+        try:
+            hc.run([0, 1, 2])
+        except RuntimeError as e:
+            assert "boom 1" in str(e)
+        else:
+            raise AssertionError("the caller thread's exception was swallowed")
+        sp.fail_on = None
+        hc.run([2, 3])                                                    # still usable afterwards
+    finally:
+        started = list(hc._threads)
+        hc.close()
+    assert len(started) == 2 and not any(t.is_alive() for t in started) and hc._threads == []
+    one = bench.HostCallers(sp, hq, 3, 1)                                 # one caller: the calling thread itself
+    sp.calls.clear()
+    one.run([0, 1])
+    assert {n for n, _ in sp.calls} == {threading.current_thread().name} and one._threads == []
