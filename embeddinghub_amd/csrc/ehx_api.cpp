@@ -1477,7 +1477,11 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   // First pass: up to 512 tiles (131 072 rows) under a threshold taken from the sample at a LOW rank, chosen so that
   // the pass collects ~1000 keys per query (any threshold is sound, see sample_select256_kernel); then x4 in rows per
   // pass under the 256th best so far.
-  constexpr uint32_t kFirstTiles = 512;
+  static const uint32_t kFirstTiles = [] {  // (EHX_I8_FIRST_TILES: sweeps of the cascade's shape on small shards)
+    const char* g = getenv("EHX_I8_FIRST_TILES");
+    const long v = g ? atol(g) : 512;
+    return (uint32_t)(v < 64 ? 64 : (v > 65536 ? 65536 : v));
+  }();
   std::vector<Pass> passes;
   {
     uint32_t done = 0, cum = kFirstTiles;
