@@ -25,7 +25,7 @@ from standins import FakeSpace  # noqa: E402
 
 
 @pytest.fixture
-def bench_on_stand_ins(monkeypatch):
+def bench_on_stand_ins(monkeypatch, tmp_path):
     standins.install(monkeypatch)
     spec = importlib.util.spec_from_file_location("bench_flow_module", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
@@ -34,14 +34,22 @@ def bench_on_stand_ins(monkeypatch):
         monkeypatch.delenv(var, raising=False)
 
     def run(argv):
-        monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+        """runs main(); returns the FULL record (the detail file).  The one stdout line — the compact record the driver
+        parses — is checked here for every run (size bound, contract fields) and kept as run.line"""
+        detail = str(tmp_path / "bench_detail.json")
+        monkeypatch.setattr(sys, "argv", ["bench.py"] + argv + ["--detail-file", detail])
         buf = io.StringIO()
         with redirect_stdout(buf):
             bench.main()
         lines = [l for l in buf.getvalue().splitlines() if l.strip()]
         assert len(lines) == 1, "bench.py must print exactly ONE line on stdout: %r" % lines
-        return json.loads(lines[0])
+        assert len(lines[0].encode()) <= 4096, "the stdout line is bounded (VERDICT r04 #1): %d bytes" % len(lines[0])
+        run.line = json.loads(lines[0])
+        assert run.line["detail"] == detail
+        with open(detail) as f:
+            return json.load(f)
     run.module = bench
+    run.line = None
     return run
 
 
@@ -72,6 +80,50 @@ def test_default_flow_prints_one_json_line_with_the_contract_fields(bench_on_sta
     assert "host pointers" in r["config"]["timed_from"] and r["exactness"]["host_pointer_path_identical"] is True
     keys = list(r)                       # quoted tables last, the measured legs before them
     assert keys[-1] == "cpu_hnsw_offline" and keys.index("roofline") < keys.index("cpu_baseline")
+    # ---- the compact stdout line: the contract + one number set per leg, nothing else ----
+    c = bench_on_stand_ins.line
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "exactness"):
+        assert key in c, key
+        if key not in ("config", "roofline", "cpu_baseline", "exactness"):
+            assert c[key] == r[key], key
+    assert set(("workload", "timed_from", "rows", "dims", "batch", "k", "world_size")) <= set(c["config"])
+    assert set(("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_session", "kernel_ms")) <= set(c["roofline"])
+    assert c["roofline"]["frac"] == r["roofline"]["frac"] and c["roofline"]["kernel"] == "flat_scan_i8_kernel"
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c["cpu_baseline"]) and c["cpu_baseline"]["kind"] == "port"
+    assert len(c["cpu_baseline"]["sample"]) < 160 and c["cpu_baseline"]["value"] == r["cpu_baseline"]["value"]
+    assert c["exactness"]["ids_identical_to_oracle"] and c["exactness"]["dist_bytes_identical_to_oracle"]
+    assert c["exactness"]["recall_at_10"] == 1.0 and c["recall_at_10"] == 1.0
+    for leg in ("graph_path", "graph_path_structured"):
+        assert set(("ef", "recall_at_10", "qps", "frac")) <= set(c[leg]) and "recall_vs_ef" not in c[leg]
+    assert c["graph_path_structured"]["exact_flat_qps"] == r["graph_path_structured"]["exact_flat_engine_same_rows_queries_per_s"]
+    assert not any(isinstance(v, str) and len(v) > 200 for v in json.dumps(c).split('"'))   # no prose
+
+
+def test_compact_line_stays_bounded_when_every_leg_reports(bench_on_stand_ins):
+    """worst case for the line's size: every optional leg on (config legs, single query, set concurrent, set stream,
+    both graph legs): still one line of <= 4096 bytes with the per-leg summaries (asserted inside run())"""
+    argv = [a for a in SMALL]
+    for flag, v in (("--config-legs", "1"), ("--single-query", "6"), ("--set-concurrent", "64")):
+        argv[argv.index(flag) + 1] = v
+    r = bench_on_stand_ins(argv + ["--config-legs-rows-div", "5000", "--graph-rows", "1000", "--structured-rows", "600",
+                                   "--set-stream", "64"])
+    c = bench_on_stand_ins.line
+    assert "truncated" not in c
+    assert list(c["configs"]) == ["configs[1]", "configs[3]", "configs[4]"]
+    for name, leg in c["configs"].items():
+        assert leg["oracle"] is True and leg["ms_per_step"] == r["configs"][name]["ms_per_step"]
+        assert leg["frac"] == r["configs"][name]["roofline"]["frac"]
+    assert set(("flat_us", "graph_ef10_us", "cpu_hnsw_us")) <= set(c["single_query"])
+    assert set(("set_rows_per_s", "search_fraction_of_alone")) <= set(c["set_concurrent"])
+    # and the fallback: an absurdly long value in a leg summary drops optional legs, never the contract
+    bench = bench_on_stand_ins.module
+    big = dict(r)
+    big["configs"] = {("configs[%d]" % i): dict(r["configs"]["configs[1]"]) for i in range(200)}
+    s = bench.compact_line(big)
+    assert len(s) <= 4096
+    back = json.loads(s)
+    assert back["truncated"] is True and "roofline" in back and "cpu_baseline" in back and "configs" not in back
 
 
 def test_config_legs_report_three_more_shapes_with_exactness_and_roofline_before_the_cpu_tables(bench_on_stand_ins):
@@ -232,8 +284,10 @@ def test_multi_rank_flow_rank0_prints_the_line(bench_on_stand_ins, monkeypatch):
     assert calls[0] == "init" and calls[-1] == "destroy" and "all_reduce" in calls and calls.count("barrier") >= 3
 
 
-def _run_bench_subprocess(argv, devices):
+def _run_bench_subprocess(argv, devices, detail=None):
     import subprocess
+    if detail is not None:
+        argv = argv + ["--detail-file", str(detail)]
     env = dict(os.environ, EHX_BENCH_STANDINS="1", EHX_STANDIN_DEVICES=str(devices),
                PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests", "bench_stubs"), ROOT,
                                            os.environ.get("PYTHONPATH", "")]))
@@ -243,14 +297,14 @@ def _run_bench_subprocess(argv, devices):
                           text=True, timeout=600)
 
 
-def test_gpus_2_launches_two_real_ranks():
+def test_gpus_2_launches_two_real_ranks(tmp_path):
     """`python bench.py --gpus 2` (no torchrun around it, WORLD_SIZE unset) must start the two ranks itself.
     Here: the real launcher, two real processes under torch.distributed.run, a real process group (gloo instead of RCCL),
     the product's own sharded.py (row partition, ONE packed all-gather per batch, merge) — only the engine and torch.cuda
     are stand-ins (sitecustomize.py in tests/bench_stubs).  Each rank holds half of the rows; the merged answer is checked
     against the oracle's exhaustive scan of ALL rows inside bench.py (exactness block), so a wrong partition, gather or
     merge fails the run."""
-    r = _run_bench_subprocess(SMALL + ["--gpus", "2", "--rows", "3001"], devices=2)
+    r = _run_bench_subprocess(SMALL + ["--gpus", "2", "--rows", "3001"], devices=2, detail=tmp_path / "d.json")
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -258,7 +312,13 @@ def test_gpus_2_launches_two_real_ranks():
     # (RCCL's "Librccl path : ..." sits in a block buffer until exit): rank 0 flushes it first, the others write to stderr
     assert r.stdout.strip().splitlines()[-1] == lines[0], r.stdout[-500:]
     assert "Librccl path : stand-in (rank 0)" in r.stdout + r.stderr
-    out = json.loads(lines[0])
+    line = json.loads(lines[0])
+    assert len(lines[0]) <= 4096 and line["n_gpus"] == 2 and line["config"]["world_size"] == 2
+    assert line["config"]["rows"] == 3001 and "row-shard x2" in line["config"]["parallelism"] and line["scaling"] == "strong"
+    assert line["exactness"]["ids_identical_to_oracle"] and line["exactness"]["recall_at_10"] == 1.0
+    assert "roofline" in line and line["value"] > 0
+    with open(tmp_path / "d.json") as f:
+        out = json.load(f)
     assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2
     assert out["config"]["rows_per_rank"] == [1500, 1501] and out["config"]["rows_per_gpu"] == 1500
     assert out["scaling"] == "strong" and "row-shard x2" in out["config"]["parallelism"]
@@ -268,17 +328,22 @@ def test_gpus_2_launches_two_real_ranks():
     assert "launching 2 ranks" in r.stderr
 
 
-def test_gpus_4_dry_run_ranks_partition_gather_and_only_rank0_does_host_legs():
+def test_gpus_4_dry_run_ranks_partition_gather_and_only_rank0_does_host_legs(tmp_path):
     """the shape of the driver's scaling run, at 4 ranks — real launcher, four real processes, gloo
     collectives, the product's sharded.py.  The shards are uneven (3003 rows over 4 ranks), every rank is handed its
     batches as HOST buffers (double-buffered upload path), the merged answer is checked against the oracle over all
     rows, rank 0 alone prints (and runs no single-GPU legs: no cpu_baseline, no graph legs, no config legs), and the
     line reports the world size the process group itself returns."""
-    r = _run_bench_subprocess(SMALL + ["--gpus", "4", "--rows", "3003"], devices=4)
+    r = _run_bench_subprocess(SMALL + ["--gpus", "4", "--rows", "3003"], devices=4, detail=tmp_path / "d.json")
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
-    out = json.loads(lines[0])
+    line = json.loads(lines[0])
+    assert len(lines[0]) <= 4096 and line["n_gpus"] == 4 and line["config"]["world_size"] == 4
+    for leg in ("cpu_baseline", "graph_path", "graph_path_structured", "configs", "single_query", "set_concurrent"):
+        assert leg not in line, leg
+    with open(tmp_path / "d.json") as f:
+        out = json.load(f)
     assert out["n_gpus"] == 4 and out["config"]["world_size"] == 4 and out["scaling"] == "strong"
     assert out["config"]["rows_per_rank"] == [750, 750, 750, 753] and sum(out["config"]["rows_per_rank"]) == 3003
     assert "pinned host tensors" in out["config"]["timed_from"] and "row-shard x4" in out["config"]["parallelism"]
