@@ -269,12 +269,16 @@ struct ehx_space {
   HostSlot hslot[kHostSlots];
   std::mutex hs_mu;
   std::condition_variable hs_cv;
-  uint32_t i8_fb_score = 0;      // recent batches that lost queries to the next engine (see knn_device_locked)
-  uint32_t i8_width = kMerged8;  // width of the int8 pipeline's candidate list (doubles when batches lose queries;
-                                 // create_one seeds it from the row length)
-  uint32_t i8_kprime_min = 0;    // floor of the list's logical length k' (raised when queries lose their certificate to
-                                 // a short list; flat_pass8 picks k' from the row count above it)
-  uint32_t i8_kprime_last = 0;   // the k' the last batch ran with
+  // Adaptation of the int8 pipeline's candidate list (i8_adapt): batches run in either scratch set, under the pipeline
+  // lock or not (knn_host_direct), so the score lives under its own small mutex and the lengths are atomics — a batch
+  // reads them ONCE, at its start.
+  std::mutex i8_adapt_mu;
+  uint32_t i8_fb_score = 0;      // recent batches that lost queries to the next engine (i8_adapt_mu)
+  std::atomic<uint32_t> i8_width{kMerged8};  // width of the int8 pipeline's candidate list (doubles when batches lose
+                                 // queries; create_one seeds it from the row length)
+  std::atomic<uint32_t> i8_kprime_min{0};    // floor of the list's logical length k' (raised when queries lose their
+                                 // certificate to a short list; flat_pass8 picks k' from the row count above it)
+  std::atomic<uint32_t> i8_kprime_last{0};   // the k' the last batch ran with (statistics only)
   bool vis_dirty = false;    // a search that clears its bitmaps with a memset BEFORE the kernel leaves them marked; the
                              // visit-log mode needs them all-zero at launch
   // GPU-side insertion state
@@ -327,11 +331,12 @@ struct ehx_space {
     DevBuf<uint64_t> dPool, dMerged8;
     DevBuf<uint32_t> dI8Ctl;  // [q_rows] pool counts | [q_rows] overflow flags | [256] lock-step counters
     DevBuf<uint32_t> dUflags;
+    DevBuf<uint64_t> dCnt;    // [8] epilogue counters of diagnosis builds (EHX_I8_COUNT); the set's own: nothing shared
     unsigned long long* dUncert = nullptr;
     unsigned long long* hUncertPin = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start | scan start | scan end | all enqueued work done
     hipEvent_t verdict = nullptr;                            // blocking-sync: the verdict has landed in hUncertPin
-    bool ev_valid = false;
+    std::atomic<bool> ev_valid{false};
     uint64_t ev_seq = 0;     // value of ehx_space::ev_counter when ev[] was last recorded (ehx_stats: which set is newest)
     hipEvent_t ring[64][2] = {};
     uint64_t ring_count = 0;
@@ -345,7 +350,7 @@ struct ehx_space {
   float* hStage = nullptr;  // pinned staging (Set / Get / query upload)
   size_t hStageBytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool ev_valid = false;
+  std::atomic<bool> ev_valid{false};
   uint64_t ev_seq = 0;
   // ring of (start, stop) event pairs around the scan kernel: per-launch durations for the roofline
   static constexpr int kRing = 64;
@@ -1414,7 +1419,7 @@ int resolve_engine(const ehx_space* s) {
 // s->dUflags / s->dUncert16 like those of flat_pass.
 // `set`: which of the space's two scratch sets (ehx_space::I8Set) this batch runs in; the caller holds that set's mutex.
 int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_queries, uint32_t k, uint64_t* d_ids,
-               float* d_dist, uint32_t* d_count, bool count_stats) {
+               float* d_dist, uint32_t* d_count, bool count_stats, uint32_t* kprime_used = nullptr) {
   Engine& E = engine();
   ehx_space::I8Set& sc = s->i8set[set];
   static const uint32_t growth = [] {
@@ -1444,7 +1449,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   // the dimension, while the spread of the dot products shrinks like 1/sqrt(d)): at 12.5 M x 1536 a fifth of the
   // queries needed more than 256 candidates and went to the next engine, which doubled the batch time.  A space whose
   // batches keep losing queries that way doubles its list (knn_device_locked), up to kMerged8Max.
-  const uint32_t width = s->i8_width;
+  const uint32_t width = s->i8_width.load(std::memory_order_relaxed);  // (read once: another batch may widen it meanwhile)
   static const long kprime_env = [] {
     const char* g = getenv("EHX_I8_KPRIME");
     return g ? atol(g) : 0L;
@@ -1466,9 +1471,10 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   if (s->dims <= 128) kp_auto = 64u;
   else if (s->dims < 512) kp_auto = 128u;
   if (s->dims >= 1024) kp_auto = width;
-  const uint32_t kp_want = std::max(kp_auto, s->i8_kprime_min);
+  const uint32_t kp_want = std::max(kp_auto, s->i8_kprime_min.load(std::memory_order_relaxed));
   const uint32_t kprime = kprime_env >= 64 ? (uint32_t)std::min<long>(kprime_env, (long)width) : std::min(kp_want, width);
-  s->i8_kprime_last = kprime;
+  s->i8_kprime_last.store(kprime, std::memory_order_relaxed);
+  if (kprime_used) *kprime_used = kprime;
   const uint32_t n_tiles = (uint32_t)((s->n + kTileRows16 - 1) / kTileRows16);
   struct Pass {
     uint32_t tile0;
@@ -1526,7 +1532,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   if ((rc = sc.dQuv.ensure(p.q_rows))) return rc;
   if ((rc = sc.dThr8.ensure(p.q_rows))) return rc;
   if ((rc = sc.dSample8.ensure((size_t)kSampleTiles * kTileRows16 * p.q_rows))) return rc;
-  if ((rc = s->dCand.ensure((size_t)grid_max * 512 * kCandSlots))) return rc;
+  if ((rc = sc.dCnt.ensure(8, true))) return rc;   // (the set's own: this function runs outside the pipeline lock too)
   if ((rc = sc.dPool.ensure((size_t)p.q_rows * kPoolCap))) return rc;
   if ((rc = sc.dMerged8.ensure((size_t)p.q_rows * width))) return rc;
   if ((rc = sc.dI8Ctl.ensure((size_t)p.q_rows * 2 + 256))) return rc;
@@ -1559,7 +1565,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   a.perm = s->dPerm8;
   a.qparams = sc.dQp8.p;
   a.thr = sc.dThr8.p;
-  a.cand = s->dCand.p;
+  a.cand = sc.dCnt.p;
   a.pool = sc.dPool.p;
   a.pool_cnt = pool_cnt;
   a.ovf = ovf;
@@ -1630,7 +1636,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   if (getenv("EHX_I8_COUNT")) {  // diagnosis builds (-DEHX_I8_COUNT=1): the scan's epilogue counters of this batch
     unsigned long long c[8] = {0};
     HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(c, s->dCand.p, sizeof(c), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c, sc.dCnt.p, sizeof(c), hipMemcpyDeviceToHost));
     fprintf(stderr, "[i8 count] tests %llu alarms %llu row-block alarms %llu trips %llu (cumulative)\n", c[0], c[1], c[2], c[3]);
   }
   if (getenv("EHX_I8_DEBUG")) {  // diagnosis only: what the uncertified queries of this batch look like
@@ -1734,6 +1740,40 @@ int exhaustive_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_quer
   return EHX_OK;
 }
 
+// Adaptation of the int8 list after a batch of `nq` queries that ran with logical length `kprime`, lost `n_failed`
+// queries to the next engine, `n_short` of them because their candidate LIST was too short.  Called for EVERY int8
+// batch, clean ones included, from both paths (knn_device_locked; knn_host_direct's pipelined stage, which used to
+// skip it for clean batches: its score never decayed, and two losing batches any distance apart widened the list).
+// The list is too short for this data when batches keep losing queries to the next engine — which re-reads every
+// row for them, nearly a batch's worth of time however few they are (12.5 M x 1536: 13 queries in 10 batches cost
+// 45 % of the run).  Only queries whose LIST was the failing part count (the re-rank flags them 2: a pool overflow,
+// exact ties at the threshold or lost candidates are not cured by width, and a width, once raised, stays).  A batch of
+// at least 64 queries that loses more than 2 % of them that way widens the list at once; otherwise every losing
+// batch adds 4 to a score that decays by 1 per clean batch, and 8 widens (two losing batches close together).
+void i8_adapt(ehx_space* s, size_t nq, size_t n_failed, size_t n_short, uint32_t kprime) {
+  std::lock_guard<std::mutex> l(s->i8_adapt_mu);
+  if (n_short == 0) s->i8_fb_score = s->i8_fb_score ? s->i8_fb_score - 1 : 0;
+  else s->i8_fb_score += 4;
+  const uint32_t width = s->i8_width.load(std::memory_order_relaxed);
+  if (!((nq >= 64 && n_short * 50 > nq) || s->i8_fb_score >= 8)) return;
+  // (a batch that ran with an older, shorter list than the space has by now says nothing about the present one)
+  if (kprime < std::min(width, std::max(s->i8_kprime_min.load(std::memory_order_relaxed), kprime))) {
+    s->i8_fb_score = 0;
+    return;
+  }
+  if (!(width < kMerged8Max || kprime < width)) return;
+  if (kprime < width) s->i8_kprime_min.store(std::min(width, 2 * kprime), std::memory_order_relaxed);  // k' first
+  else {
+    s->i8_width.store(width * 2, std::memory_order_relaxed);
+    s->i8_kprime_min.store(width * 2, std::memory_order_relaxed);
+  }
+  s->i8_fb_score = 0;
+  static const bool trace = getenv("EHX_I8_TRACE") != nullptr;
+  if (trace)
+    fprintf(stderr, "[ehx i8] %zu of %zu queries uncertified (%zu by a short list): candidate list now %u of %u\n", n_failed,
+            nq, n_short, std::max(s->i8_kprime_min.load(), kprime), s->i8_width.load());
+}
+
 // Device pipeline of a flat space: up to three stages, each run only for the queries the previous one
 // could not certify, so the answer is always the exhaustive fp32 answer in the oracle's arithmetic:
 //   0. int8 matrix-core filter scan + certified re-rank      (all queries; spaces with the int8 scan copy, >= i8_min_rows)
@@ -1748,7 +1788,7 @@ int exhaustive_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_quer
 // (i8_short of them because their candidate list was too short) continue with the next engine.
 int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k,
                       uint64_t* d_ids, float* d_dist, uint32_t* d_count, const std::vector<uint32_t>* i8_failed = nullptr,
-                      size_t i8_short = 0) {
+                      size_t i8_short = 0, uint32_t i8_kprime_in = 0) {
   if (k == 0 || nq == 0) return EHX_OK;
   if (nq > (1u << 24)) return fail(EHX_EINVAL, "too many queries in one call: %zu", nq);
   if (s->params.mode == EHX_MODE_GRAPH) {
@@ -1793,6 +1833,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   enum { kI8, kFilter, kF32, kExhaustive };
   int rc;
   size_t n_short = 0;  // of the last stage's uncertified queries: those whose candidate LIST was too short (flag 2)
+  uint32_t i8_kprime = i8_kprime_in;  // the k' this batch's int8 stage ran with
   // run one stage on `subset` (nullptr = every query); *unc = global indices it could not certify
   auto stage = [&](int kind, const std::vector<uint32_t>* subset, bool count_stats, std::vector<uint32_t>* unc) -> int {
     const size_t m = subset ? subset->size() : nq;
@@ -1819,7 +1860,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     std::unique_lock<std::mutex> set_lock(s->i8set[0].mu, std::defer_lock);
     if (kind == kI8) set_lock.lock();
     if (kind == kExhaustive) rc = exhaustive_pass(s, st, m, q, k, oi, od, oc);
-    else if (kind == kI8) rc = flat_pass8(s, 0, st, m, q, k, oi, od, oc, count_stats);
+    else if (kind == kI8) rc = flat_pass8(s, 0, st, m, q, k, oi, od, oc, count_stats, &i8_kprime);
     else rc = flat_pass(s, st, m, q, k, oi, od, oc, kind == kFilter, count_stats);
     if (rc) return rc;
     unsigned long long* d_unc = kind == kI8 ? s->i8set[0].dUncert : s->dUncert16;
@@ -1866,26 +1907,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     counted = true;
     s->n_i8_queries += nq;
     s->n_i8_fallback += next.size();
-    // The list is too short for this data when batches keep losing queries to the next engine — which re-reads every
-    // row for them, nearly a batch's worth of time however few they are (12.5 M x 1536: 13 queries in 10 batches cost
-    // 45 % of the run).  Only queries whose LIST was the failing part count (the re-rank flags them 2: a pool overflow,
-    // exact ties at the threshold or lost candidates are not cured by width, and a width, once raised, stays).  A batch of
-    // at least 64 queries that loses more than 2 % of them that way widens the list at once; otherwise every losing
-    // batch adds 4 to a score that decays by 1 per clean batch, and 8 widens (two losing batches close together).
-    if (n_short == 0) s->i8_fb_score = s->i8_fb_score ? s->i8_fb_score - 1 : 0;
-    else s->i8_fb_score += 4;
-    if (((nq >= 64 && n_short * 50 > nq) || s->i8_fb_score >= 8) &&
-        (s->i8_width < kMerged8Max || s->i8_kprime_last < s->i8_width)) {
-      if (s->i8_kprime_last < s->i8_width) s->i8_kprime_min = std::min(s->i8_width, 2 * s->i8_kprime_last);  // k' first
-      else {
-        s->i8_width *= 2;
-        s->i8_kprime_min = s->i8_width;
-      }
-      s->i8_fb_score = 0;
-      if (getenv("EHX_I8_TRACE"))
-        fprintf(stderr, "[ehx i8] %zu of %zu queries uncertified (%zu by a short list): candidate list now %u of %u\n",
-                next.size(), nq, n_short, std::max(s->i8_kprime_min, s->i8_kprime_last), s->i8_width);
-    }
+    i8_adapt(s, nq, next.size(), n_short, i8_kprime);
     if (next.empty()) return EHX_OK;
     todo.swap(next);
     all = todo.size() * 2 > nq;
@@ -3086,7 +3108,12 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
   struct Release {
     ehx_space* s;
     ehx_space::HostSlot* h;
+    bool ok = false;   // set on the success path; an early error return may leave copies / kernels of this call in flight
     ~Release() {
+      if (!ok) {  // drain them before the slot's pinned and device buffers go to the next caller
+        if (h->st) (void)hipStreamSynchronize(h->st);
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+      }
       {
         std::lock_guard<std::mutex> hl(s->hs_mu);
         h->busy = false;
@@ -3129,12 +3156,13 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
   bool done = false, have_failed = false;
   std::vector<uint32_t> failed;
   size_t n_short = 0;
+  uint32_t kprime_used = 0;
   if (pipe_on && s->params.mode == EHX_MODE_FLAT && k <= EHX_MAX_K && s->n > 0 && resolve_engine(s) == EHX_ENGINE_I8) {
     const int set = (int)(s->i8_next_set.fetch_add(1, std::memory_order_relaxed) & 1u);   // consecutive batches alternate
     ehx_space::I8Set& sc = s->i8set[set];
     std::lock_guard<std::mutex> l(sc.mu);
     HIP_TRY(hipStreamWaitEvent(s->stream, hs->in_ev, 0));
-    if ((rc = flat_pass8(s, set, s->stream, n_queries, hs->dq.p, k, d_ids, d_dist, d_cnt, false))) return rc;
+    if ((rc = flat_pass8(s, set, s->stream, n_queries, hs->dq.p, k, d_ids, d_dist, d_cnt, false, &kprime_used))) return rc;
     HIP_TRY(hipMemcpyAsync(sc.hUncertPin, sc.dUncert, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipEventRecord(sc.verdict, s->stream));
     HIP_TRY(hipEventRecord(hs->done_ev, s->stream));
@@ -3145,6 +3173,7 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
     if (*sc.hUncertPin == 0) {
       done = true;
       s->n_i8_queries += n_queries;
+      i8_adapt(s, n_queries, 0, 0, kprime_used);   // a clean batch: the score decays
     } else {  // which queries, and why: the engine chain continues with them (below, under the pipeline lock)
       HIP_TRY(hipMemsetAsync(sc.dUncert, 0, sizeof(unsigned long long), s->stream));
       std::vector<uint32_t> flags(n_queries);
@@ -3162,7 +3191,7 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
     std::lock_guard<std::mutex> sl2(s->scratch_mu);
     HIP_TRY(hipStreamWaitEvent(s->stream, hs->in_ev, 0));
     if ((rc = knn_device_locked(s, s->stream, n_queries, hs->dq.p, k, d_ids, d_dist, d_cnt, have_failed ? &failed : nullptr,
-                                n_short)))
+                                n_short, kprime_used)))
       return rc;
     HIP_TRY(hipEventRecord(hs->done_ev, s->stream));
   }
@@ -3173,6 +3202,7 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
   memcpy(out_ids, ho, ids_b);
   memcpy(out_dist, ho + ids_b, dist_b);
   memcpy(out_count, ho + ids_b + dist_b, n_queries * sizeof(uint32_t));
+  release.ok = true;
   return EHX_OK;
 }
 

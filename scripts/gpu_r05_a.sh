@@ -9,7 +9,8 @@ O=gpurun_out
 COMMON="--check-queries 0 --no-f32-engine --graph-rows 0 --set-concurrent 0 --single-query 0 --no-cpu-baseline --config-legs 0 --cpu-hnsw-seconds 0"
 : > $O/r05_a_structured.jsonl
 for flags in "--steps 20 --warmup 5" "--steps 10 --warmup 2" "--steps 20 --warmup 5" "--steps 10 --warmup 2"; do
-  timeout 300 python bench.py $flags $COMMON 2> $O/r05_a_progress_last.txt | tail -1 >> $O/r05_a_structured.jsonl
+  timeout 300 python bench.py $flags $COMMON 2> $O/r05_a_progress_last.txt | tail -1 >> $O/r05_a_lines.jsonl
+  python -c "import json;print(json.dumps(json.load(open('gpurun_out/bench_detail.json'))))" >> $O/r05_a_structured.jsonl
   grep -h "ehx i8\|structured" $O/r05_a_progress_last.txt | tail -12
 done
 python - <<'PY'

@@ -55,7 +55,8 @@ def bench_on_stand_ins(monkeypatch, tmp_path):
 
 SMALL = ["--rows", "3000", "--dims", "32", "--batch", "16", "--steps", "3", "--warmup", "1", "--check-queries", "8",
          "--cpu-sample-rows", "3000", "--cpu-sample-queries", "8", "--cpu-hnsw-rows", "500", "--graph-batches", "2",
-         "--graph-efs", "10,20", "--config-legs", "0", "--single-query", "0", "--set-concurrent", "0"]
+         "--graph-efs", "10,20", "--reference-benchmark", "0", "--config-legs", "0", "--single-query", "0",
+         "--set-concurrent", "0"]
 
 
 def test_default_flow_prints_one_json_line_with_the_contract_fields(bench_on_stand_ins):
@@ -366,3 +367,22 @@ def test_world_size_that_contradicts_gpus_is_an_error(bench_on_stand_ins, monkey
     with pytest.raises(SystemExit) as e:
         bench_on_stand_ins(SMALL + ["--gpus", "2"])
     assert "WORLD_SIZE=4" in str(e.value)
+
+
+def test_reference_benchmark_leg_over_two_oracle_stores():
+    """the reference's benchmark shape (benchmark.py:217-272) through the gRPC shim — MultiSet, sequential
+    nearest_neighbor(num=20, key=...) RPCs, the same through a 10-worker pool, two stores side by side, key lists
+    compared.  Here (no GPU) both sides are the oracle-backed store: pins the leg's flow and its record."""
+    import importlib.util
+    from oracle.oracle_store import OracleStore
+    spec = importlib.util.spec_from_file_location("bench_refbench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r = bench.reference_benchmark(OracleStore, OracleStore, rows=400, dims=50, requests=120, num=20, workers=10)
+    assert r["identical_key_lists"] is True and r["lists_compared"] == 240 and "first_difference" not in r
+    for k in ("engine_multiset_s", "engine_sequential_s", "engine_pool10_s", "oracle_sequential_s", "oracle_pool10_s"):
+        assert r[k] > 0, k
+    line = bench.compact({"reference_benchmark": r})
+    assert line["reference_benchmark"]["identical_key_lists"] is True and line["reference_benchmark"]["requests"] == 120
+    assert set(line["reference_benchmark"]) == {"rows", "dims", "requests", "engine_sequential_s", "engine_pool10_s",
+                                                "oracle_sequential_s", "oracle_pool10_s", "identical_key_lists"}
