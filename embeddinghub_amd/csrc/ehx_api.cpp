@@ -179,6 +179,9 @@ struct ehx_space {
                                // thread still holding the handle fails with EHX_ENOTFOUND instead of touching
                                // freed memory; reclaimed by ehx_shutdown
   bool implicit_keys = false;  // rows appended by ehx_fill_synthetic: key == decimal row id
+  std::atomic<bool> poisoned{false};  // single-copy graph space (x_perm): an in-place overwrite of committed rows failed
+                               // between the raw upload and the permutation — those rows sit in raw order inside a
+                               // permuted store; searches and Gets refuse (EHX_EINTERNAL) instead of answering wrongly
   std::shared_mutex mu;        // writers: set/drop/reserve ; readers: knn/get
   std::mutex wmu;              // every mutator takes wmu first, then mu: writers are serialised among themselves, and
                                // a batch of fresh keys does its upload / statistics / scan copies holding wmu only —
@@ -1103,6 +1106,8 @@ ScanPlan plan_scan(uint32_t nq, uint32_t n_tiles, uint32_t k, int n_cus) {
 // graph pipeline: prepared queries -> zero visited bitmaps -> one-wave-per-query search
 int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k, uint64_t* d_ids,
                      float* d_dist, uint32_t* d_count) {
+  if (s->poisoned.load())
+    return fail(EHX_EINTERNAL, "graph space: an in-place overwrite failed half way (rows left in raw order); drop and rebuild it");
   if (s->g_n != s->n)
     return fail(EHX_EUNSUPPORTED,
                 "graph mode: the graph covers %llu of %llu rows (rows were written while graph building was "
@@ -2749,7 +2754,29 @@ static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>
   if ((rc = ensure_stage(s, 2 * half_bytes))) return rc;
   uint64_t min_id = ~0ull, max_id = 0;
   size_t slab = 0;
+  // single-copy graph space: everything fallible that does not depend on the upload happens BEFORE the first row lands
+  // (the id list of a non-contiguous batch and its device buffer); a failure after an in-place upload of committed rows
+  // poisons the space (the rows would stay in raw order inside a permuted store)
+  bool perm_run = true;
+  std::vector<uint64_t> perm_uniq;
+  bool touches_committed = false;
+  if (s->x_perm) {
+    for (size_t i = 1; i < n && perm_run; ++i) perm_run = ids[i] == ids[0] + i;
+    if (!perm_run) {
+      perm_uniq.assign(ids.begin(), ids.begin() + n);
+      std::sort(perm_uniq.begin(), perm_uniq.end());
+      perm_uniq.erase(std::unique(perm_uniq.begin(), perm_uniq.end()), perm_uniq.end());
+      if ((rc = s->dPermIds.ensure(perm_uniq.size()))) return rc;
+    }
+    for (size_t i = 0; i < n && !touches_committed; ++i) touches_committed = ids[i] < old_n;
+  }
+  struct Poison {   // armed while raw rows may sit in a permuted store
+    ehx_space* s;
+    bool armed = false;
+    ~Poison() { if (armed) s->poisoned.store(true); }
+  } poison{s};
   for (size_t i0 = 0; i0 < n; i0 += slab_rows, ++slab) {
+    if (touches_committed) poison.armed = true;
     const size_t m = std::min(slab_rows, n - i0);
     char* stage = (char*)s->hStage + (slab & 1) * half_bytes;
     if (slab >= 2) HIP_TRY(hipEventSynchronize(s->sev[slab & 1]));  // the upload that last used this half
@@ -2776,19 +2803,14 @@ static int write_rows_locked(ehx_space* s, size_t n, const std::vector<uint64_t>
   if (s->x_perm) {
     // single-copy graph space: the rows just written go into the search copy's block order, in place, exactly once
     // each (the permutation is its own inverse: a row written twice in this batch is permuted once)
-    bool run = true;
-    for (size_t i = 1; i < n && run; ++i) run = ids[i] == ids[0] + i;
-    if (run) {
+    if (perm_run) {
       HIP_TRY(launch_permute_blocks((float*)s->dX, s->ld, ids[0], n, nullptr, ws));
     } else {
-      std::vector<uint64_t> uniq(ids.begin(), ids.begin() + n);
-      std::sort(uniq.begin(), uniq.end());
-      uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-      if ((rc = s->dPermIds.ensure(uniq.size()))) return rc;
-      HIP_TRY(hipMemcpyAsync(s->dPermIds.p, uniq.data(), uniq.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ws));
-      HIP_TRY(hipStreamSynchronize(ws));  // (the list lives on this stack frame)
-      HIP_TRY(launch_permute_blocks((float*)s->dX, s->ld, 0, uniq.size(), s->dPermIds.p, ws));
+      HIP_TRY(hipMemcpyAsync(s->dPermIds.p, perm_uniq.data(), perm_uniq.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ws));
+      HIP_TRY(launch_permute_blocks((float*)s->dX, s->ld, 0, perm_uniq.size(), s->dPermIds.p, ws));
     }
+    HIP_TRY(hipStreamSynchronize(ws));  // (the list lives on this stack frame; the rows are in block order from here on)
+    poison.armed = false;
   }
   // per-row statistics over the touched id range (idempotent for untouched rows in between)
   HIP_TRY(launch_row_stats(s->dX, s->x_half, min_id, max_id - min_id + 1, s->dims, s->ld, s->metric, s->dInv,
@@ -2926,6 +2948,8 @@ int ehx_get_by_id(ehx_space* s, uint64_t id, float* out_vec) {
     return EHX_OK;
   }
   if (s->x_perm) {  // single-copy graph space: the row is stored in the search copy's block order — undo it here
+    if (s->poisoned.load())
+      return fail(EHX_EINTERNAL, "graph space: an in-place overwrite failed half way (rows left in raw order); drop and rebuild it");
     std::vector<float> h(s->ld);
     HIP_TRY(hipMemcpy(h.data(), s->xrow(id), (size_t)s->ld * sizeof(float), hipMemcpyDeviceToHost));
     for (uint32_t c = 0; c < s->dims; ++c) out_vec[c] = h[search_copy_pos(c)];

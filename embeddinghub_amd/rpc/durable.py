@@ -153,10 +153,13 @@ class DurableSpace:
         # the space's; taking them the other way round here deadlocked a concurrent FreezeSpace / DeleteSpace)
         # ... but the store's lock is never HELD while waiting for a busy space (a long set_batch on this space — log
         # append + engine write — would stall get_space / create_space / delete_space of every other space): the space's
-        # lock is tried for a moment under the store's, and if the space is busy both are let go before the next try.
+        # lock is TRIED (never waited for) under the store's, and if the space is busy the store's lock is let go and this
+        # thread sleeps before the next try — Python locks are not fair: a loop that re-took the store's lock at once kept
+        # it away from everybody else for as long as the space stayed busy.
+        import time as _time
         while True:
             with self._owner._mu:
-                if self._mu.acquire(timeout=0.02):
+                if self._mu.acquire(blocking=False):
                     try:
                         self._inner.freeze()
                         if self._owner._spaces.get(self._name) is self:  # (a stale handle of a deleted space records nothing)
@@ -164,6 +167,7 @@ class DurableSpace:
                     finally:
                         self._mu.release()
                     return
+            _time.sleep(0.01)
 
     def __getattr__(self, name):  # get / nearest / keys_sorted / __len__ ... : straight through
         return getattr(self._inner, name)

@@ -84,7 +84,8 @@ def phase(name, stream_handle, sync):
     print(json.dumps({"label": args.label, "phase": name, "qps": round(nb * B / wall, 1), "wall_ms_per_batch": round(wall / nb * 1e3, 3),
                       "scan_ms_mean": round(st["scan_ms_mean"], 4), "last_scan_ms": round(st["last_scan_ms"], 4),
                       "last_total_ms": round(st["last_total_ms"], 4), "fallbacks": int(st["n_i8_fallback"] + st["n_filter_fallback"]),
-                      "call_ms_then_sync_ms": per[:6], "ids_checksum": int(ti.sum().item())}), flush=True)
+                      "call_ms_then_sync_ms": per[:6], "slowest_call": max(range(nb), key=lambda i: per[i][0] + per[i][1]),
+                      "slowest_call_ms_then_sync_ms": max(per, key=lambda p: p[0] + p[1]), "ids_checksum": int(ti.sum().item())}), flush=True)
 
 
 phase("null stream, device sync", torch.cuda.current_stream().cuda_stream, torch.cuda.synchronize)
