@@ -1441,10 +1441,17 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
     const double v = g ? atof(g) : 2.0;  // (1e9: always the 256th best)
     return v < 1.0 ? 1.0 : v;
   }();
-  static const bool use_sync = [] {
+  // EHX_I8_SYNC: lock-step of the query-tile workgroups that stream one row chunk (k_flati8.hip).  "rev": by ring
+  // revolution (rounds 2-4: 9 % of the scan time in round 2, 60 % on round 4's kernel); N > 0: by tile, tolerance N tiles
+  // (round 5); 0 / unset: off.
+  static const int sync_mode = [] {
     const char* g = getenv("EHX_I8_SYNC");
-    return g ? atoi(g) != 0 : false;  // measured r02: the lock-step costs ~9 % of the scan time at 10 M x 768
+    if (!g) return 0;
+    if (!strcmp(g, "rev")) return -1;
+    const int v = atoi(g);
+    return v < 0 ? 0 : (v > 64 ? 64 : v);
   }();
+  const bool use_sync = sync_mode != 0;
   constexpr uint32_t kSampleTiles = 8;
   // The int8 bound leaves ~60-75 rows per query ON AVERAGE that it cannot exclude from the top-10 at 10 M rows
   // (scripts/studies/int8_filter_bound.py), with a heavy tail — a query whose 10th neighbour is unusually far has
@@ -1519,8 +1526,14 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   // passes to come it only has to deliver the next threshold's rank (twice over, at least min(512, 2 k') keys: round 2
   // collected 1024 and spent more than half of the first pass in the epilogue's slow path).
   const uint64_t first_rows = (uint64_t)passes.front().plan.n_tiles * kTileRows16;
+  static const uint64_t first_keys_env = [] {  // (EHX_I8_FIRST_KEYS: keys per query the first pass of a cascade aims for)
+    const char* g = getenv("EHX_I8_FIRST_KEYS");
+    const long v = g ? atol(g) : 0;
+    return (uint64_t)(v < 0 ? 0 : v);
+  }();
+  const uint64_t first_floor = first_keys_env ? first_keys_env : std::min<uint64_t>(512, 2ull * kprime);
   const uint64_t first_keys = std::min<uint64_t>(
-      2048, passes.size() == 1 ? 2ull * kprime : std::max<uint64_t>(std::min<uint64_t>(512, 2ull * kprime), 2ull * rank_after(0)));
+      2048, passes.size() == 1 ? 2ull * kprime : std::max<uint64_t>(first_floor, 2ull * rank_after(0)));
   const uint32_t sample_rank =
       (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, first_keys * kSampleTiles * kTileRows16 / first_rows));
   const ScanPlan p = passes.back().plan;  // (q_tiles, q_rows are the same for every pass)
@@ -1540,7 +1553,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   if ((rc = sc.dCnt.ensure(8, true))) return rc;   // (the set's own: this function runs outside the pipeline lock too)
   if ((rc = sc.dPool.ensure((size_t)p.q_rows * kPoolCap))) return rc;
   if ((rc = sc.dMerged8.ensure((size_t)p.q_rows * width))) return rc;
-  if ((rc = sc.dI8Ctl.ensure((size_t)p.q_rows * 2 + 256))) return rc;
+  if ((rc = sc.dI8Ctl.ensure((size_t)p.q_rows * 2 + kSyncWordsI8))) return rc;
   if ((rc = sc.dUflags.ensure(p.q_rows))) return rc;
   if (!sc.dUncert) {
     HIP_TRY(hipMalloc((void**)&sc.dUncert, sizeof(unsigned long long)));
@@ -1603,7 +1616,8 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
     a.sync = nullptr;
     if (use_sync && passes[i].plan.xcd_map && p.q_tiles > 1 && passes[i].plan.tiles_per_chunk >= 4) {
       a.sync = sync;
-      if (i > 0) HIP_TRY(hipMemsetAsync(sync, 0, 256 * sizeof(uint32_t), st));
+      a.sync_tol = sync_mode > 0 ? (uint32_t)sync_mode : 0u;
+      if (i > 0) HIP_TRY(hipMemsetAsync(sync, 0, kSyncWordsI8 * sizeof(uint32_t), st));
     }
     HIP_TRY(scan(passes[i].plan, passes[i].tile0));
     if (last) {  // (the last select and the re-rank are outside the timed scan phase, like flat_pass's final merge)

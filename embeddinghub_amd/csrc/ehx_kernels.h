@@ -583,6 +583,7 @@ inline float scan16_eps(uint32_t dims) { return 1.0e-3f + 2.0e-7f * (float)dims;
 
 // ---- int8-MFMA filter scan (k_flati8.hip) ----
 constexpr uint32_t kPoolCap = 4096;    // candidate keys one query can collect in one pass (overflow: query flagged)
+constexpr uint32_t kSyncWordsI8 = 1024; // lock-step progress words of the int8 scan: [n_chunks <= 256][4 query tiles]
 constexpr uint32_t kMerged8 = 256;     // default width of the running best list of the int8 pipeline
 constexpr uint32_t kMerged8Max = 1024; // widest list (a space widens its list when queries go uncertified: ehx_api.cpp)
 struct ScanArgsI8 {
@@ -604,7 +605,10 @@ struct ScanArgsI8 {
   uint32_t ld;            // bytes (= k-values) per row of the scan copy, % 64 == 0 (whole 64-byte stages)
   uint32_t tile0, n_tiles, q_tiles, n_chunks, tiles_per_chunk;
   uint32_t xcd_map;
-  uint32_t* sync = nullptr;  // [n_chunks] lock-step counters, zero before the launch (nullptr: off)
+  uint32_t* sync = nullptr;  // lock-step words, zero before the launch (nullptr: off): sync_tol == 0: [n_chunks] counters,
+                             // one add per workgroup and ring revolution; sync_tol > 0: [n_chunks][4] progress words,
+                             // tiles completed by each of the chunk's (<= 4) query-tile workgroups
+  uint32_t sync_tol = 0;     // > 0: a workgroup does not run more than this many TILES ahead of its slowest sibling
 };
 // Stage-blocked layout of the int8 scan copy / query tiles: tiles of 256 rows, stages of 64 columns (bytes); one
 // (tile, stage) block is 256 rows x 64 B = 16 KiB in exactly the LDS image of the kernel (16-byte chunk c of row r

@@ -584,7 +584,10 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   };
 
   // ---- lock-step with the sibling workgroups of this chunk (see the header) ----
-  uint32_t* const sync_ctr = (a.sync && a.xcd_map && a.q_tiles > 1) ? a.sync + chunk : nullptr;
+  const bool sync_by_tile = a.sync_tol > 0u;   // per-sibling progress words, checked once per tile (REV loop only)
+  uint32_t* const sync_ctr = (a.sync && a.xcd_map && a.q_tiles > 1 && (!sync_by_tile || (REV && a.q_tiles <= 4)))
+                                 ? a.sync + (sync_by_tile ? chunk * 4u : chunk)
+                                 : nullptr;
   bool sync_on = sync_ctr != nullptr && !DUMP;
   uint32_t sync_m0 = kSyncOffI8;
   uint32_t sync_voff = 0u;
@@ -786,8 +789,48 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     rsrc += kTileRows16 * 16;
     if (w < 4) EHX_DMA(rdst, 4096, voff, rsrc);
     uint32_t q = 0;
+    // Lock-step by TILE (round 5; a.sync_tol = the tolerance in tiles): each of the chunk's query-tile workgroups
+    // publishes how many tiles it has completed in a word of its own (a plain store: no read-modify-write, no return
+    // value to wait for) and, once per tile, looks at a snapshot of its siblings' words taken a tile earlier (an
+    // asynchronous global->LDS load: stale by a tile, and progress only grows, so a stale view shows less than the truth
+    // and at worst sends the wave to the live poll, which decides).  Only a workgroup that really is more than sync_tol
+    // tiles ahead of the slowest sibling waits.  What the four stream stays inside the XCD's L2: 8 chunks x
+    // (sync_tol + 1) tiles x 192 KiB at d = 768.  One foreign store per tile in the vmcnt queue (see the header: more
+    // than one outstanding could let a counted wait pass early; a tile is ~10 us, the store retires in ~1).
+    auto after_tile = [&](const uint32_t t) {
+      if (sync_on && sync_by_tile && w == 0) {
+        uint32_t mn = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < a.q_tiles; ++i) mn = min(mn, (uint32_t)__builtin_amdgcn_readfirstlane(sync_lds[i]));
+        const uint32_t need = t + 1u > a.sync_tol ? t + 1u - a.sync_tol : 0u;
+        if (mn < need) {
+          uint32_t spins = 0;
+          for (;;) {
+            mn = 0xFFFFFFFFu;
+            for (uint32_t i = 0; i < a.q_tiles; ++i)
+              mn = min(mn, (uint32_t)__builtin_amdgcn_readfirstlane(
+                               __hip_atomic_load(sync_ctr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+            if (mn >= need) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > 4000u) {  // a sibling is not resident (or died): never hang, just stop synchronising
+              sync_on = false;
+              break;
+            }
+          }
+        }
+        if (lane == 0) __hip_atomic_store(sync_ctr + qt, t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the lane id behind an opaque copy: a loop-invariant derived from it would be kept alive across the stage
+        // loop, which has no register to spare)
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));
+        const uint32_t voff4 = ((uint32_t)lane_s & 3u) * 4u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1"
+                     :
+                     : "s"(sync_m0), "v"(voff4), "s"(sync_ctr)
+                     : "memory");
+      }
+    };
     auto after_revolution = [&]() {
-      if (sync_on && w == 0) {
+      if (sync_on && !sync_by_tile && w == 0) {
         // revolution q is done.  The snapshot taken after revolution q-1 (landed long ago: four stage waits have
         // passed) must show every sibling through revolution q-2; then announce q and take the next snapshot.
         const uint32_t seen = __builtin_amdgcn_readfirstlane(sync_lds[0]);
@@ -832,6 +875,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
         epilogue(t);
 #endif
       }
+      after_tile(t);
       // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
       // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
       qsrc = qbase + 3 * kStageI8;

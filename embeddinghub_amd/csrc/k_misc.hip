@@ -738,7 +738,7 @@ __device__ __forceinline__ void prep_query8_row(const float* __restrict__ q_in, 
 // Everything a batch of the int8 engine needs before its first scan launch, ONE launch (it was three: the fp32 query
 // rows of the re-rank, the int8 tiles + parameters, and a memset of the scan's control words): one wave per query row
 // writes its prepared fp32 row, its int8 tile and parameters, and zeroes its pool count and overflow flag; block 0 also
-// zeroes the 256 lock-step counters.  ctl = [q_rows] pool counts | [q_rows] overflow flags | [256] counters.
+// zeroes the lock-step counters.  ctl = [q_rows] pool counts | [q_rows] overflow flags | [kSyncWordsI8] counters.
 __global__ __launch_bounds__(64) void prep_queries_i8_kernel(const float* __restrict__ q_in, uint32_t nq, uint32_t dims,
                                                              uint32_t ld, uint32_t ld8, uint32_t q_rows, int metric,
                                                              float* __restrict__ q_out, int8_t* __restrict__ Q8,
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(64) void prep_queries_i8_kernel(const float* __rest
     ctl[q_rows + row] = 0;
   }
   if (row == 0)
-    for (uint32_t i = lane; i < 256; i += 64) ctl[2 * (size_t)q_rows + i] = 0;
+    for (uint32_t i = lane; i < kSyncWordsI8; i += 64) ctl[2 * (size_t)q_rows + i] = 0;
 }
 
 hipError_t launch_prep_queries_i8(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld, uint32_t ld8,

@@ -1,0 +1,26 @@
+#!/bin/bash
+# round 5, session f: the cascade's shape on a small shard (1 M x 768; pass 1 of 512 tiles runs at half the steady-state
+# rate: its loose threshold lets ~256 keys per query through the epilogue's slow path) — first pass size, growth, and the
+# number of keys the first pass aims for (EHX_I8_FIRST_KEYS, new)
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+O=gpurun_out
+OUT=$O/r05_f_cascade.jsonl
+: > $OUT
+one() {  # rows dims metric first growth keys
+  EHX_I8_FIRST_TILES=$4 EHX_I8_GROWTH=$5 EHX_I8_FIRST_KEYS=$6 timeout 120 python scripts/ab_flat.py --rows $1 --dims $2 --metric $3 --steps 60 --warmup 8 --label "first=$4 growth=$5 keys=$6" 2>/dev/null | tail -1 >> $OUT
+}
+for cfg in "512 4 0" "512 4 128" "512 4 96" "512 4 64" "256 4 0" "256 4 96" "1024 4 96" "512 8 96" "512 16 96" "256 8 96" "1024 8 96" "2048 4 96" "512 4 0"; do
+  one 1000000 768 cosine $cfg
+done
+for cfg in "512 4 0" "512 4 96" "512 8 96" "256 4 96"; do
+  one 1250000 768 cosine $cfg
+  one 6250000 128 l2 $cfg
+  one 10000000 768 cosine $cfg
+done
+python - <<'PY'
+import json
+for l in open("gpurun_out/r05_f_cascade.jsonl"):
+    r = json.loads(l)
+    print(r["rows"], r["dims"], r["label"], "ms", r["ms_per_step"], "kernel", r["kernel_ms"], "fb", r["i8_fallback"], r["filter_fallback"], r["exhaustive"], "chk", r["ids_checksum_last_batch"])
+PY

@@ -27,6 +27,8 @@ ap.add_argument("--batches", type=int, default=10)
 ap.add_argument("--graph-rows", type=int, default=0)
 ap.add_argument("--gauss", action="store_true", help="isotropic rows instead (control)")
 ap.add_argument("--label", default="")
+ap.add_argument("--own-first", action="store_true", help="first phase on the stream of its own instead of the NULL stream")
+ap.add_argument("--sleep", type=float, default=0.0, help="seconds between the end of the build and the first search")
 args = ap.parse_args()
 n2, d, R, B, k, chunk = args.rows, args.dims, args.R, 1024, 10, 65536
 A = np.random.default_rng(20250213).standard_normal((R, d)).astype(np.float32) / np.sqrt(R)
@@ -88,6 +90,10 @@ def phase(name, stream_handle, sync):
                       "slowest_call_ms_then_sync_ms": max(per, key=lambda p: p[0] + p[1]), "ids_checksum": int(ti.sum().item())}), flush=True)
 
 
+if args.sleep:
+    time.sleep(args.sleep)
+if args.own_first:
+    phase("own stream, stream sync (first)", own.cuda_stream, own.synchronize)
 phase("null stream, device sync", torch.cuda.current_stream().cuda_stream, torch.cuda.synchronize)
 phase("own stream, stream sync", own.cuda_stream, own.synchronize)
 phase("null stream, device sync (again)", torch.cuda.current_stream().cuda_stream, torch.cuda.synchronize)
