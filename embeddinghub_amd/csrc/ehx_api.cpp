@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/ehx.h"
+#include "ehx_env.h"
 #include "ehx_kernels.h"
 
 using namespace ehx;
@@ -806,11 +807,7 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
   // few rows it holds (one wave's ef_construction search is a millisecond of dependent steps), so the small shares are
   // paid once, while the graph is small: 2 M x 768 takes 18.4 s with 1/16 and 19.2 s with 1/64.
   // EHX_BUILD_DIV overrides the share (A/B runs).
-  static const uint64_t div_env = [] {
-    const char* e = getenv("EHX_BUILD_DIV");
-    const long v = e ? atol(e) : 0;
-    return (uint64_t)(v < 0 ? 0 : v);
-  }();
+  const uint64_t div_env = env().build_div;
   const uint64_t div = div_env >= 2 ? div_env : (end < (128u << 10) ? 256 : 128);
   auto round_size = [&](uint64_t g_n, uint64_t left) {
     uint64_t P = 1;
@@ -877,7 +874,7 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
   a.link_next = s->dLinkNext.p;
   a.link_touched = (uint2*)s->dLinkTouched.p;
   // EHX_BUILD_TRACE=1: progress to stderr (costs a stream synchronisation every 128 rounds)
-  const bool trace = getenv("EHX_BUILD_TRACE") != nullptr;
+  const bool trace = env().build_trace;
   const auto t_build0 = std::chrono::steady_clock::now();
   uint64_t pos = id0, round = 0;
   while (pos < end) {
@@ -922,10 +919,7 @@ int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch) {
   // rounds of 4096 rows on a 10 M-row index, four times what a 1024-query search batch needs (it re-allocates its own,
   // zeroed, at its first call: ~1 ms).  Streamed Sets (small calls) keep theirs.
   // (EHX_BUILD_SCRATCH_KEEP=<bytes>: what a build may keep, whatever its size — tests release at small sizes with 0)
-  static const long long keep_env = [] {
-    const char* e = getenv("EHX_BUILD_SCRATCH_KEEP");
-    return e ? atoll(e) : -1ll;
-  }();
+  const long long keep_env = env().build_scratch_keep;
   const bool give_back = keep_env >= 0 ? s->dVisited.n * sizeof(uint32_t) > (unsigned long long)keep_env
                                        : (end - id0 >= 65536 && s->dVisited.n * sizeof(uint32_t) > (1ull << 30));
   if (give_back) {
@@ -1122,10 +1116,7 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   // the bitmaps are all-zero between kernels (every kernel that marks rows clears them again): zeroed once, on
   // allocation
   if ((rc = s->dVisited.ensure((size_t)nq * vis_words, true))) return rc;
-  static const bool use_vislog = [] {
-    const char* g = getenv("EHX_GRAPH_VISLOG");  // "0": per-batch memset of the bitmaps instead (A/B runs)
-    return g ? atoi(g) != 0 : true;
-  }();
+  const bool use_vislog = env().graph_vislog;  // (EHX_GRAPH_VISLOG=0: per-batch memset of the bitmaps instead, A/B runs)
   // Measured (r02, batch 1024, memset inside the timed region; gpurun_out of scripts/gpu_session_n.sh): the memset
   // costs n/8 bytes per query, streamed; the log costs one store per visited row plus one RANDOM 4-byte store per row
   // when the query clears its words — ~27 ef of them.  6.25 M x 128: ef 50 log 0.41 / memset 0.47 ms, ef 200 1.11 /
@@ -1427,30 +1418,18 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
                float* d_dist, uint32_t* d_count, bool count_stats, uint32_t* kprime_used = nullptr) {
   Engine& E = engine();
   ehx_space::I8Set& sc = s->i8set[set];
-  static const uint32_t growth = [] {
-    const char* g = getenv("EHX_I8_GROWTH");
-    const long v = g ? atol(g) : 4;
-    return (uint32_t)(v < 2 ? 2 : (v > 64 ? 64 : v));
-  }();
-  static const double safety = [] {
-    const char* g = getenv("EHX_I8_SAFETY");
+  const uint32_t growth = env().i8_growth;
+  const double safety = [] {
     // rank of the next pass's threshold = 256 x (share of the rows seen) x safety.  2: the last pass of a 10 M-row batch
     // runs under the 138th best of the first 27 % (about 510 rows below it overall: the list still fills to 256, the
     // certificate's floor is unchanged) instead of the 256th (950 rows): fewer alarms, fewer keys — 7.64 -> 7.46 ms per
     // batch, 0 fallbacks over 25 batches; 1.5: 7.44; 1: a query falls to the next engine (profiles/r03_e_i8_safety_sweep.jsonl)
-    const double v = g ? atof(g) : 2.0;  // (1e9: always the 256th best)
-    return v < 1.0 ? 1.0 : v;
+    return env().i8_safety;  // (EHX_I8_SAFETY; 1e9: always the 256th best)
   }();
   // EHX_I8_SYNC: lock-step of the query-tile workgroups that stream one row chunk (k_flati8.hip).  "rev": by ring
   // revolution (rounds 2-4: 9 % of the scan time in round 2, 60 % on round 4's kernel); N > 0: by tile, tolerance N tiles
   // (round 5); 0 / unset: off.
-  static const int sync_mode = [] {
-    const char* g = getenv("EHX_I8_SYNC");
-    if (!g) return 0;
-    if (!strcmp(g, "rev")) return -1;
-    const int v = atoi(g);
-    return v < 0 ? 0 : (v > 64 ? 64 : v);
-  }();
+  const int sync_mode = env().i8_sync;
   const bool use_sync = sync_mode != 0;
   constexpr uint32_t kSampleTiles = 8;
   // The int8 bound leaves ~60-75 rows per query ON AVERAGE that it cannot exclude from the top-10 at 10 M rows
@@ -1462,10 +1441,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   // queries needed more than 256 candidates and went to the next engine, which doubled the batch time.  A space whose
   // batches keep losing queries that way doubles its list (knn_device_locked), up to kMerged8Max.
   const uint32_t width = s->i8_width.load(std::memory_order_relaxed);  // (read once: another batch may widen it meanwhile)
-  static const long kprime_env = [] {
-    const char* g = getenv("EHX_I8_KPRIME");
-    return g ? atol(g) : 0L;
-  }();
+  const long kprime_env = env().i8_kprime;
   // How many candidates a query keeps is what the scan's epilogue pays for (every key collected is a trip through its
   // slow path, and the waves of a workgroup wait for each other at every stage: 1.25 M x 768 collected 470 keys per
   // query, 70 % of the epilogue's tests alarmed).  The rows a query cannot exclude grow with the index (60-75 on average
@@ -1495,11 +1471,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   // First pass: up to 512 tiles (131 072 rows) under a threshold taken from the sample at a LOW rank, chosen so that
   // the pass collects ~1000 keys per query (any threshold is sound, see sample_select256_kernel); then x4 in rows per
   // pass under the 256th best so far.
-  static const uint32_t kFirstTiles = [] {  // (EHX_I8_FIRST_TILES: sweeps of the cascade's shape on small shards)
-    const char* g = getenv("EHX_I8_FIRST_TILES");
-    const long v = g ? atol(g) : 512;
-    return (uint32_t)(v < 64 ? 64 : (v > 65536 ? 65536 : v));
-  }();
+  const uint32_t kFirstTiles = env().i8_first_tiles;  // (EHX_I8_FIRST_TILES: sweeps of the cascade's shape on small shards)
   std::vector<Pass> passes;
   {
     uint32_t done = 0, cum = kFirstTiles;
@@ -1526,11 +1498,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   // passes to come it only has to deliver the next threshold's rank (twice over, at least min(512, 2 k') keys: round 2
   // collected 1024 and spent more than half of the first pass in the epilogue's slow path).
   const uint64_t first_rows = (uint64_t)passes.front().plan.n_tiles * kTileRows16;
-  static const uint64_t first_keys_env = [] {  // (EHX_I8_FIRST_KEYS: keys per query the first pass of a cascade aims for)
-    const char* g = getenv("EHX_I8_FIRST_KEYS");
-    const long v = g ? atol(g) : 0;
-    return (uint64_t)(v < 0 ? 0 : v);
-  }();
+  const uint64_t first_keys_env = env().i8_first_keys;  // (EHX_I8_FIRST_KEYS: keys per query the first pass aims for)
   const uint64_t first_floor = first_keys_env ? first_keys_env : std::min<uint64_t>(512, 2ull * kprime);
   const uint64_t first_keys = std::min<uint64_t>(
       2048, passes.size() == 1 ? 2ull * kprime : std::max<uint64_t>(first_floor, 2ull * rank_after(0)));
@@ -1652,13 +1620,13 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   r.ld = s->ld;
   r.metric = s->metric;
   HIP_TRY(launch_rerank256(r, st));
-  if (getenv("EHX_I8_COUNT")) {  // diagnosis builds (-DEHX_I8_COUNT=1): the scan's epilogue counters of this batch
+  if (env().i8_count) {  // diagnosis builds (-DEHX_I8_COUNT=1): the scan's epilogue counters of this batch
     unsigned long long c[8] = {0};
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(c, sc.dCnt.p, sizeof(c), hipMemcpyDeviceToHost));
     fprintf(stderr, "[i8 count] tests %llu alarms %llu row-block alarms %llu trips %llu (cumulative)\n", c[0], c[1], c[2], c[3]);
   }
-  if (getenv("EHX_I8_DEBUG")) {  // diagnosis only: what the uncertified queries of this batch look like
+  if (env().i8_debug) {  // diagnosis only: what the uncertified queries of this batch look like
     HIP_TRY(hipStreamSynchronize(st));
     std::vector<uint32_t> fl(nq), ov(nq);
     std::vector<float4> qp(nq);
@@ -1787,8 +1755,7 @@ void i8_adapt(ehx_space* s, size_t nq, size_t n_failed, size_t n_short, uint32_t
     s->i8_kprime_min.store(width * 2, std::memory_order_relaxed);
   }
   s->i8_fb_score = 0;
-  static const bool trace = getenv("EHX_I8_TRACE") != nullptr;
-  if (trace)
+  if (env().i8_trace)
     fprintf(stderr, "[ehx i8] %zu of %zu queries uncertified (%zu by a short list): candidate list now %u of %u\n", n_failed,
             nq, n_short, std::max(s->i8_kprime_min.load(), kprime), s->i8_width.load());
 }
@@ -1836,10 +1803,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
   // cascade, selects, re-rank) take ~0.55 ms for a single query on 10 k rows, where the exhaustive canonical pass — the
   // oracle's arithmetic over every row, exact by construction, three launches — reads the rows once.  Concurrent single
   // queries never get here alone: ehx_knn coalesces them into device batches.  (EHX_SMALL_EXACT_BYTES=0 switches it off.)
-  static const uint64_t small_bytes = [] {
-    const char* e = getenv("EHX_SMALL_EXACT_BYTES");
-    return e ? strtoull(e, nullptr, 10) : (512ull << 20);
-  }();
+  const uint64_t small_bytes = env().small_exact_bytes;
   if (nq == 1 && s->scan_sel == EHX_SCAN_AUTO && s->n > 0 && (uint64_t)s->n * s->ld * s->esz <= small_bytes) {
     int rc2 = exhaustive_pass(s, st, nq, d_queries, k, d_ids, d_dist, d_count);
     if (rc2) return rc2;
@@ -2219,6 +2183,7 @@ int ehx_init(const int* device_ids, int n_devices) {
   Engine& E = engine();
   std::lock_guard<std::mutex> lk(E.mu);
   if (E.inited) return EHX_OK;
+  (void)env();   // every environment knob is read here, once (ehx_env.h)
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) {
@@ -2242,8 +2207,7 @@ int ehx_init(const int* device_ids, int n_devices) {
   // devices is opened EXPLICITLY, and a pair that cannot be opened fails the call, naming the two devices — a node whose
   // links are down must not quietly run its exchange step through host memory (EHX_ALLOW_NO_PEER=1 accepts it: the
   // copies then stage through the host, correct but slow).
-  const char* allow = getenv("EHX_ALLOW_NO_PEER");
-  const bool strict = !(allow && atoi(allow) != 0);
+  const bool strict = !env().allow_no_peer;
   for (int a : devs)
     for (int b : devs) {
       if (a == b) continue;
@@ -2303,8 +2267,7 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
     // row's ring loads (ehx_kernels.h, wave_group_dists_t): sunk below them it is the youngest load when the first
     // product needs it and the wait drains the ring — that cost 13 % at 2 M x 768 (profiles/r04_r_*); requested first
     // the cost is 2 % (profiles/r04_s_*, r04_t_*).  EHX_GRAPH_TWO_COPIES=1: raw rows + search copy as in rounds 1-3.
-    const char* two = getenv("EHX_GRAPH_TWO_COPIES");
-    s->x_perm = params && params->mode == EHX_MODE_GRAPH && !s->x_half && !(two && atoi(two) != 0);
+    s->x_perm = params && params->mode == EHX_MODE_GRAPH && !s->x_half && !env().graph_two_copies;
   }
   if (parent) s->params.shards = params->shards;
   if (s->params.mode != EHX_MODE_FLAT && s->params.mode != EHX_MODE_GRAPH)
@@ -2320,9 +2283,8 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
   }
   if (s->params.scan > EHX_SCAN_F16) return fail(EHX_EINVAL, "unknown scan engine %u", s->params.scan);
   {
-    const char* env = getenv("EHX_SCAN");  // "f32": every space scans in fp32 (A/B runs, profiling)
-    const bool env_f32 = env && strcmp(env, "f32") == 0;
-    const bool env_f16 = env && strcmp(env, "f16") == 0;  // "f16": no int8 scan copy (A/B runs)
+    const bool env_f32 = env().scan_f32;  // EHX_SCAN=f32: every space scans in fp32 (A/B runs, profiling)
+    const bool env_f16 = env().scan_f16;  // EHX_SCAN=f16: no int8 scan copy (A/B runs)
     s->use16 = s->params.mode == EHX_MODE_FLAT && s->params.scan != EHX_SCAN_F32 && !env_f32;
     s->has16 = s->use16;
     s->scan_sel = s->use16 ? s->params.scan : (uint32_t)EHX_SCAN_F32;
@@ -2340,11 +2302,8 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
     // scores shrinks like 1/sqrt(d) — at d = 1536 (12.5 M rows) a fifth of the queries needed more than 256 candidates
     // and the first batches paid a second engine's pass for them until the list had widened by itself
     s->i8_width = dims >= 1536 ? 2 * kMerged8 : kMerged8;
-    if (const char* wd = getenv("EHX_I8_WIDTH")) {
-      const long v = atol(wd);
-      if (v == 256 || v == 512 || v == 1024) s->i8_width = (uint32_t)v;
-    }
-    if (const char* mr = getenv("EHX_I8_MIN_ROWS")) s->i8_min_rows = std::max<uint64_t>(4096, strtoull(mr, nullptr, 10));
+    if (env().i8_width) s->i8_width = env().i8_width;
+    if (env().i8_min_rows) s->i8_min_rows = env().i8_min_rows;
     if (s->has16) {
       HIP_TRY(hipMalloc((void**)&s->dUnsafe, sizeof(unsigned long long)));
       HIP_TRY(hipMemset(s->dUnsafe, 0, sizeof(unsigned long long)));
@@ -2682,10 +2641,7 @@ static int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n, hipStream_t s
     // keeps the row order, for good), or anywhere under an exclusive writer — which re-makes whole tiles, because a
     // rewritten row of an ordered tile no longer sits where its id says.
     uint64_t r8 = row0, e8 = row0 + n;
-    static const bool sort_tiles = [] {
-      const char* g = getenv("EHX_I8_SORT");
-      return g ? atoi(g) != 0 : true;
-    }();
+    const bool sort_tiles = env().i8_sort;
     if (exclusive) {
       {  // searches still in flight on other streams
         int rcw = wait_searches_in_flight(s, st);
@@ -3041,14 +2997,8 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
     // launch reads the query from host-visible memory, scans every row in the oracle's arithmetic, and the last
     // workgroup writes the answer into host-visible memory and raises a flag this thread spins on (k_flat.hip:
     // single_query_kernel).  10 k x 128: ~130 us through the three-launch path -> see DESIGN §e.
-    static const uint64_t one_bytes = [] {
-      const char* e = getenv("EHX_SMALL_EXACT_BYTES");
-      return e ? strtoull(e, nullptr, 10) : (512ull << 20);
-    }();
-    static const bool one_on = [] {
-      const char* e = getenv("EHX_ONE_LAUNCH");
-      return e ? atoi(e) != 0 : true;
-    }();
+    const uint64_t one_bytes = env().small_exact_bytes;
+    const bool one_on = env().one_launch;
     if (one_on && n_queries == 1 && k <= 64 && s->params.mode == EHX_MODE_FLAT && s->scan_sel == EHX_SCAN_AUTO && s->n > 0 &&
         s->ld <= 4096 && (uint64_t)s->n * s->ld * s->esz <= one_bytes) {
       constexpr size_t kOneQ = 16384;   // query slot (ld <= 4096 floats)
@@ -3187,10 +3137,7 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
   // caller's while that one still waits for its verdict, so the scan kernels of consecutive batches run back to back with
   // no host round trip (launches, verdict copy, thread wake-up: ~0.1 ms per batch) between them.  A batch that does lose
   // queries is re-run through the full engine chain under the lock (rare; the chain also adapts the list's length).
-  static const bool pipe_on = [] {
-    const char* e = getenv("EHX_HOST_PIPELINE");
-    return e ? atoi(e) != 0 : true;
-  }();
+  const bool pipe_on = env().host_pipeline;
   bool done = false, have_failed = false;
   std::vector<uint32_t> failed;
   size_t n_short = 0;

@@ -48,6 +48,7 @@
 // of its slowest sibling; the poll is an asynchronous 4-byte global->LDS load issued a revolution before its value
 // is looked at.  The wait is bounded (a sibling that is not resident must not hang the launch).  It removes the
 // re-reads (1.03 x) and costs 60 % of the scan time on the round-4 kernel.
+#include "ehx_env.h"
 #include "ehx_kernels.h"
 #include "k_scan_common.h"
 
@@ -57,23 +58,39 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kThreadsI8 = 512;
 constexpr uint32_t kRingI8 = 4;
 constexpr uint32_t kRowBI8 = 64;                                   // bytes (= k-values) per stage row
-constexpr uint32_t kStageI8 = kTileRows16 * kRowBI8;               // 16 KiB (X and Q alike: 256 rows / queries)
-constexpr uint32_t kXOffI8 = 0;
-constexpr uint32_t kQOffI8 = kRingI8 * kStageI8;                   // 64 KiB
-constexpr uint32_t kStgCap = 128;                                  // staging entries per wave
-constexpr uint32_t kRowpOffI8 = 2 * kRingI8 * kStageI8;            // float4 rowp_lds[3][256]
-constexpr uint32_t kQpOffI8 = kRowpOffI8 + 3 * kTileRows16 * 16;   // float4 qp_lds[256] = (s_q, e_q, gamma_q, thr_q)
-constexpr uint32_t kQinvOffI8 = kQpOffI8 + kTileQ * 16;            // float qinv_lds[256] = (1 - 1e-5) / s_q
-constexpr uint32_t kSyncOffI8 = kQinvOffI8 + kTileQ * 4;           // u32 snapshot[64] of the lock-step counter
-constexpr uint32_t kCtxOffI8 = kSyncOffI8 + 256;                   // I8Ctx: what the (rare) flush path needs
-constexpr uint32_t kStgKeyOffI8 = kCtxOffI8 + 64;                  // u64 stg_key[8][128]
-constexpr uint32_t kStgQlOffI8 = kStgKeyOffI8 + 8 * kStgCap * 8;   // u32 stg_ql[8][128]
-constexpr uint32_t kStgCntOffI8 = kStgQlOffI8 + 8 * kStgCap * 4;   // u32 stg_cnt[8]
-constexpr uint32_t kLdsBytesI8 = kStgCntOffI8 + 64;
-static_assert(kLdsBytesI8 <= 160 * 1024, "LDS budget");
+constexpr uint32_t kStageI8 = kTileRows16 * kRowBI8;               // 16 KiB: one (tile, stage) block in HBM, X and Q alike
+// LDS layout and geometry of one workgroup.  HALF = false: 8 waves, 256 rows x 256 queries (everything above).
+// HALF = true (round 5, short rows): 4 waves — ONE wave per SIMD and workgroup — take one 128-row HALF of every tile of
+// their chunk against the resident query tile; two such workgroups share a CU (<= 80 KiB of LDS each), so one's tile
+// epilogue (vector ALU only) runs beside the other's matrix work instead of all eight waves of a CU leaving the matrix
+// pipe together.
+template <bool HALF>
+struct I8L {
+  static constexpr int kThreads = HALF ? 256 : 512;
+  static constexpr uint32_t kWaves = HALF ? 4 : 8;
+  static constexpr uint32_t kXStage = HALF ? kStageI8 / 2 : kStageI8;  // X bytes of one stage in LDS (128 / 256 rows x 64 B)
+  static constexpr uint32_t kXShift = HALF ? 13 : 14;
+  static constexpr uint32_t kQSlots = HALF ? 2 : kRingI8;             // 16-KiB query stage blocks held in LDS
+  static constexpr uint32_t kStgCap = HALF ? 64 : 128;                // staging entries per wave
+  static constexpr uint32_t kRowpSlot = (HALF ? 128 : 256) * 16;      // row parameters of one (half) tile
+  static constexpr uint32_t kRowpWaves = HALF ? 2 : 4;                // waves that copy a 1-KiB piece of them
+  static constexpr uint32_t kXOff = 0;
+  static constexpr uint32_t kQOff = kRingI8 * kXStage;                // 64 KiB (HALF: 32)
+  static constexpr uint32_t kRowpOff = kQOff + kQSlots * kStageI8;    // float4 rowp_lds[3][256 (128)]
+  static constexpr uint32_t kQpOff = kRowpOff + 3 * kRowpSlot;        // float4 qp_lds[256] = (s_q, e_q, gamma_q, thr_q)
+  static constexpr uint32_t kQinvOff = kQpOff + kTileQ * 16;          // float qinv_lds[256] = (1 - 1e-5) / s_q
+  static constexpr uint32_t kSyncOff = kQinvOff + kTileQ * 4;         // u32 snapshot[64] of the lock-step counter
+  static constexpr uint32_t kCtxOff = kSyncOff + 256;                 // I8Ctx: what the (rare) flush path needs
+  static constexpr uint32_t kStgKeyOff = kCtxOff + 64;                // u64 stg_key[waves][cap]
+  static constexpr uint32_t kStgQlOff = kStgKeyOff + kWaves * kStgCap * 8;  // u32 stg_ql[waves][cap]
+  static constexpr uint32_t kStgCntOff = kStgQlOff + kWaves * kStgCap * 4;  // u32 stg_cnt[8]
+  static constexpr uint32_t kLdsBytes = kStgCntOff + 64;
+};
+static_assert(I8L<false>::kLdsBytes <= 160 * 1024, "LDS budget");
+static_assert(I8L<true>::kLdsBytes <= 80 * 1024, "LDS budget: two half-tile workgroups per CU");
+static_assert(I8L<false>::kQOff == 64 * 1024 && I8L<false>::kRowpOff == 128 * 1024, "layout of the full-tile kernel");
 static_assert(kTileRows16 == 256 && kTileQ == 256, "kernel geometry is hard-wired");
 
 #define EHX_MFMA_I8(A, B, C) __builtin_amdgcn_mfma_i32_16x16x64_i8((A), (B), (C), 0, 0, 0)
@@ -155,15 +172,17 @@ static_assert(sizeof(I8Ctx) <= 64, "I8Ctx slot");
 // Empty this wave's staging buffer into the pools of its queries (wave-uniform call).  Every entry takes one slot
 // of its query's pool with a global atomicAdd; the vmcnt queue is drained before returning, so the caller's counted
 // waits see DMA pieces only.
+template <bool HALF>
 __device__ __attribute__((noinline)) void i8_flush_staging() {
+  using L = I8L<HALF>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const I8Ctx* ctx = (const I8Ctx*)(smem + kCtxOffI8);
+  const I8Ctx* ctx = (const I8Ctx*)(smem + L::kCtxOff);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint64_t* keys = (const uint64_t*)(smem + kStgKeyOffI8) + (size_t)w * kStgCap;
-  const uint32_t* qls = (const uint32_t*)(smem + kStgQlOffI8) + (size_t)w * kStgCap;
-  uint32_t* cnt = (uint32_t*)(smem + kStgCntOffI8) + w;
+  const uint64_t* keys = (const uint64_t*)(smem + L::kStgKeyOff) + (size_t)w * L::kStgCap;
+  const uint32_t* qls = (const uint32_t*)(smem + L::kStgQlOff) + (size_t)w * L::kStgCap;
+  uint32_t* cnt = (uint32_t*)(smem + L::kStgCntOff) + w;
   uint32_t n = *cnt;
-  if (n > kStgCap) n = kStgCap;
+  if (n > L::kStgCap) n = L::kStgCap;
   const uint32_t cap = ctx->pool_cap;
   for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
     uint64_t key = keys[i];
@@ -185,8 +204,10 @@ __device__ __attribute__((noinline)) void i8_flush_staging() {
 // LDS round trip (the row's parameters): the staging buffer belongs to this wave alone, so its fill count lives in a
 // wave-uniform register (stg_n) and the slots are handed out by a ballot and a lane prefix count — round 3 took them
 // with an LDS atomic per key and waited for its return.
+template <bool HALF>
 __device__ __forceinline__ void i8_hit(int v, bool hi, uint32_t r_local, uint32_t tile_row0, uint32_t rp_off,
                                        const float4 qq, int ql, int w, uint32_t n_rows, uint32_t& stg_n) {
+  using L = I8L<HALF>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const float4 P = *(const float4*)(smem + rp_off + r_local * 16u);
   const float S = i8_score(P, qq, v);
@@ -195,17 +216,17 @@ __device__ __forceinline__ void i8_hit(int v, bool hi, uint32_t r_local, uint32_
   const uint64_t m = __ballot(ok);
   if (m == 0ull) return;
   const uint32_t k = (uint32_t)__builtin_popcountll(m);
-  uint32_t* cnt = (uint32_t*)(smem + kStgCntOffI8) + w;
-  if (stg_n + k > kStgCap) {  // (64 lanes, 128 entries: an emptied buffer takes them all)
+  uint32_t* cnt = (uint32_t*)(smem + L::kStgCntOff) + w;
+  if (stg_n + k > L::kStgCap) {  // (64 lanes, at least 64 entries: an emptied buffer takes them all)
     if ((threadIdx.x & 63) == 0) *cnt = stg_n;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    i8_flush_staging();
+    i8_flush_staging<HALF>();
     stg_n = 0u;
   }
   if (ok) {
     const uint32_t pos = stg_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    uint64_t* keys = (uint64_t*)(smem + kStgKeyOffI8) + (size_t)w * kStgCap;
-    uint32_t* qls = (uint32_t*)(smem + kStgQlOffI8) + (size_t)w * kStgCap;
+    uint64_t* keys = (uint64_t*)(smem + L::kStgKeyOff) + (size_t)w * L::kStgCap;
+    uint32_t* qls = (uint32_t*)(smem + L::kStgQlOff) + (size_t)w * L::kStgCap;
     keys[pos] = ((uint64_t)f32_to_ordered(S) << 32) | grow;
     qls[pos] = (uint32_t)ql;
   }
@@ -214,7 +235,7 @@ __device__ __forceinline__ void i8_hit(int v, bool hi, uint32_t r_local, uint32_
 
 }  // namespace
 
-size_t scan_i8_lds_bytes() { return kLdsBytesI8; }
+size_t scan_i8_lds_bytes() { return I8L<false>::kLdsBytes; }
 
 // DUMP: the sample pass — every lower bound of the scanned tiles is written to a.dump[row - tile0*256][q] and
 // sample_select256_kernel turns them into the first thresholds.
@@ -226,35 +247,50 @@ size_t scan_i8_lds_bytes() { return kLdsBytesI8; }
 // registers each; a stage row's 64 bytes are ONE k-step: lane l holds bytes [16 (l >> 4), +16) of row / query l & 15 of
 // its block — one ds_read_b128 per block and stage, twelve per stage as before.  Every block gets exactly one MFMA
 // per stage.  An accumulator block holds, per lane, rows 4 (l >> 4) + 0..3 of its 16 rows for query l & 15.
-template <bool DUMP, bool REV, bool FUSE, bool QRES = false>
-__global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanArgsI8 a) {
+template <bool DUMP, bool REV, bool FUSE, bool QRES = false, bool HALF = false>
+__global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(const ScanArgsI8 a) {
   static_assert(!QRES || (!REV && !FUSE && !DUMP), "QRES: the run-time-slot loop of the plain scan only");
+  static_assert(!HALF || QRES, "HALF: short rows, the query tile resident in LDS");
+  using L = I8L<HALF>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 2, wc = w & 3;
   const int j15 = lane & 15, qd = lane >> 4;
 
-  uint32_t qt, chunk;
+  uint32_t qt, chunk, half = 0u;   // half (HALF): which 128 rows of every tile this workgroup takes
   {
-    const uint32_t b = blockIdx.x;
+    uint32_t b = blockIdx.x;
     if (a.xcd_map) {
-      const uint32_t xcd = b & 7u, slot = b >> 3;
+      const uint32_t xcd = b & 7u;
+      uint32_t slot = b >> 3;
+      if constexpr (HALF) {   // (both halves and every query tile of a chunk on one XCD: they share its L2)
+        half = slot & 1u;
+        slot >>= 1;
+      }
       qt = slot % a.q_tiles;
       chunk = xcd * (a.n_chunks >> 3) + slot / a.q_tiles;
     } else {
+      if constexpr (HALF) {
+        half = b & 1u;
+        b >>= 1;
+      }
       qt = b % a.q_tiles;
       chunk = b / a.q_tiles;
     }
+    half = (uint32_t)__builtin_amdgcn_readfirstlane((int)half);
     // (a division by a run-time value goes through the vector ALU: without this the tile range, the loop bound and the
     // DMA sources derived from it would live in vector registers — and, this kernel being out of them, in scratch)
     qt = (uint32_t)__builtin_amdgcn_readfirstlane((int)qt);
     chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
   }
-  float4* qp_lds = (float4*)(smem + kQpOffI8);
-  float* qinv_lds = (float*)(smem + kQinvOffI8);
-  const volatile uint32_t* sync_lds = (const volatile uint32_t*)(smem + kSyncOffI8);
+  // wave (wr, wc) takes rows [128 wr, +128) x queries [64 wc, +64) of the tile; HALF: the workgroup's four waves are the
+  // four wc of row half wr = half
+  const int wr = HALF ? (int)half : (w >> 2), wc = w & 3;
+  const uint32_t lrow0 = HALF ? 0u : (uint32_t)wr * 128u;   // the wave's first row inside the X stage / row-parameter block in LDS
+  float4* qp_lds = (float4*)(smem + L::kQpOff);
+  float* qinv_lds = (float*)(smem + L::kQinvOff);
+  const volatile uint32_t* sync_lds = (const volatile uint32_t*)(smem + L::kSyncOff);
 
   if (tid < (int)kTileQ) {  // query parameters and this pass's threshold, once per workgroup
     const size_t qg = (size_t)qt * kTileQ + tid;
@@ -265,10 +301,10 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     // S_lower does not depend on I and nothing can alarm
     qinv_lds[tid] = qp.x > 0.0f ? (1.0f - 1e-5f) / qp.x : __builtin_inff();
   }
-  if (tid < 64) ((uint32_t*)(smem + kSyncOffI8))[tid] = 0u;
-  if (tid < 8) ((uint32_t*)(smem + kStgCntOffI8))[tid] = 0u;
+  if (tid < 64) ((uint32_t*)(smem + L::kSyncOff))[tid] = 0u;
+  if (tid < 8) ((uint32_t*)(smem + L::kStgCntOff))[tid] = 0u;
   if (tid == 0) {
-    I8Ctx* ctx = (I8Ctx*)(smem + kCtxOffI8);
+    I8Ctx* ctx = (I8Ctx*)(smem + L::kCtxOff);
     ctx->pool = a.pool;
     ctx->pool_cnt = a.pool_cnt;
     ctx->ovf = a.ovf;
@@ -292,15 +328,19 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   // copies: the blocks are stored in HBM in the LDS image, scan8_index); waves 0..3 also one piece each of the
   // tile's row parameters (256 x 16 B), once per tile.  Sources are uniform pointers advanced one block per stage.
   const uint32_t voff = (uint32_t)lane * 16u;
-  const uint32_t voff8 = voff + 8u * 1024u;
+  const uint32_t voff8 = voff + L::kXStage / 2;   // the wave's second piece of a stage: 8 (HALF: 4) KiB further on
   const size_t tile_bytes = (size_t)ktiles * kStageI8;
-  const char* xsrc = (const char*)a.X + (size_t)tile_begin * tile_bytes + (size_t)w * 1024;
+  // (HALF: rows [128 half, +128) of a stage block are its bytes [8192 half, +8192) — the LDS image is row-major)
+  const char* xsrc = (const char*)a.X + (size_t)tile_begin * tile_bytes + (size_t)half * L::kXStage * (HALF ? 1u : 0u) +
+                     (size_t)w * 1024;
   const char* qbase = (const char*)a.Q + (size_t)qt * ((size_t)(ktiles + 3) * kStageI8) + (size_t)w * 1024;
   const char* qsrc = qbase;
-  const char* rsrc = (const char*)(a.rowp + (size_t)tile_begin * kTileRows16) + (size_t)(w & 3) * 1024;
-  const uint32_t xdst = kXOffI8 + (uint32_t)w * 1024u;  // + slot*16384 (+8192 for the second piece)
-  const uint32_t qdst = kQOffI8 + (uint32_t)w * 1024u;
-  const uint32_t rdst = kRowpOffI8 + (uint32_t)(w & 3) * 1024u;  // + (tile % 3)*4096
+  const uint32_t rpiece = (uint32_t)w & (L::kRowpWaves - 1u);
+  const char* rsrc = (const char*)(a.rowp + (size_t)tile_begin * kTileRows16 + (HALF ? (size_t)half * 128u : 0u)) +
+                     (size_t)rpiece * 1024;
+  const uint32_t xdst = L::kXOff + (uint32_t)w * 1024u;  // + slot * kXStage (+ kXStage / 2 for the second piece)
+  const uint32_t qdst = L::kQOff + (uint32_t)w * 1024u;
+  const uint32_t rdst = L::kRowpOff + rpiece * 1024u;  // + (tile % 3) * kRowpSlot
 
 #define EHX_DMA(DST_BASE, DST_IMM, VOFF, SRC)                                                              \
   do {                                                                                                     \
@@ -318,12 +358,12 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
                  : "s"(DST), "v"(VOFF), "s"(SRC)                                         \
                  : "memory");                                                            \
   } while (0)
-#define EHX_DMA_X0(SLOT) EHX_DMA(xdst, (SLOT) * 16384, voff, xsrc)
+#define EHX_DMA_X0(SLOT) EHX_DMA(xdst, (SLOT) * L::kXStage, voff, xsrc)
 #define EHX_DMA_Q0(SLOT) EHX_DMA(qdst, (SLOT) * 16384, voff, qsrc)
-#define EHX_DMA_X1(SLOT) EHX_DMA(xdst, (SLOT) * 16384 + 8192, voff8, xsrc)
+#define EHX_DMA_X1(SLOT) EHX_DMA(xdst, (SLOT) * L::kXStage + L::kXStage / 2, voff8, xsrc)
 #define EHX_DMA_Q1(SLOT)                               \
   do {                                                 \
-    EHX_DMA(qdst, (SLOT) * 16384 + 8192, voff8, qsrc); \
+    EHX_DMA(qdst, (SLOT) * 16384 + 8192, voff8, qsrc); /* (full-tile kernel only: voff8 = voff + 8192) */ \
     xsrc += kStageI8;                                  \
     qsrc += kStageI8;                                  \
   } while (0)
@@ -332,8 +372,8 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   // assignment of k to lanes is fine as long as rows and queries use the same one); the chunk's physical place is
   // swizzled by the row (scan8_swz) so that the four 16-lane groups a ds_read_b128 is served in hit 16 different slots
   const uint32_t sw = scan8_swz((uint32_t)j15);
-  uint32_t a_off = kXOffI8 + (uint32_t)(wr * 128 + j15) * kRowBI8 + (((uint32_t)qd) ^ sw) * 16u;  // + rb*1024
-  uint32_t b_off = kQOffI8 + (uint32_t)(wc * 64 + j15) * kRowBI8 + (((uint32_t)qd) ^ sw) * 16u;   // + cb*1024
+  uint32_t a_off = L::kXOff + (lrow0 + (uint32_t)j15) * kRowBI8 + (((uint32_t)qd) ^ sw) * 16u;  // + rb*1024
+  uint32_t b_off = L::kQOff + (uint32_t)(wc * 64 + j15) * kRowBI8 + (((uint32_t)qd) ^ sw) * 16u;   // + cb*1024
   // (opaque to the compiler: it would fold kQOffI8 = 64 KiB into every read's constant, find that the sum no longer
   // fits the instruction's 16-bit offset field, and keep one address register per (ring slot, block) — 24 registers
   // spilled to scratch, whose reloads sit in the stage loop behind s_waitcnt vmcnt(0).  As two opaque bases every
@@ -375,8 +415,10 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   // =============================== tile epilogue ===============================
   auto epilogue = [&](uint32_t t) {
     const uint32_t tile = tile_begin + t;
-    const uint32_t tile_row0 = tile * kTileRows16;
-    const uint32_t rp_off = kRowpOffI8 + rp_slot * 4096u;  // this tile's row parameters in LDS
+    // (HALF: "the tile" of this workgroup is rows [128 half, +128) of it — row parameters, positions and lane rows are
+    // counted from there)
+    const uint32_t tile_row0 = tile * kTileRows16 + (HALF ? half * 128u : 0u);
+    const uint32_t rp_off = L::kRowpOff + rp_slot * L::kRowpSlot;  // this (half) tile's row parameters in LDS
     const float4* rp = (const float4*)(smem + rp_off);
     // (the lane's coordinates are derived afresh, behind an opaque copy of the lane id: left to itself the compiler
     // keeps a dozen epilogue addresses alive across the stage loop, which has no registers to spare)
@@ -384,7 +426,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     asm volatile("" : "+v"(lane_e));
     const int j15 = lane_e & 15, qd = lane_e >> 4;
     const int col0 = wc * 64 + j15;                          // + 16 cb: this lane's four queries
-    const uint32_t rbase = (uint32_t)(wr * 128) + 4u * (uint32_t)qd;  // + 16 rb + r: this lane's 32 rows
+    const uint32_t rbase = lrow0 + 4u * (uint32_t)qd;  // + 16 rb + r: this lane's 32 rows
     if (DUMP) {
       const size_t q_rows = (size_t)a.q_tiles * kTileQ;
       float* const o0 = a.dump + (size_t)(tile_row0 - a.tile0 * kTileRows16 + rbase) * q_rows + (size_t)qt * kTileQ + col0;
@@ -474,7 +516,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
           v = r == 0 ? c4[0] : (r == 1 ? c4[1] : (r == 2 ? c4[2] : c4[3]));
           r_local = rbase + 16u * (uint32_t)(b >> 2) + (uint32_t)r;
         }
-        i8_hit(v, hi, r_local, tile_row0, rp_off, qq, ql, w, a.n, stg_n);
+        i8_hit<HALF>(v, hi, r_local, tile_row0, rp_off, qq, ql, w, a.n, stg_n);
       }
     }
   };
@@ -491,11 +533,11 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   // named statically, no select over the eight row blocks).  Same alarms, same hits; only the order in which a wave
   // stages them differs (pools are sets).  Only row block 0's test and the levels remain outside the MFMA stream.
   int ti4[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};  // (no tile waiting: nothing alarms)
-  uint32_t epi_tile_row0 = 0u, epi_rp_off = kRowpOffI8;
+  uint32_t epi_tile_row0 = 0u, epi_rp_off = L::kRowpOff;
   bool epi_al = false;
   auto epi_levels = [&](uint32_t t) {  // tile t is complete; its parameters are tp_cur / tg_cur, its rows' in rp_slot
     epi_tile_row0 = (tile_begin + t) * kTileRows16;
-    epi_rp_off = kRowpOffI8 + rp_slot * 4096u;
+    epi_rp_off = L::kRowpOff + rp_slot * L::kRowpSlot;
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int j15 = lane_e & 15, qd = lane_e >> 4;
@@ -549,7 +591,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       }
       const int ql = (int)(cbv * 16u) + j15;
       const float4 qq = qp_lds[wc * 64 + ql];
-      i8_hit(v, hi, rbase + r, epi_tile_row0, epi_rp_off, qq, ql, w, a.n, stg_n);
+      i8_hit<HALF>(v, hi, rbase + r, epi_tile_row0, epi_rp_off, qq, ql, w, a.n, stg_n);
     }
   };
 #if EHX_I8_ABL & 1
@@ -588,14 +630,14 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   uint32_t* const sync_ctr = (a.sync && a.xcd_map && a.q_tiles > 1 && (!sync_by_tile || (REV && a.q_tiles <= 4)))
                                  ? a.sync + (sync_by_tile ? chunk * 4u : chunk)
                                  : nullptr;
-  bool sync_on = sync_ctr != nullptr && !DUMP;
-  uint32_t sync_m0 = kSyncOffI8;
+  bool sync_on = sync_ctr != nullptr && !DUMP && !HALF;
+  uint32_t sync_m0 = L::kSyncOff;
   uint32_t sync_voff = 0u;
 
   __syncthreads();  // state init visible
   if (my_tiles > 0) {  // (a chunk past the end of the pass has nothing to scan and must not touch memory)
   // ---- prologue: row parameters of tile 0, stages 0..2 into ring slots 0..2 ----
-  if (w < 4) EHX_DMA(rdst, 0, voff, rsrc);
+  if (w < (int)L::kRowpWaves) EHX_DMA(rdst, 0, voff, rsrc);
   // QRES (short rows: a tile is at most four stages, ld <= 256): the query tile's stage blocks — the same for every
   // row tile — are copied ONCE into the four slots of the Q ring and stay there; a stage then copies its two X pieces
   // per wave only (half the DMA instructions, half the L2 -> LDS bytes), and the query fragments of stage ks of a
@@ -604,11 +646,13 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   if constexpr (QRES) {
     for (uint32_t ks = 0; ks < ktiles; ++ks) {
       const uint32_t qd0 = qdst + (ks << 14);
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(qd0), "v"(voff), "s"(qsrc) : "memory");
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                   :
-                   : "s"(qd0 + 8192u), "v"(voff8), "s"(qsrc)
-                   : "memory");
+      // the 16 1-KiB pieces of a query stage block: two per wave (pieces w, w + 8), HALF: four (w, w + 4, w + 8, w + 12)
+      constexpr uint32_t kQStep = HALF ? 4096u : 8192u;
+#pragma unroll
+      for (uint32_t pc = 0; pc < 16u / L::kWaves; ++pc) {
+        const uint32_t qdp = qd0 + pc * kQStep, vo = voff + pc * kQStep;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(qdp), "v"(vo), "s"(qsrc) : "memory");
+      }
       qsrc += kStageI8;
     }
     EHX_DMA_X0(0); EHX_DMA_X1(0); xsrc += kStageI8;
@@ -787,7 +831,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     const uint32_t kquads = ktiles >> 2;
     // row parameters of tile 1 (consumed by its epilogue, a whole tile from now)
     rsrc += kTileRows16 * 16;
-    if (w < 4) EHX_DMA(rdst, 4096, voff, rsrc);
+    if (w < (int)L::kRowpWaves) EHX_DMA(rdst, L::kRowpSlot, voff, rsrc);
     uint32_t q = 0;
     // Lock-step by TILE (round 5; a.sync_tol = the tolerance in tiles): each of the chunk's query-tile workgroups
     // publishes how many tiles it has completed in a word of its own (a plain store: no read-modify-write, no return
@@ -885,8 +929,8 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       // tile t+2 goes to the slot tile t-1 used: every wave left that epilogue long ago
       const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 2) % 3 == (t - 1) % 3
       rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
-      if (w < 4) {
-        const uint32_t rd = rdst + rp_next * 4096u;
+      if (w < (int)L::kRowpWaves) {
+        const uint32_t rd = rdst + rp_next * L::kRowpSlot;
         EHX_DMA(rd, 0, voff, rsrc);
       }
     }
@@ -900,7 +944,7 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     const uint32_t total_stages = my_tiles * ktiles;
     // row parameters of tile 1 (consumed by its epilogue, a whole tile from now)
     rsrc += kTileRows16 * 16;
-    if (w < 4) EHX_DMA(rdst, 4096, voff, rsrc);
+    if (w < (int)L::kRowpWaves) EHX_DMA(rdst, L::kRowpSlot, voff, rsrc);
     uint32_t ks = 0, t = 0, slot = 0;
     // (FUSE needs tiles of two stages or more — the launcher sees to it: the row parameters of the tile after next are
     // copied over the previous tile's at the end of a tile, and only a later stage barrier of the same tile guarantees
@@ -909,12 +953,12 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
     // one stage whose ring slot is a run-time value: STAGE is the stage body to use (first stage of a tile or not)
 #define EHX_RT_DX0 EHX_SDMA(dx0, voff, xsrc)
 #define EHX_RT_DQ0 do { if constexpr (!QRES) EHX_SDMA(dq0, voff, qsrc); } while (0)
-#define EHX_RT_DX1 EHX_SDMA(dx0 + 8192u, voff8, xsrc)
+#define EHX_RT_DX1 EHX_SDMA(dx0 + L::kXStage / 2, voff8, xsrc)
 #define EHX_RT_DQ1 do { if constexpr (!QRES) EHX_SDMA(dq0 + 8192u, voff8, qsrc); } while (0)
   // (QRES: the next stage's query fragments come from the resident slot of ITS index inside its tile)
 #define EHX_RT_STAGE(STAGE)                                                                  \
   do {                                                                                       \
-    const uint32_t sn = ((slot + 1u) & 3u) << 14, sd = ((slot + 3u) & 3u) << 14;             \
+    const uint32_t sn = ((slot + 1u) & 3u) << L::kXShift, sd = ((slot + 3u) & 3u) << L::kXShift; \
     const uint32_t dx0 = xdst + sd, dq0 = qdst + sd;                                         \
     const uint32_t ksn_ = ks + 1u == ktiles ? 0u : ks + 1u;                                  \
     const uint32_t an_ = a_off + sn, bn_ = b_off + (QRES ? (ksn_ << 14) : sn);               \
@@ -967,8 +1011,8 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
       // tile t+1 (counting the new t) goes to the slot tile t-2 used: every wave left that epilogue long ago
       const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 1) % 3 == (t - 2) % 3
       rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
-      if (w < 4) {
-        const uint32_t rd = rdst + rp_next * 4096u;
+      if (w < (int)L::kRowpWaves) {
+        const uint32_t rd = rdst + rp_next * L::kRowpSlot;
         EHX_DMA(rd, 0, voff, rsrc);
       }
     };
@@ -1032,9 +1076,9 @@ __global__ __launch_bounds__(kThreadsI8, 2) void flat_scan_i8_kernel(const ScanA
   // ---- final: what is left in this wave's staging buffer goes to the pools ----
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   if (DUMP) return;
-  if (lane == 0) ((uint32_t*)(smem + kStgCntOffI8))[w] = stg_n;
+  if (lane == 0) ((uint32_t*)(smem + L::kStgCntOff))[w] = stg_n;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  i8_flush_staging();
+  i8_flush_staging<HALF>();
 }
 
 hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st) {
@@ -1042,22 +1086,20 @@ hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st) {
   const void* fns[] = {(const void*)flat_scan_i8_kernel<false, true, false>, (const void*)flat_scan_i8_kernel<false, false, false>,
                        (const void*)flat_scan_i8_kernel<true, true, false>, (const void*)flat_scan_i8_kernel<true, false, false>,
                        (const void*)flat_scan_i8_kernel<false, false, false, true>,
+                       (const void*)flat_scan_i8_kernel<false, false, false, true, true>,
 #if EHX_I8_FUSED
                        (const void*)flat_scan_i8_kernel<false, true, true>, (const void*)flat_scan_i8_kernel<false, false, true>,
 #endif
   };
-  if (hipError_t e = attr.ensure(fns, (int)(sizeof(fns) / sizeof(fns[0])), kLdsBytesI8); e != hipSuccess) return e;
+  if (hipError_t e = attr.ensure(fns, (int)(sizeof(fns) / sizeof(fns[0])), I8L<false>::kLdsBytes); e != hipSuccess) return e;
   if (a.ld == 0 || a.ld % kRowBI8) return hipErrorInvalidValue;
   const uint32_t grid = a.q_tiles * a.n_chunks;
   const bool rev = a.ld % (4 * kRowBI8) == 0;  // whole ring revolutions per tile: the compile-time-slot loop
 #define EHX_LAUNCH_I8(D, R, F) \
-  hipLaunchKernelGGL((flat_scan_i8_kernel<D, R, F>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a)
+  hipLaunchKernelGGL((flat_scan_i8_kernel<D, R, F>), dim3(grid), dim3(I8L<false>::kThreads), I8L<false>::kLdsBytes, st, a)
 #if EHX_I8_FUSED
   // the epilogue inside the next tile's first stage: tiles of at least two stages (see the kernel), never the sample pass
-  static const bool fused_on = [] {
-    const char* e = getenv("EHX_I8_FUSED");
-    return !(e && atoi(e) == 0);
-  }();
+  const bool fused_on = env().i8_fused;
   if (fused_on && !a.dump && a.ld >= 2 * kRowBI8) {
     if (rev) EHX_LAUNCH_I8(false, true, true);
     else EHX_LAUNCH_I8(false, false, true);
@@ -1065,17 +1107,19 @@ hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st) {
   }
 #endif
   // short rows (a tile of at most four stages): the query tile resident in LDS (QRES in the kernel); EHX_I8_QRES=0: off
-  static const bool qres_on = [] {
-    const char* e = getenv("EHX_I8_QRES");
-    return !(e && atoi(e) == 0);
-  }();
+  const bool qres_on = env().i8_qres;
   if (a.dump) {
     if (rev) EHX_LAUNCH_I8(true, true, false);
     else EHX_LAUNCH_I8(true, false, false);
   } else {
+    // short rows of at most two stages: two half-tile workgroups per CU (HALF in the kernel); EHX_I8_HALF=0: off
+    const bool half_on = env().i8_half;
     if (rev) EHX_LAUNCH_I8(false, true, false);
+    else if (qres_on && half_on && a.ld <= 2 * kRowBI8)
+      hipLaunchKernelGGL((flat_scan_i8_kernel<false, false, false, true, true>), dim3(2 * grid), dim3(I8L<true>::kThreads),
+                         I8L<true>::kLdsBytes, st, a);
     else if (qres_on && a.ld <= 4 * kRowBI8)
-      hipLaunchKernelGGL((flat_scan_i8_kernel<false, false, false, true>), dim3(grid), dim3(kThreadsI8), kLdsBytesI8, st, a);
+      hipLaunchKernelGGL((flat_scan_i8_kernel<false, false, false, true>), dim3(grid), dim3(I8L<false>::kThreads), I8L<false>::kLdsBytes, st, a);
     else EHX_LAUNCH_I8(false, false, false);
   }
 #undef EHX_LAUNCH_I8

@@ -28,6 +28,7 @@
 //     words when it is done — a few thousand stores instead of a 1.3-GB memset per batch (a query that outgrows
 //     its log clears its whole bitmap instead);
 //   * work counters as SURVEY §8d: n_dist = rows actually fetched, n_hops0 / n_hops_up = expansions.
+#include "ehx_env.h"
 #include "ehx_kernels.h"
 
 namespace ehx {
@@ -525,10 +526,7 @@ hipError_t launch_graph_search(const GraphArgs& a, hipStream_t st) {
   // shorten them: at 3-KB rows the kernel already moves 4.7-5.1 TB/s of RANDOM rows, 80-86 % of what the part delivers
   // for that access pattern with every SIMD full of gather waves (scripts/ubench/gather_rows.hip: 5.9 TB/s) — the row
   // phase is bound by the memory system, not by how many loads one wave keeps in flight.
-  static const int helper_env = [] {
-    const char* e = getenv("EHX_GRAPH_HELPER");
-    return e ? atoi(e) : 0;
-  }();
+  const int helper_env = env().graph_helper;
   const bool pairable = a.dims <= 256 && (a.dims == 32 || a.dims == 64 || a.dims == 96 || a.dims == 128 || a.dims == 192 || a.dims == 256);
   const bool helper = helper_env != 0 && !pairable && a.nq <= 2048;
   if (helper) {

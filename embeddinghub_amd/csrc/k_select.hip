@@ -4,6 +4,7 @@
 //   select256_kernel         a pass's pool (unsorted) merged into the query's running best 256; publishes the
 //                            k'-th best score as the next pass's threshold
 //   rerank256_kernel         canonical (oracle-order) fp32 distances of the k' best lower bounds, top-k, certificate
+#include "ehx_env.h"
 #include "ehx_kernels.h"
 
 namespace ehx {
@@ -515,10 +516,7 @@ hipError_t launch_rerank256(const Rerank256Args& a, hipStream_t st) {
   }
   const size_t qbytes = (size_t)a.ld * sizeof(float);
   const uint32_t in_lds = qbytes <= 32 * 1024 ? 1u : 0u;  // (very long rows: the query stays in global memory)
-  static const bool allow_staged = [] {
-    const char* e = getenv("EHX_RERANK_STAGED");  // "0": every lane walks its own row (A/B runs)
-    return e ? atoi(e) != 0 : true;
-  }();
+  const bool allow_staged = env().rerank_staged;  // (EHX_RERANK_STAGED=0: every lane walks its own row, A/B runs)
   const uint32_t staged = (allow_staged && in_lds && (a.dims & 31u) == 0 && a.dims >= 32) ? 1u : 0u;
   const size_t lds = (in_lds ? qbytes : 0) + (staged ? kStageFloat4 * sizeof(float4) : 0);
 #define EHX_RR(M, S)                                                                                              \

@@ -28,6 +28,7 @@ ap.add_argument("--graph-rows", type=int, default=0)
 ap.add_argument("--gauss", action="store_true", help="isotropic rows instead (control)")
 ap.add_argument("--label", default="")
 ap.add_argument("--own-first", action="store_true", help="first phase on the stream of its own instead of the NULL stream")
+ap.add_argument("--device-queries", action="store_true", help="query batches generated on the device (no pageable upload)")
 ap.add_argument("--sleep", type=float, default=0.0, help="seconds between the end of the build and the first search")
 args = ap.parse_args()
 n2, d, R, B, k, chunk = args.rows, args.dims, args.R, 1024, 10, 65536
@@ -59,8 +60,14 @@ for i0 in range(0, n2, chunk):
     flat.set_batch(keys, X)
 nb = args.batches
 sq = torch.empty((nb, B, d), dtype=torch.float32, device="cuda")
-for i in range(nb):
-    sq[i].copy_(torch.from_numpy(manifold(ehx.SEED_QUERY + 1000 + i, B)))
+if args.device_queries:
+    import ctypes as C
+    from embeddinghub_amd import _lib
+    for i in range(nb):
+        _lib.check(_lib.load().ehx_gen_rows_device(C.c_void_p(0), ehx.SEED_QUERY, i * B, B, d, 1, C.c_void_p(sq[i].data_ptr())))
+else:
+    for i in range(nb):
+        sq[i].copy_(torch.from_numpy(manifold(ehx.SEED_QUERY + 1000 + i, B)))
 torch.cuda.synchronize()
 ti = torch.empty((B, k), dtype=torch.int64, device="cuda")
 td = torch.empty((B, k), dtype=torch.float32, device="cuda")
