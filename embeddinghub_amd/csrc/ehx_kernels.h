@@ -1,4 +1,4 @@
-// Internal launch interface between the C-ABI host code (ehx_api.cpp) and the gfx950 kernels.
+// Internal launch interface between the C-ABI host code (ehx_*.cpp) and the gfx950 kernels.
 // Not part of the public boundary (include/ehx.h is).
 #pragma once
 
@@ -585,7 +585,7 @@ inline float scan16_eps(uint32_t dims) { return 1.0e-3f + 2.0e-7f * (float)dims;
 constexpr uint32_t kPoolCap = 4096;    // candidate keys one query can collect in one pass (overflow: query flagged)
 constexpr uint32_t kSyncWordsI8 = 1024; // lock-step progress words of the int8 scan: [n_chunks <= 256][4 query tiles]
 constexpr uint32_t kMerged8 = 256;     // default width of the running best list of the int8 pipeline
-constexpr uint32_t kMerged8Max = 1024; // widest list (a space widens its list when queries go uncertified: ehx_api.cpp)
+constexpr uint32_t kMerged8Max = 1024; // widest list (a space widens its list when queries go uncertified: ehx_flat.cpp)
 struct ScanArgsI8 {
   const int8_t* Q;        // [q_tiles][ld/64 + 3][256][64] int8 query tiles, scan8 stage-blocked layout
   const int8_t* X;        // scan copy, scan8_index layout; cap % 256 == 0

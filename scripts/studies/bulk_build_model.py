@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CPU study: what does the engine's BULK graph build (rounds of rows that do not see each other; ehx_api.cpp
+"""CPU study: what does the engine's BULK graph build (rounds of rows that do not see each other; ehx_graph.cpp
 graph_insert, k_insert.hip) cost in recall against hnswlib's sequential build, at equal ef?
 
 The oracle carries a CPU MODEL of the bulk build (oracle/hnsw_oracle.hpp addPointsRounds: the same round sizes, searches

@@ -156,7 +156,7 @@ def test_batched_gpu_build_recall_parity_with_oracle():
 
 
 def test_bulk_build_gives_its_scratch_back_and_the_space_keeps_working():
-    """A bulk build releases its per-insertion visited bitmaps and link scratch when it returns (ehx_api.cpp
+    """A bulk build releases its per-insertion visited bitmaps and link scratch when it returns (ehx_graph.cpp
     graph_insert: from 1 GiB on by default — 5 GB at 10 M rows; EHX_BUILD_SCRATCH_KEEP=0 forces it here).  Afterwards:
     searches allocate their own bitmaps, a second bulk Set allocates fresh scratch, sequential Sets and updates work —
     and every answer equals that of a space that kept its scratch (the library reads the variable once per process, so
