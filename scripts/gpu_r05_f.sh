@@ -7,6 +7,15 @@ mkdir -p gpurun_out
 O=gpurun_out
 OUT=$O/r05_f_cascade.jsonl
 : > $OUT
+# the stall of sessions c-h = the cgroup's CPU quota (numpy's BLAS threads burn it): the counters, and the cure
+cat /sys/fs/cgroup/cpu.max 2>/dev/null; nproc
+for bt in "" 8; do
+  SFM_BLAS_THREADS=$bt timeout 200 python scripts/studies/structured_flat_mode.py --graph-rows 16384 --batches 30 --label "blas threads '$bt'" 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    r = json.loads(l); print(r['label'], '|', r['phase'], '| qps', r['qps'], 'slowest', r['slowest_call_ms_then_sync_ms'], 'throttled (times, ms)', r['cgroup_throttled_times_ms'])
+" | tee -a $O/r05_f_throttle.txt
+done
 # parity of the round's kernel changes first (half-tile workgroups for d <= 128, lock-step by tile): a fast wrong kernel is not done
 timeout 900 python -m pytest tests/test_i8_filter.py tests/test_structured_rows.py tests/test_fuzz_parity.py -x -q -m gpu 2>&1 | tail -6 | tee $O/r05_f_pytest_tail.txt
 one() {  # rows dims metric first growth keys

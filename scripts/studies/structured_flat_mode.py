@@ -46,6 +46,11 @@ def manifold(seed, rows):
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
+if os.environ.get("SFM_BLAS_THREADS"):   # cap numpy's BLAS pool (default: one spinning thread per visible core)
+    from threadpoolctl import threadpool_limits
+    threadpool_limits(limits=int(os.environ["SFM_BLAS_THREADS"]))
+
+
 flat = ehx.Space.unique("sfm-flat", d, metric=ehx.METRIC_COSINE, initial_capacity=n2)
 g = None
 if args.graph_rows:
@@ -75,7 +80,16 @@ tc = torch.empty((B,), dtype=torch.int32, device="cuda")
 own = torch.cuda.Stream()
 
 
+def throttled():
+    try:
+        kv = dict(l.split()[:2] for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(kv["nr_throttled"]), int(kv["throttled_usec"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def phase(name, stream_handle, sync):
+    thr0 = throttled()
     for _ in range(3):
         flat.knn_device(sq[0], k, ti, td, tc, stream=stream_handle)
         sync()
@@ -90,7 +104,9 @@ def phase(name, stream_handle, sync):
         per.append((round((t1 - t0) * 1e3, 3), round((time.perf_counter() - t1) * 1e3, 3)))
     wall = time.perf_counter() - t00
     st = flat.stats()
-    print(json.dumps({"label": args.label, "phase": name, "qps": round(nb * B / wall, 1), "wall_ms_per_batch": round(wall / nb * 1e3, 3),
+    thr1 = throttled()
+    print(json.dumps({"cgroup_throttled_times_ms": None if thr0 is None or thr1 is None else [thr1[0] - thr0[0], round((thr1[1] - thr0[1]) / 1e3, 1)],
+                      "label": args.label, "phase": name, "qps": round(nb * B / wall, 1), "wall_ms_per_batch": round(wall / nb * 1e3, 3),
                       "scan_ms_mean": round(st["scan_ms_mean"], 4), "last_scan_ms": round(st["last_scan_ms"], 4),
                       "last_total_ms": round(st["last_total_ms"], 4), "fallbacks": int(st["n_i8_fallback"] + st["n_filter_fallback"]),
                       "call_ms_then_sync_ms": per[:6], "slowest_call": max(range(nb), key=lambda i: per[i][0] + per[i][1]),
