@@ -375,8 +375,12 @@ int graph_update(ehx_space* s, uint32_t id) {
 }
 
 // graph pipeline: prepared queries -> zero visited bitmaps -> one-wave-per-query search
+// `one` (optional): ONE query per call in ONE launch — the raw query sits in host-visible memory (one->q_host), the
+// kernel prepares it itself, writes ids / distances / count into host-visible memory (d_ids / d_dist / d_count then point
+// there) and publishes one->seq in one->done_flag; no prepare launch, no timing events (nothing between the host's
+// launch and the wave's first instruction but the runtime).
 int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k, uint64_t* d_ids,
-                     float* d_dist, uint32_t* d_count) {
+                     float* d_dist, uint32_t* d_count, const GraphOneLaunch* one) {
   if (s->poisoned.load())
     return fail(EHX_EINTERNAL, "graph space: an in-place overwrite failed half way (rows left in raw order); drop and rebuild it");
   if (s->g_n != s->n)
@@ -399,8 +403,10 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   // when the query clears its words — ~27 ef of them.  6.25 M x 128: ef 50 log 0.41 / memset 0.47 ms, ef 200 1.11 /
   // 1.11, ef 800 4.27 / 3.89; 2 M x 768: ef 100 2.06 / 2.05, ef 400 6.99 / 6.81; small bitmaps (1 M x 128): the
   // memset is nearly free.  Hence: the log when the bitmaps are large AND the index has more than 32 000 rows per ef.
-  const bool log_now = use_vislog && (size_t)nq * vis_words * sizeof(uint32_t) >= (192u << 20) &&
-                       s->n >= (uint64_t)32000 * ef;
+  // (one launch: always the log — the wave clears the handful of words it marked; a memset would be a second command)
+  const bool log_now = one ? true
+                           : use_vislog && (size_t)nq * vis_words * sizeof(uint32_t) >= (192u << 20) &&
+                                 s->n >= (uint64_t)32000 * ef;
   const uint32_t vislog_cap = log_now ? 48u * ef + 256u : 0u;
   if ((rc = s->dInsVislog.ensure((size_t)nq * (vislog_cap ? vislog_cap : 1u)))) return rc;
   if (!s->dGraphCounters) {
@@ -411,8 +417,10 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
     int rcw = wait_searches_in_flight(s, st);
     if (rcw) return rcw;
   }
-  HIP_TRY(hipEventRecord(s->ev[0], st));
-  HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, q_rows, s->metric, s->dQ.p, st));
+  if (!one) {
+    HIP_TRY(hipEventRecord(s->ev[0], st));
+    HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, q_rows, s->metric, s->dQ.p, st));
+  }
   GraphArgs a;
   a.Q = s->dQ.p;
   a.X = (s->x_half || s->x_perm) ? nullptr : s->xf32();  // (graph kernels read the search copy; X: fp32 ablation builds only)
@@ -442,6 +450,16 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   a.entry_point = s->g_entry;
   a.max_level = s->g_maxlevel;
   a.metric = s->metric;
+  if (one) {
+    a.q_raw = one->q_host;
+    a.done_flag = one->done_flag;
+    a.seq = one->seq;
+    if (s->vis_dirty) HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, s->dVisited.n * sizeof(uint32_t), st));
+    s->vis_dirty = false;
+    HIP_TRY(launch_graph_search(a, st));
+    s->n_queries += nq;
+    return EHX_OK;
+  }
   hipEvent_t* pr = s->ring[s->ring_count % ehx_space::kRing];
   HIP_TRY(hipEventRecord(s->ev[1], st));
   HIP_TRY(hipEventRecord(pr[0], st));

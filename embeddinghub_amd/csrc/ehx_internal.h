@@ -566,8 +566,13 @@ int graph_ensure_arrays(ehx_space* s);
 int graph_ensure_lists(ehx_space* s, uint64_t lists);
 int graph_insert(ehx_space* s, uint64_t id0, uint64_t count, uint32_t batch);
 int graph_update(ehx_space* s, uint32_t id);
+struct GraphOneLaunch {   // one query per call in one launch (knn_graph_locked)
+  const float* q_host;     // the raw query, host-visible
+  uint32_t* done_flag;     // host-visible; the kernel stores `seq` there when the results are written
+  uint32_t seq;
+};
 int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k, uint64_t* d_ids,
-                     float* d_dist, uint32_t* d_count);
+                     float* d_dist, uint32_t* d_count, const GraphOneLaunch* one = nullptr);
 
 // ---- ehx_flat.cpp ----
 int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, uint32_t k, uint64_t* d_ids,

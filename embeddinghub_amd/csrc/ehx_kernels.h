@@ -815,6 +815,12 @@ struct GraphArgs {
   unsigned long long* counters;  // [kGraphCounters]
   uint32_t nq, k, ef, ef_cap, n, dims, ld, M, M0, vis_words, entry_point;
   int max_level, metric;
+  // One query per call in ONE launch (round 5; the reference's request shape, server.cc:172-210): q_raw != nullptr — the
+  // raw query is read from host-visible memory and prepared by the kernel itself into Q (device scratch, [ld]); out_*
+  // then point into host-visible memory and the kernel publishes `seq` in done_flag (system scope) when they are written.
+  const float* q_raw = nullptr;
+  uint32_t* done_flag = nullptr;
+  uint32_t seq = 0;
 };
 size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap);
 hipError_t launch_graph_search(const GraphArgs& a, hipStream_t st);

@@ -112,6 +112,45 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
       s->n_dist += s->n;
       return EHX_OK;
     }
+    // ... and in GRAPH mode (round 5; the reference's own index and request: HNSW, one query per NearestNeighbor RPC):
+    // the graph search kernel reads the raw query from host-visible memory, prepares it itself, walks the graph (one
+    // wave) and writes the answer into host-visible memory — one launch instead of prepare + search + two copies.
+    if (one_on && n_queries == 1 && k <= 64 && s->params.mode == EHX_MODE_GRAPH && s->n > 0 && s->ld <= 4096) {
+      constexpr size_t kOneQ = 16384;
+      if (!s->hOnePin) {
+        HIP_TRY(hipHostMalloc((void**)&s->hOnePin, kOneQ + 2048, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(s->hOnePin, 0, kOneQ + 2048);
+      }
+      char* h = s->hOnePin;
+      memcpy(h, queries, qbytes);
+      GraphOneLaunch one;
+      one.q_host = (const float*)h;
+      one.done_flag = (uint32_t*)(h + kOneQ + 1024);
+      one.seq = ++s->one_seq ? s->one_seq : ++s->one_seq;   // (never 0: the buffer starts zeroed)
+      uint64_t* o_ids = (uint64_t*)(h + kOneQ);
+      float* o_dist = (float*)(h + kOneQ + 512);
+      uint32_t* o_cnt = (uint32_t*)(h + kOneQ + 768);
+      if ((rc = knn_graph_locked(s, s->stream, 1, nullptr, k, o_ids, o_dist, o_cnt, &one))) return rc;
+      volatile uint32_t* flag = (volatile uint32_t*)one.done_flag;
+      bool seen = false;
+      for (uint32_t spin = 0; spin < 4000000u; ++spin) {
+        if (*flag == one.seq) {
+          seen = true;
+          break;
+        }
+        __builtin_ia32_pause();
+      }
+      if (!seen) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (*flag != one.seq) return fail(EHX_EINTERNAL, "graph search kernel finished without publishing its result");
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      memcpy(out_ids, o_ids, k * sizeof(uint64_t));
+      memcpy(out_dist, o_dist, k * sizeof(float));
+      out_count[0] = *o_cnt;
+      s->n_one_launch += 1;
+      return EHX_OK;
+    }
     if ((rc = s->dQraw.ensure(n_queries * s->dims))) return rc;
     if (!s->hSmallPin) HIP_TRY(hipHostMalloc((void**)&s->hSmallPin, 2 * kSmallCall, hipHostMallocDefault));
     if ((rc = s->dSmallOut.ensure(kSmallCall / sizeof(uint64_t)))) return rc;

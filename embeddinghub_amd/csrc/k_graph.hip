@@ -30,6 +30,7 @@
 //   * work counters as SURVEY §8d: n_dist = rows actually fetched, n_hops0 / n_hops_up = expansions.
 #include "ehx_env.h"
 #include "ehx_kernels.h"
+#include "k_prep_query.h"
 
 namespace ehx {
 
@@ -166,6 +167,13 @@ __global__ __launch_bounds__(64 * WAVES) void graph_search_kernel(const GraphArg
   if (wv == 0)
     for (uint32_t i = lane; i < a.ef_cap; i += 64) F[i] = 0;
 
+  if (WAVES == 1 && a.q_raw) {
+    // one query per call, one launch: the raw query comes from host-visible memory and is prepared here, by this wave,
+    // into the device scratch row the loads below read (the same arithmetic as prep_queries_kernel: identical bytes)
+    prep_query_row(a.q_raw, 1u, a.dims, a.ld, a.metric, const_cast<float*>(a.Q), 0u, lane);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  }
 #if EHX_G_COOP
   for (uint32_t i = threadIdx.x; i < a.ld; i += 64 * WAVES) qs[search_copy_pos(i)] = a.Q[(size_t)qi * a.ld + i];
 #else
@@ -510,6 +518,11 @@ __global__ __launch_bounds__(64 * WAVES) void graph_search_kernel(const GraphArg
 #ifdef EHX_GRAPH_PROFILE
     for (int i = 0; i < 8; ++i) atomicAdd(&a.counters[4 + i], prof_[i]);
 #endif
+  }
+  if (a.done_flag) {   // one-launch form: the results above went to host-visible memory; tell the spinning host thread
+    __threadfence_system();
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0) __hip_atomic_store(a.done_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

@@ -63,6 +63,35 @@ def test_strict_parity_on_oracle_graph(n, d, nq, k, efs, em, om):
     s.drop()
 
 
+@pytest.mark.parametrize("em,om", METRICS)
+@pytest.mark.parametrize("n,d,k,ef", [(10000, 128, 10, 10), (3000, 768, 10, 64), (2000, 50, 20, 10), (900, 19, 64, 10)])
+def test_one_query_per_call_in_one_launch_walks_the_oracles_path(n, d, k, ef, em, om):
+    """The reference's request shape in the reference's index (one query per NearestNeighbor RPC against the HNSW graph,
+    server.cc:172-210): `ehx_knn` with one query runs the graph search as ONE launch — raw query read from host-visible
+    memory and prepared by the kernel itself (cosine: normalised there), results written to host-visible memory — and
+    must return what the batched path returns: the oracle's ids, distance bytes, counts and traversal counters, query
+    after query (the visited bitmap is the wave's to clear), and again after a batch call in between."""
+    X, h, s, rng = _build(n, d, em, om, seed=n + d + k)
+    Q = rng.standard_normal((24, d)).astype(np.float32)
+    h.set_ef(ef)
+    s.set_ef(ef)
+    labels, dists, counts, _, st = h.search_batch(Q, k, threads=1)
+    s.stats_reset()
+    for i in range(12):
+        ids, dist, cnt = s.knn(Q[i:i + 1], k)
+        assert cnt[0] == counts[i] and list(ids[0]) == list(labels[i]) and dist[0].tobytes() == dists[i].tobytes(), i
+    ids, dist, cnt = s.knn(Q[12:20], k)        # a batch in between (prepare launch + search launch, memset or log)
+    np.testing.assert_array_equal(ids, labels[12:20])
+    assert dist.tobytes() == dists[12:20].tobytes()
+    for i in range(20, 24):
+        ids, dist, cnt = s.knn(Q[i:i + 1], k)
+        assert cnt[0] == counts[i] and list(ids[0]) == list(labels[i]) and dist[0].tobytes() == dists[i].tobytes(), i
+    g = s.stats()
+    assert g["n_queries"] == 24
+    assert g["n_dist"] == st["n_dist"] - 24 and g["n_hops"] == st["n_hops0"] + st["n_hops_up"]
+    s.drop()
+
+
 def test_graph_mode_requires_a_graph_and_flat_agrees_at_high_ef():
     X, h, s, rng = _build(2000, 32, ehx.METRIC_L2SQ, pyoracle.METRIC_L2, seed=5)
     Q = rng.standard_normal((32, 32)).astype(np.float32)
