@@ -664,7 +664,8 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
       HIP_TRY(hipEventSynchronize(c.ev[3]));
       if (c.ev_seq > newest) {
         newest = c.ev_seq;
-        if (hipEventElapsedTime(&ms, c.ev[1], c.ev[2]) == hipSuccess) out->last_scan_ms = ms;
+        if (c.last_scan[0] && c.last_scan[1] && hipEventElapsedTime(&ms, c.last_scan[0], c.last_scan[1]) == hipSuccess)
+          out->last_scan_ms = ms;
         if (hipEventElapsedTime(&ms, c.ev[0], c.ev[3]) == hipSuccess) out->last_total_ms = ms;
       }
       const uint64_t m = c.ring_count < 64 ? c.ring_count : 64;

@@ -19,12 +19,12 @@ struct Env {
   bool host_pipeline = true;      // EHX_HOST_PIPELINE=0: host batches take the pipeline lock for the whole call
   bool allow_no_peer = false;     // EHX_ALLOW_NO_PEER=1: in-process shards without peer access (copies stage through the host)
   // ---- int8 filter scan ----
-  uint32_t i8_growth = 4;         // EHX_I8_GROWTH [2, 64]: rows of pass i+1 / rows of pass i
+  uint32_t i8_growth = 0;         // EHX_I8_GROWTH [2, 64]: rows of pass i+1 / rows of pass i (0: automatic, ehx_flat.cpp)
   double i8_safety = 2.0;         // EHX_I8_SAFETY >= 1: slack of the rank a middle pass's threshold is taken at
   int i8_sync = 0;                // EHX_I8_SYNC: 0 off, N > 0 lock-step by tile with tolerance N, "rev" (-1) by ring revolution
   long i8_kprime = 0;             // EHX_I8_KPRIME >= 64: fixed logical length of the candidate list (0: automatic)
-  uint32_t i8_first_tiles = 512;  // EHX_I8_FIRST_TILES [64, 65536]: tiles of the cascade's first pass
-  uint64_t i8_first_keys = 0;     // EHX_I8_FIRST_KEYS: keys per query the first pass aims for (0: min(512, 2 k'))
+  uint32_t i8_first_tiles = 0;    // EHX_I8_FIRST_TILES [64, 65536]: tiles of the cascade's first pass (0: automatic)
+  uint64_t i8_first_keys = 0;     // EHX_I8_FIRST_KEYS: keys per query the first pass aims for (0: automatic)
   uint32_t i8_width = 0;          // EHX_I8_WIDTH = 256 | 512 | 1024: initial width of the list (0: by row length)
   uint64_t i8_min_rows = 0;       // EHX_I8_MIN_ROWS >= 4096: below this many rows the fp16 filter serves (0: 16384)
   bool i8_sort = true;            // EHX_I8_SORT=0: tiles keep their row order (no per-tile ordering by quantisation step)

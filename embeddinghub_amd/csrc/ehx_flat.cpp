@@ -260,7 +260,16 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
                float* d_dist, uint32_t* d_count, bool count_stats, uint32_t* kprime_used) {
   Engine& E = engine();
   ehx_space::I8Set& sc = s->i8set[set];
-  const uint32_t growth = env().i8_growth;
+  const uint32_t n_tiles = (uint32_t)((s->n + kTileRows16 - 1) / kTileRows16);
+  // The cascade's shape.  Shards of at least 2048 tiles (524 288 rows): a first pass of 128 tiles that aims for 64 keys
+  // per query, then x8 in rows per pass; smaller ones: 512 tiles, min(512, 2 k') keys, x4 (one or two passes).  Round 5,
+  // same box, 60 batches each (profiles/r05_i_ab_cascade.jsonl): 1.25 M x 768 1.190 -> 1.146 ms per batch, 10 M x 768
+  // 6.64 -> 6.58, 6.25 M x 128 1.154 -> 1.139 (256 / x8 / 64: 12.5 M x 1536 fp16 18.7 -> 18.4); at 200 000 x 768 the
+  // second pass the small first pass brings costs more than its tighter threshold saves (scan phase 0.248 -> 0.274).
+  // A loose first pass is the expensive one: its threshold comes from a 2048-row sample and every key it lets through
+  // is a trip through the epilogue's slow path.  EHX_I8_FIRST_TILES / EHX_I8_GROWTH / EHX_I8_FIRST_KEYS override.
+  const bool big = n_tiles >= 2048;
+  const uint32_t growth = env().i8_growth ? env().i8_growth : (big ? 8u : 4u);
   const double safety = [] {
     // rank of the next pass's threshold = 256 x (share of the rows seen) x safety.  2: the last pass of a 10 M-row batch
     // runs under the 138th best of the first 27 % (about 510 rows below it overall: the list still fills to 256, the
@@ -305,7 +314,6 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   const uint32_t kprime = kprime_env >= 64 ? (uint32_t)std::min<long>(kprime_env, (long)width) : std::min(kp_want, width);
   s->i8_kprime_last.store(kprime, std::memory_order_relaxed);
   if (kprime_used) *kprime_used = kprime;
-  const uint32_t n_tiles = (uint32_t)((s->n + kTileRows16 - 1) / kTileRows16);
   struct Pass {
     uint32_t tile0;
     ScanPlan plan;
@@ -313,7 +321,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   // First pass: up to 512 tiles (131 072 rows) under a threshold taken from the sample at a LOW rank, chosen so that
   // the pass collects ~1000 keys per query (any threshold is sound, see sample_select256_kernel); then x4 in rows per
   // pass under the 256th best so far.
-  const uint32_t kFirstTiles = env().i8_first_tiles;  // (EHX_I8_FIRST_TILES: sweeps of the cascade's shape on small shards)
+  const uint32_t kFirstTiles = env().i8_first_tiles ? env().i8_first_tiles : (big ? 128u : 512u);
   std::vector<Pass> passes;
   {
     uint32_t done = 0, cum = kFirstTiles;
@@ -341,7 +349,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   // collected 1024 and spent more than half of the first pass in the epilogue's slow path).
   const uint64_t first_rows = (uint64_t)passes.front().plan.n_tiles * kTileRows16;
   const uint64_t first_keys_env = env().i8_first_keys;  // (EHX_I8_FIRST_KEYS: keys per query the first pass aims for)
-  const uint64_t first_floor = first_keys_env ? first_keys_env : std::min<uint64_t>(512, 2ull * kprime);
+  const uint64_t first_floor = first_keys_env ? first_keys_env : (big ? 64ull : std::min<uint64_t>(512, 2ull * kprime));
   const uint64_t first_keys = std::min<uint64_t>(
       2048, passes.size() == 1 ? 2ull * kprime : std::max<uint64_t>(first_floor, 2ull * rank_after(0)));
   const uint32_t sample_rank =
@@ -410,8 +418,10 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
     return launch_flat_scan_i8(a, st);
   };
   hipEvent_t* pr = sc.ring[sc.ring_count % 64];
-  HIP_TRY(hipEventRecord(sc.ev[1], st));
+  // (one record per mark: sc.ev[1] / ev[2] — "scan start / end of the LAST batch" for ehx_stats — are the ring's own events
+  // of this batch; a second marker packet at the same place cost ~5 us of queue time each, twice per batch)
   HIP_TRY(hipEventRecord(pr[0], st));
+  sc.last_scan[0] = pr[0];
   {  // sample pass: lower bounds of the first 2048 rows -> thr[q] = the k'-th best of them
     ScanPlan sp = plan_scan((uint32_t)nq, kSampleTiles, k, E.n_cus);
     a.dump = sc.dSample8.p;
@@ -432,7 +442,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
     HIP_TRY(scan(passes[i].plan, passes[i].tile0));
     if (last) {  // (the last select and the re-rank are outside the timed scan phase, like flat_pass's final merge)
       HIP_TRY(hipEventRecord(pr[1], st));
-      HIP_TRY(hipEventRecord(sc.ev[2], st));
+      sc.last_scan[1] = pr[1];
       sc.ring_count++;
     }
     HIP_TRY(launch_select256(sc.dPool.p, pool_cnt, kPoolCap, (uint32_t)nq, rank_after(i), sc.dMerged8.p, width, i > 0,

@@ -342,7 +342,8 @@ struct ehx_space {
     DevBuf<uint64_t> dCnt;    // [8] epilogue counters of diagnosis builds (EHX_I8_COUNT); the set's own: nothing shared
     unsigned long long* dUncert = nullptr;
     unsigned long long* hUncertPin = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start | scan start | scan end | all enqueued work done
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start | (unused) | (unused) | all enqueued work done
+    hipEvent_t last_scan[2] = {nullptr, nullptr};            // scan start / end of the last batch: two of ring[][]'s events
     hipEvent_t verdict = nullptr;                            // blocking-sync: the verdict has landed in hUncertPin
     std::atomic<bool> ev_valid{false};
     uint64_t ev_seq = 0;     // value of ehx_space::ev_counter when ev[] was last recorded (ehx_stats: which set is newest)

@@ -231,7 +231,7 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
   // no host round trip (launches, verdict copy, thread wake-up: ~0.1 ms per batch) between them.  A batch that does lose
   // queries is re-run through the full engine chain under the lock (rare; the chain also adapts the list's length).
   const bool pipe_on = env().host_pipeline;
-  bool done = false, have_failed = false;
+  bool done = false, have_failed = false, copied_early = false;
   std::vector<uint32_t> failed;
   size_t n_short = 0;
   uint32_t kprime_used = 0;
@@ -244,6 +244,12 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
     HIP_TRY(hipMemcpyAsync(sc.hUncertPin, sc.dUncert, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipEventRecord(sc.verdict, s->stream));
     HIP_TRY(hipEventRecord(hs->done_ev, s->stream));
+    // the results start their way back NOW, before the verdict is known (it is clean for all but a few batches in a
+    // thousand): one host wait per batch instead of two in a row — verdict, then copy.  A batch that did lose queries runs
+    // the rest of the chain below and copies again (same slot stream: in order, the later copy wins).
+    HIP_TRY(hipStreamWaitEvent(hs->st, hs->done_ev, 0));
+    HIP_TRY(hipMemcpyAsync(hs->pin + qbytes, hs->dout.p, out_bytes, hipMemcpyDeviceToHost, hs->st));
+    copied_early = true;
     HIP_TRY(hipEventSynchronize(sc.verdict));
     s->n_queries += n_queries;
     s->n_dist += (uint64_t)n_queries * s->n;
@@ -274,8 +280,10 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
     HIP_TRY(hipEventRecord(hs->done_ev, s->stream));
   }
   char* ho = hs->pin + qbytes;
-  HIP_TRY(hipStreamWaitEvent(hs->st, hs->done_ev, 0));
-  HIP_TRY(hipMemcpyAsync(ho, hs->dout.p, out_bytes, hipMemcpyDeviceToHost, hs->st));
+  if (!(done && copied_early)) {
+    HIP_TRY(hipStreamWaitEvent(hs->st, hs->done_ev, 0));
+    HIP_TRY(hipMemcpyAsync(ho, hs->dout.p, out_bytes, hipMemcpyDeviceToHost, hs->st));
+  }
   HIP_TRY(hipStreamSynchronize(hs->st));
   memcpy(out_ids, ho, ids_b);
   memcpy(out_dist, ho + ids_b, dist_b);
