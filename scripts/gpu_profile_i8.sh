@@ -5,18 +5,20 @@
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 R=$(pwd)
-ARGS="--steps 4 --warmup 1 --check-queries 0 --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --single-query 0 --no-cpu-baseline $BENCH_ARGS"
+ARGS="--steps 4 --warmup 1 --check-queries 0 --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --single-query 0 --no-cpu-baseline --reference-benchmark 0 $BENCH_ARGS"
 run() {  # name, env, rocprof args...
   local name=$1 envs=$2; shift 2
   rm -rf gpurun_out/prof/$name
   (cd /tmp && env $envs timeout 600 rocprofv3 --kernel-trace "$@" -d $R/gpurun_out/prof/$name -o p -- python $R/bench.py $ARGS > $R/gpurun_out/prof/$name.log 2>&1)
   ROCPD_SEQ=${SEQ:-0} python scripts/rocpd_summary.py gpurun_out/prof/$name > gpurun_out/prof/${name}_summary.txt 2>&1
 }
-SEQ=22 run ${TAG:-r03}_i8_trace "EHX_I8_SYNC=0" --stats
-run ${TAG:-r03}_i8_pmc_fetch "EHX_I8_SYNC=0" --pmc FETCH_SIZE
-run ${TAG:-r03}_i8_pmc_write "EHX_I8_SYNC=0" --pmc WRITE_SIZE
-run ${TAG:-r03}_i8_pmc_sq "EHX_I8_SYNC=0" --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE
-run ${TAG:-r03}_i8_pmc_clk "EHX_I8_SYNC=0" --pmc GRBM_GUI_ACTIVE
+PASSES=${PASSES:-"trace fetch write sq clk"}   # (round 5: PASSES="trace" = the launch-by-launch trace of another shape only)
+SYNC=${SYNC:-0}                                # EHX_I8_SYNC of every pass (lock-step variants: SYNC=2 PASSES="fetch")
+case " $PASSES " in *" trace "*) SEQ=22 run ${TAG:-r03}_i8_trace "EHX_I8_SYNC=$SYNC" --stats;; esac
+case " $PASSES " in *" fetch "*) run ${TAG:-r03}_i8_pmc_fetch "EHX_I8_SYNC=$SYNC" --pmc FETCH_SIZE;; esac
+case " $PASSES " in *" write "*) run ${TAG:-r03}_i8_pmc_write "EHX_I8_SYNC=$SYNC" --pmc WRITE_SIZE;; esac
+case " $PASSES " in *" sq "*) run ${TAG:-r03}_i8_pmc_sq "EHX_I8_SYNC=$SYNC" --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE;; esac
+case " $PASSES " in *" clk "*) run ${TAG:-r03}_i8_pmc_clk "EHX_I8_SYNC=$SYNC" --pmc GRBM_GUI_ACTIVE;; esac
 TAG=${TAG:-r03} python - <<'PY'
 import json, re
 def counter_sum(path, kernel_sub, counter):
@@ -35,17 +37,20 @@ def calls(path, kernel_sub):
 out = {}
 import os
 TAG = os.environ.get("TAG", "r03")
+if not os.path.exists("gpurun_out/prof/%s_i8_pmc_fetch_summary.txt" % TAG):
+    raise SystemExit(0)
 for tag, fpath, wpath in (("nosync", "gpurun_out/prof/%s_i8_pmc_fetch_summary.txt" % TAG, "gpurun_out/prof/%s_i8_pmc_write_summary.txt" % TAG),):
     batches = calls(fpath, "_i8_kernelILb1")
     fetch = counter_sum(fpath, "_i8_kernelILb", "FETCH_SIZE")
-    write = counter_sum(wpath, "_i8_kernelILb", "WRITE_SIZE") if wpath else 0.0
-    wb = calls(wpath, "_i8_kernelILb1") if wpath else 1
+    have_w = wpath and os.path.exists(wpath)
+    write = counter_sum(wpath, "_i8_kernelILb", "WRITE_SIZE") if have_w else 0.0
+    wb = calls(wpath, "_i8_kernelILb1") if have_w else 1
     per_batch = (2 * fetch / max(batches, 1) + write / max(wb, 1)) * 1024
     out[tag] = {"batches": batches, "fetch_KB_sum": fetch, "write_KB_sum": write, "bytes_per_batch": per_batch,
                 "x_algorithmic_7.68e9": per_batch / (1e7 * 768 + 1024 * 768 * 4 + 1024 * 10 * 12)}
 print(json.dumps(out, indent=1))
 open("gpurun_out/prof/%s_i8_traffic.json" % TAG, "w").write(json.dumps(out, indent=1))
 PY
-head -28 gpurun_out/prof/${TAG:-r03}_i8_trace_summary.txt | cut -c1-150
-grep -h "_i8_kernelILb" gpurun_out/prof/${TAG:-r03}_i8_pmc_sq_summary.txt gpurun_out/prof/${TAG:-r03}_i8_pmc_clk_summary.txt | cut -c1-140
+head -28 gpurun_out/prof/${TAG:-r03}_i8_trace_summary.txt 2>/dev/null | cut -c1-150
+grep -h "_i8_kernelILb" gpurun_out/prof/${TAG:-r03}_i8_pmc_sq_summary.txt gpurun_out/prof/${TAG:-r03}_i8_pmc_clk_summary.txt 2>/dev/null | cut -c1-140
 find gpurun_out/prof -name "*.db" -size +8M -delete; du -sh gpurun_out/prof
