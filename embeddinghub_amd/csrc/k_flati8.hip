@@ -450,7 +450,9 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     // max |A_r| over this lane's 32 rows (tiles ordered by step: every row of the group has exactly this |A_r|)
     const float4 tg = tg_cur;
     const float gm = qd == 0 ? tg.x : (qd == 1 ? tg.y : (qd == 2 ? tg.z : tg.w));
-    const float rgm = (1.0f - 2e-6f) / gm;   // (gm = 0: a group of padding rows — +inf, nothing alarms unless K = -inf)
+    // (gm = 0: a group of padding rows — +inf, nothing alarms unless K = -inf.  v_rcp_f32 is good to 1 ulp: three
+    // roundings against a margin of 2e-6 — the level still errs low; the IEEE division was a dozen instructions per tile)
+    const float rgm = (1.0f - 2e-6f) * __builtin_amdgcn_rcpf(gm);
     // The alarm level K of a (tile, query) is computed ONCE per wave — lane (qd, j15) takes query 16 qd + j15 of the
     // wave's 64 — and handed to the four lanes that hold the query's accumulators by a lane permute.  -inf, +inf or > 0.
     const float k_own = i8_alarm_k(tp, qp_lds[wc * 64 + lane_e], qinv_lds[wc * 64 + lane_e]);

@@ -4,6 +4,7 @@
 # short-row shapes (fractions recomputed from a rocprof trace of those shapes, not from HIP events)
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof
+timeout 600 python -m pytest tests/test_i8_filter.py tests/test_fuzz_parity.py tests/test_flat_parity.py -x -q -m gpu 2>&1 | tail -3 | tee gpurun_out/r05_k_pytest_tail.txt
 TAG=r05_k BENCH_ARGS="--config-legs 0" bash scripts/gpu_profile_i8.sh 2>&1 | tail -24
 TAG=r05_k_sync2 SYNC=2 PASSES="fetch" BENCH_ARGS="--config-legs 0" bash scripts/gpu_profile_i8.sh 2>&1 | tail -8
 TAG=r05_k_1250k PASSES="trace" BENCH_ARGS="--config-legs 0 --rows 1250000 --steps 8" bash scripts/gpu_profile_i8.sh 2>&1 | tail -3
