@@ -72,6 +72,8 @@ SYMBOLS = {
     "ehx_knn_keys": (C.c_int, [_vp, C.c_size_t, _f32p, C.c_uint32, _u64p, _f32p, _u32p, C.c_char_p,
                                C.c_size_t, _u64p]),
     "ehx_knn_by_key": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.c_uint32, _u64p, _f32p, _u32p]),
+    "ehx_knn_by_key_keys": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.c_uint32, _u64p, _f32p, _u32p, C.c_char_p, C.c_size_t,
+                                      _u64p]),
     "ehx_knn_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp, _vp]),
     "ehx_merge_topk_device": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ehx_merge_topk_strided_device": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_uint32, _vp, C.c_size_t, _vp,

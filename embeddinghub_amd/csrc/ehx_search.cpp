@@ -443,6 +443,29 @@ int ehx_knn_by_key(ehx_space* s, const char* key, size_t klen, uint32_t k, uint6
   return EHX_OK;
 }
 
+int ehx_knn_by_key_keys(ehx_space* s, const char* key, size_t klen, uint32_t k, uint64_t* out_ids, float* out_dist,
+                        uint32_t* out_count, char* key_arena, size_t arena_cap, uint64_t* key_off) {
+  if (!key_off || !out_count || (!key_arena && arena_cap)) return fail(EHX_EINVAL, "NULL argument");
+  std::vector<uint64_t> ids(k ? k : 1);
+  int rc = ehx_knn_by_key(s, key, klen, k, ids.data(), out_dist, out_count);
+  if (rc) return rc;
+  std::shared_lock<std::shared_mutex> rl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+  uint64_t off = 0;
+  std::string nk;
+  for (uint32_t j = 0; j < k; ++j) {
+    key_off[j] = off;
+    if (j < *out_count && key_for_id(s, ids[j], &nk) == EHX_OK) {
+      if (off + nk.size() > arena_cap) return fail(EHX_ERANGE, "key arena too small");
+      memcpy(key_arena + off, nk.data(), nk.size());
+      off += nk.size();
+    }
+    if (out_ids) out_ids[j] = j < *out_count ? ids[j] : ~0ull;
+  }
+  key_off[k] = off;
+  return EHX_OK;
+}
+
 int ehx_merge_topk_strided_device(void* stream, size_t n_queries, uint32_t k, uint32_t n_lists, const uint64_t* d_ids,
                                   size_t ids_stride, const float* d_dist, size_t dist_stride, const uint32_t* d_count,
                                   size_t count_stride, uint64_t* d_out_ids, float* d_out_dist,

@@ -235,6 +235,25 @@ class Space:
                                      dist.ctypes.data_as(C.POINTER(C.c_float)), C.byref(cnt)))
         return ids[:cnt.value], dist[:cnt.value]
 
+    def knn_by_key_keys(self, key, k):
+        """the NearestNeighbor RPC by key in ONE engine call -> list of neighbour keys, nearest first"""
+        kb = key.encode() if isinstance(key, str) else bytes(key)
+        cnt = C.c_uint32()
+        off = np.zeros(k + 1, dtype=np.uint64)
+        cap = 1 << 12
+        while True:
+            arena = C.create_string_buffer(cap)
+            rc = self._L.ehx_knn_by_key_keys(self._h, kb, len(kb), k, None, None, C.byref(cnt), arena, cap,
+                                             off.ctypes.data_as(C.POINTER(C.c_uint64)))
+            if rc == _lib.ERANGE:
+                cap *= 8
+                continue
+            check(rc)
+            break
+        raw = arena.raw
+        o = off.tolist()
+        return [raw[o[j]:o[j + 1]].decode() for j in range(cnt.value)]
+
     # ---- device-resident (torch tensors on the GPU) ----
     def knn_device(self, d_queries, k, d_ids, d_dist, d_count, stream=None):
         """All arguments are device pointers (ints) or torch CUDA tensors; enqueues on `stream`."""
@@ -292,8 +311,7 @@ def nearest_neighbor_rpc(space, num, key="", embedding=None):
         return 3, []
     try:
         if has_key:
-            ids, _ = space.knn_by_key(key, num)
-            return 0, [space.key_of(i) for i in ids]
+            return 0, space.knn_by_key_keys(key, num)   # (one engine call: lookup, search k + 1, drop the key, keys back)
         return 0, space.knn_keys(np.asarray(embedding, dtype=np.float32), num)[0]
     except EhxError as e:
         if e.code == _lib.ENOTFOUND:

@@ -199,6 +199,12 @@ int ehx_knn_keys(ehx_space* s, size_t n_queries, const float* queries, uint32_t 
  * itself if present else drop the last.  EHX_ENOTFOUND for an unknown key (the reference has UB). */
 int ehx_knn_by_key(ehx_space* s, const char* key, size_t klen, uint32_t k, uint64_t* out_ids,
                    float* out_dist, uint32_t* out_count);
+/* as ehx_knn_by_key, plus the neighbours' KEYS in one call — the whole NearestNeighbor RPC by key (server.cc:172-210:
+ * look the key up, search k+1, drop the key itself, answer with keys) without k calls of ehx_key_of: key j is
+ * key_arena[key_off[j] .. key_off[j+1]), key_off has k+1 entries; EHX_ERANGE if the arena is too small.
+ * out_ids / out_dist may be NULL. */
+int ehx_knn_by_key_keys(ehx_space* s, const char* key, size_t klen, uint32_t k, uint64_t* out_ids, float* out_dist,
+                        uint32_t* out_count, char* key_arena, size_t arena_cap, uint64_t* key_off);
 
 /* ---- device-resident entry points (inputs/outputs already in HBM; `stream` is a hipStream_t
  *      passed as void*, NULL = default stream).  These are what a batching shim and bench.py

@@ -76,6 +76,36 @@ def test_rpc_semantics_match_oracle():  # server.cc:172-210
         assert ehx.nearest_neighbor_rpc(s, **c) == o.nearest_neighbor_rpc(**c), c
 
 
+@pytest.mark.parametrize("mode", ["flat", "graph"])
+def test_by_key_with_keys_in_one_call_is_the_rpc(mode):
+    """ehx_knn_by_key_keys = the NearestNeighbor RPC by key (server.cc:172-210) in one call: the same neighbours as
+    ehx_knn_by_key + ehx_key_of per id, their keys in the arena (long keys: the arena grows on EHX_ERANGE), fewer than k
+    results on a small space, EHX_ENOTFOUND for an unknown key"""
+    rng = np.random.default_rng(5)
+    n, d = 700, 24
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    keys = ["key-%05d-" % i + "x" * (i % 7 == 0) * 300 for i in range(n)]
+    kw = dict(mode=ehx.MODE_GRAPH, build_batch=1) if mode == "graph" else {}
+    s = ehx.Space.unique("bykey-" + mode, d, metric=ehx.METRIC_L2SQ, **kw)
+    s.set_batch(keys, X)
+    if mode == "graph":
+        s.set_ef(64)
+    for q in (0, 7, 349, 699):
+        ids, _ = s.knn_by_key(keys[q], 20)
+        assert s.knn_by_key_keys(keys[q], 20) == [s.key_of(i) for i in ids] and len(ids) == 20 and q not in ids
+    if mode == "flat":   # (exact: the neighbours of a stored row, itself excluded, are the oracle's)
+        oids, _, _ = pyoracle.exhaustive(X, X[349:350], 21, pyoracle.METRIC_L2)
+        assert s.knn_by_key_keys(keys[349], 20) == [keys[i] for i in oids[0] if i != 349][:20]
+    tiny = ehx.Space.unique("bykey-tiny-" + mode, d, metric=ehx.METRIC_L2SQ, **kw)
+    tiny.set_batch(keys[:3], X[:3])
+    assert sorted(tiny.knn_by_key_keys(keys[1], 20)) == sorted([keys[0], keys[2]])
+    with pytest.raises(ehx.EhxError) as e:
+        s.knn_by_key_keys("no such key", 5)
+    assert e.value.code == ehx._lib.ENOTFOUND
+    s.drop()
+    tiny.drop()
+
+
 def test_get_set_roundtrip_and_errors():  # version_test.cc:16-23, storage_test.cc:17-23
     s = ehx.Space.unique("rt", 5, metric=ehx.METRIC_COSINE)
     v = np.array([1.5, -2.25, 3.0, 0.125, 7.0], dtype=np.float32)
