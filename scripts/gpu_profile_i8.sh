@@ -40,11 +40,11 @@ TAG = os.environ.get("TAG", "r03")
 if not os.path.exists("gpurun_out/prof/%s_i8_pmc_fetch_summary.txt" % TAG):
     raise SystemExit(0)
 for tag, fpath, wpath in (("nosync", "gpurun_out/prof/%s_i8_pmc_fetch_summary.txt" % TAG, "gpurun_out/prof/%s_i8_pmc_write_summary.txt" % TAG),):
-    batches = calls(fpath, "_i8_kernelILb1")
-    fetch = counter_sum(fpath, "_i8_kernelILb", "FETCH_SIZE")
+    batches = calls(fpath, "nelILb1E")   # the sample (DUMP) pass: once per batch; names are cut to their last 46 characters
+    fetch = counter_sum(fpath, "ScanArgsI8E", "FETCH_SIZE")
     have_w = wpath and os.path.exists(wpath)
-    write = counter_sum(wpath, "_i8_kernelILb", "WRITE_SIZE") if have_w else 0.0
-    wb = calls(wpath, "_i8_kernelILb1") if have_w else 1
+    write = counter_sum(wpath, "ScanArgsI8E", "WRITE_SIZE") if have_w else 0.0
+    wb = calls(wpath, "nelILb1E") if have_w else 1
     per_batch = (2 * fetch / max(batches, 1) + write / max(wb, 1)) * 1024
     out[tag] = {"batches": batches, "fetch_KB_sum": fetch, "write_KB_sum": write, "bytes_per_batch": per_batch,
                 "x_algorithmic_7.68e9": per_batch / (1e7 * 768 + 1024 * 768 * 4 + 1024 * 10 * 12)}
@@ -52,5 +52,5 @@ print(json.dumps(out, indent=1))
 open("gpurun_out/prof/%s_i8_traffic.json" % TAG, "w").write(json.dumps(out, indent=1))
 PY
 head -28 gpurun_out/prof/${TAG:-r03}_i8_trace_summary.txt 2>/dev/null | cut -c1-150
-grep -h "_i8_kernelILb" gpurun_out/prof/${TAG:-r03}_i8_pmc_sq_summary.txt gpurun_out/prof/${TAG:-r03}_i8_pmc_clk_summary.txt 2>/dev/null | cut -c1-140
+grep -h "ScanArgsI8E" gpurun_out/prof/${TAG:-r03}_i8_pmc_sq_summary.txt gpurun_out/prof/${TAG:-r03}_i8_pmc_clk_summary.txt 2>/dev/null | cut -c1-140
 find gpurun_out/prof -name "*.db" -size +8M -delete; du -sh gpurun_out/prof
