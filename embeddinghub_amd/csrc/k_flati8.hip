@@ -290,7 +290,6 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
   const uint32_t lrow0 = HALF ? 0u : (uint32_t)wr * 128u;   // the wave's first row inside the X stage / row-parameter block in LDS
   float4* qp_lds = (float4*)(smem + L::kQpOff);
   float* qinv_lds = (float*)(smem + L::kQinvOff);
-  const volatile uint32_t* sync_lds = (const volatile uint32_t*)(smem + L::kSyncOff);
 
   if (tid < (int)kTileQ) {  // query parameters and this pass's threshold, once per workgroup
     const size_t qg = (size_t)qt * kTileQ + tid;
@@ -845,8 +844,16 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     // than one outstanding could let a counted wait pass early; a tile is ~10 us, the store retires in ~1).
     auto after_tile = [&](const uint32_t t) {
       if (sync_on && sync_by_tile && w == 0) {
+        // (the snapshot is read with a REAL LDS instruction: through the volatile generic pointer the compiler emitted
+        // flat_load_dword + s_waitcnt vmcnt(0) — the whole DMA look-ahead of the wave drained at every look, which is what
+        // the lock-step "cost" in rounds 2-4 and in this round's first measurement: +7.7 % by tile, +60 % by revolution)
+        i32x4 snap;
+        {
+          const uint32_t snap_at = L::kSyncOff;
+          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(snap) : "v"(snap_at) : "memory");
+        }
         uint32_t mn = 0xFFFFFFFFu;
-        for (uint32_t i = 0; i < a.q_tiles; ++i) mn = min(mn, (uint32_t)__builtin_amdgcn_readfirstlane(sync_lds[i]));
+        for (uint32_t i = 0; i < a.q_tiles; ++i) mn = min(mn, (uint32_t)__builtin_amdgcn_readfirstlane(snap[i]));
         const uint32_t need = t + 1u > a.sync_tol ? t + 1u - a.sync_tol : 0u;
         if (mn < need) {
           uint32_t spins = 0;
@@ -879,7 +886,12 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
       if (sync_on && !sync_by_tile && w == 0) {
         // revolution q is done.  The snapshot taken after revolution q-1 (landed long ago: four stage waits have
         // passed) must show every sibling through revolution q-2; then announce q and take the next snapshot.
-        const uint32_t seen = __builtin_amdgcn_readfirstlane(sync_lds[0]);
+        uint32_t seen;
+        {
+          const uint32_t snap_at = L::kSyncOff;   // (a real ds_read: see after_tile)
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(snap_at) : "memory");
+        }
+        seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
         const uint32_t need = q >= 2 ? a.q_tiles * (q - 1) : 0u;
         if (seen < need) {
           uint32_t spins = 0;
@@ -976,7 +988,12 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     auto after_revolution_rt = [&](const uint32_t q) {
       // revolution q is done.  The snapshot taken after revolution q-1 (landed long ago: four stage waits have
       // passed) must show every sibling through revolution q-2; then announce q and take the next snapshot.
-      const uint32_t seen = __builtin_amdgcn_readfirstlane(sync_lds[0]);
+      uint32_t seen;
+      {
+        const uint32_t snap_at = L::kSyncOff;   // (a real ds_read: see after_tile)
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(snap_at) : "memory");
+      }
+      seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
       const uint32_t need = q >= 2 ? a.q_tiles * (q - 1) : 0u;
       if (seen < need) {
         uint32_t spins = 0;
