@@ -926,6 +926,11 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
         EHX_STAGE16_CT(3, EHX_MF, fb1, fb0);
         after_revolution();
       }
+      // (the lock-step's store and snapshot load go out BEFORE the epilogue: the rows of tile t are consumed — that is
+      // what the siblings' L2 window is about — and the store, which retires out of order and makes the next counted wait
+      // one entry stricter while it is in flight, gets the epilogue and half a stage to come back: issued after the
+      // epilogue it cost 5 % of the scan time, profiles/r05_l_sync.jsonl)
+      after_tile(t);
       if constexpr (kFused) {
         epi_levels(t);  // (the accumulators are judged inside the next tile's first stage, or after the loop)
       } else {
@@ -933,7 +938,6 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
         epilogue(t);
 #endif
       }
-      after_tile(t);
       // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
       // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
       qsrc = qbase + 3 * kStageI8;
