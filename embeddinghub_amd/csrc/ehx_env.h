@@ -34,6 +34,7 @@ struct Env {
   bool i8_fused = true;           // EHX_I8_FUSED=0: (builds with -DEHX_I8_FUSED=1) the fused epilogue off
   bool i8_qres = true;            // EHX_I8_QRES=0: short rows through the query ring instead of the resident query tile
   bool i8_half = true;            // EHX_I8_HALF=0: rows of <= 128 dims through full-tile workgroups (one per CU)
+  uint32_t i8_skew = 56;          // EHX_I8_SKEW: half-tile workgroups: start skew of a SIMD's second wave, x 64 cycles (0: none)
   bool rerank_staged = true;      // EHX_RERANK_STAGED=0: every lane of the re-rank walks its own row
   // ---- graph mode ----
   uint64_t build_div = 0;         // EHX_BUILD_DIV >= 2: a bulk-build round is at most 1/DIV of the graph it joins
@@ -99,6 +100,10 @@ inline const Env& env() {
     v.i8_fused = flag("EHX_I8_FUSED", true);
     v.i8_qres = flag("EHX_I8_QRES", true);
     v.i8_half = flag("EHX_I8_HALF", true);
+    if (const char* g = str("EHX_I8_SKEW")) {
+      const long x = atol(g);
+      v.i8_skew = (uint32_t)(x < 0 ? 0 : (x > 4096 ? 4096 : x));
+    }
     v.rerank_staged = flag("EHX_RERANK_STAGED", true);
     if (const char* g = str("EHX_BUILD_DIV")) {
       const long x = atol(g);

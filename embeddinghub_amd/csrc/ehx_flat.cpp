@@ -409,6 +409,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   a.n = (uint32_t)s->n;
   a.ld = s->ld8;
   a.q_tiles = p.q_tiles;
+  a.skew = env().i8_skew;
   auto scan = [&](const ScanPlan& pl, uint32_t tile0) -> hipError_t {
     a.tile0 = tile0;
     a.n_tiles = pl.n_tiles;

@@ -609,6 +609,7 @@ struct ScanArgsI8 {
                              // one add per workgroup and ring revolution; sync_tol > 0: [n_chunks][4] progress words,
                              // tiles completed by each of the chunk's (<= 4) query-tile workgroups
   uint32_t sync_tol = 0;     // > 0: a workgroup does not run more than this many TILES ahead of its slowest sibling
+  uint32_t skew = 0;         // half-tile workgroups: the second-resident wave of a SIMD starts skew x 64 cycles late
 };
 // Stage-blocked layout of the int8 scan copy / query tiles: tiles of 256 rows, stages of 64 columns (bytes); one
 // (tile, stage) block is 256 rows x 64 B = 16 KiB in exactly the LDS image of the kernel (16-byte chunk c of row r

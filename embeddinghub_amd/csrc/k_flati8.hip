@@ -636,6 +636,20 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
   uint32_t sync_voff = 0u;
 
   __syncthreads();  // state init visible
+  if constexpr (HALF) {
+    // Two half-tile workgroups share a CU so that one's tile epilogue (vector ALU) runs beside the other's matrix work —
+    // but two identical workgroups launched together run IN PHASE: both in their matrix stages, then both in their
+    // epilogues.  The second-resident wave of every SIMD (hardware wave slot, HW_ID[0]) therefore starts a.skew x 64
+    // cycles late — about half a tile — and the two stay out of phase because they run at the same rate.
+    // Measured (profiles/r05_r_skew.jsonl, 6.25 M x 128, scan phase per batch): skew 0 1.031-1.037 ms, 16 / 32 1.023,
+    // 48 0.987-0.998, 64 0.985, 96 0.996; 1 M x 128: no difference (0.290).  Short chunks are not worth the wait.
+    if (a.skew && my_tiles >= 16u) {
+      uint32_t hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      if (hwid & 1u)
+        for (uint32_t i = 0; i < a.skew; i += 32) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   if (my_tiles > 0) {  // (a chunk past the end of the pass has nothing to scan and must not touch memory)
   // ---- prologue: row parameters of tile 0, stages 0..2 into ring slots 0..2 ----
   if (w < (int)L::kRowpWaves) EHX_DMA(rdst, 0, voff, rsrc);
