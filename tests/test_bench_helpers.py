@@ -186,3 +186,15 @@ def test_host_callers_are_long_lived_threads_that_split_the_batches_and_report_e
     sp.calls.clear()
     one.run([0, 1])
     assert {n for n, _ in sp.calls} == {threading.current_thread().name} and one._threads == []
+
+
+def test_cpu_quota_helpers():
+    """round 5: the cgroup throttle counters bench.py records beside its timed regions, and the BLAS pool cap"""
+    st = bench.cpu_throttle_stat()
+    assert st is None or (len(st) == 2 and st[0] >= 0 and st[1] >= 0)
+    assert bench.throttle_delta(None) is None
+    if st is not None:
+        d = bench.throttle_delta(st)
+        assert set(d) == {"times", "ms"} and d["times"] >= 0 and d["ms"] >= 0.0
+    n = bench.limit_blas_threads()
+    assert n is None or 1 <= n <= max(1, bench.host_cores())
