@@ -354,6 +354,10 @@ struct ehx_space {
   I8Set i8set[2];
   std::atomic<uint64_t> ev_counter{0};
   std::atomic<uint32_t> i8_next_set{0};
+  std::mutex i8_enqueue_mu;  // held while ONE host batch's int8 stage is enqueued on the space's stream (not while its
+                             // verdict is awaited): two callers in different scratch sets must not interleave their
+                             // launches — the batches' kernels would alternate on the stream and every per-batch scan
+                             // time (the timing ring, ehx_stats) would span both
   std::atomic<uint64_t> n_filter_queries{0}, n_filter_fallback{0}, n_exhaustive{0}, n_uncertified_final{0};
   std::atomic<uint64_t> n_i8_queries{0}, n_i8_fallback{0};
   float* hStage = nullptr;  // pinned staging (Set / Get / query upload)

@@ -239,11 +239,13 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
     const int set = (int)(s->i8_next_set.fetch_add(1, std::memory_order_relaxed) & 1u);   // consecutive batches alternate
     ehx_space::I8Set& sc = s->i8set[set];
     std::lock_guard<std::mutex> l(sc.mu);
+    std::unique_lock<std::mutex> ql(s->i8_enqueue_mu);   // (this batch's launches go onto the stream as one block)
     HIP_TRY(hipStreamWaitEvent(s->stream, hs->in_ev, 0));
     if ((rc = flat_pass8(s, set, s->stream, n_queries, hs->dq.p, k, d_ids, d_dist, d_cnt, false, &kprime_used))) return rc;
     HIP_TRY(hipMemcpyAsync(sc.hUncertPin, sc.dUncert, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipEventRecord(sc.verdict, s->stream));
     HIP_TRY(hipEventRecord(hs->done_ev, s->stream));
+    ql.unlock();
     // the results start their way back NOW, before the verdict is known (it is clean for all but a few batches in a
     // thousand): one host wait per batch instead of two in a row — verdict, then copy.  A batch that did lose queries runs
     // the rest of the chain below and copies again (same slot stream: in order, the later copy wins).
