@@ -95,3 +95,21 @@ def test_product_never_imports_oracle():
                     s = line.strip()
                     if s.startswith(("import ", "from ", "#include")):
                         assert "oracle" not in s or "oracle/" in s and s.startswith("//"), (f, s)
+
+
+def test_environment_knobs_live_in_one_table_and_are_documented():
+    """every environment knob of the engine is read once, in csrc/ehx_env.h — nothing else in csrc/ calls
+    getenv — and INTEGRATION.md §7 lists every one of them"""
+    csrc = os.path.join(ROOT, "embeddinghub_amd", "csrc")
+    env_h = open(os.path.join(csrc, "ehx_env.h")).read()
+    knobs = sorted(set(re.findall(r'str\("(EHX_[A-Z0-9_]+)"\)|flag\("(EHX_[A-Z0-9_]+)"', env_h)))
+    knobs = sorted({a or b for a, b in knobs})
+    assert len(knobs) >= 25, knobs
+    for name in sorted(os.listdir(csrc)):
+        if name == "ehx_env.h" or not name.endswith((".cpp", ".hip", ".h")):
+            continue
+        src = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, name)).read())   # (comments may mention it)
+        assert "getenv(" not in src, "%s calls getenv: knobs belong in ehx_env.h" % name
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [k for k in knobs if "`%s`" % k not in doc]
+    assert not missing, "INTEGRATION.md §7 does not list %s" % missing
