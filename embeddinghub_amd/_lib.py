@@ -30,7 +30,8 @@ class Params(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("M", C.c_uint32), ("ef_construction", C.c_uint32),
                 ("ef", C.c_uint32), ("seed", C.c_uint64), ("initial_capacity", C.c_uint64),
                 ("build_batch", C.c_uint32), ("scan", C.c_uint32), ("shards", C.c_uint32),
-                ("reserved", C.c_uint32 * 5)]
+                ("search_width", C.c_uint32),
+                ("reserved", C.c_uint32 * 4)]
 
 
 class Stats(C.Structure):
@@ -61,6 +62,7 @@ SYMBOLS = {
     "ehx_space_dims": (C.c_int, [_vp, _u32p]),
     "ehx_space_reserve": (C.c_int, [_vp, C.c_uint64]),
     "ehx_space_set_ef": (C.c_int, [_vp, C.c_uint32]),
+    "ehx_space_set_search_width": (C.c_int, [_vp, C.c_uint32]),
     "ehx_space_set_scan": (C.c_int, [_vp, C.c_uint32]),
     "ehx_space_scan_engine": (C.c_int, [_vp, _u32p]),
     "ehx_set": (C.c_int, [_vp, C.c_char_p, C.c_size_t, _f32p]),

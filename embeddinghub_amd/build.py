@@ -11,7 +11,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libehx%s.so" % os.environ.get("EHX_LIB_SUFFIX", ""))  # suffix: ablation builds
 SOURCES = ["ehx_api.cpp", "ehx_space.cpp", "ehx_flat.cpp", "ehx_graph.cpp", "ehx_shards.cpp", "ehx_write.cpp", "ehx_search.cpp",
            "k_flat.hip", "k_flat8.hip", "k_flat16.hip", "k_flati8.hip", "k_select.hip", "k_misc.hip",
-           "k_graph.hip", "k_insert.hip"]
+           "k_graph.hip", "k_graphw.hip", "k_insert.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),

@@ -112,6 +112,8 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
       return fail(EHX_EUNSUPPORTED, "graph mode: M=%u outside [2, 32]", s->params.M);
   }
   if (s->params.scan > EHX_SCAN_F16) return fail(EHX_EINVAL, "unknown scan engine %u", s->params.scan);
+  if (!(s->params.search_width <= 2 || s->params.search_width == 4))
+    return fail(EHX_EINVAL, "search_width %u: 0, 1, 2 or 4", s->params.search_width);
   {
     const bool env_f32 = env().scan_f32;  // EHX_SCAN=f32: every space scans in fp32 (A/B runs, profiling)
     const bool env_f16 = env().scan_f16;  // EHX_SCAN=f16: no int8 scan copy (A/B runs)
@@ -314,6 +316,18 @@ int ehx_space_set_ef(ehx_space* s, uint32_t ef) {
   s->params.ef = ef;
   for (ehx_space* c : s->shards) {
     int rc = ehx_space_set_ef(c, ef);
+    if (rc) return rc;
+  }
+  return EHX_OK;
+}
+
+int ehx_space_set_search_width(ehx_space* s, uint32_t width) {
+  if (!valid_space(s) || !(width <= 2 || width == 4)) return fail(EHX_EINVAL, "search_width must be 0, 1, 2 or 4");
+  std::unique_lock<std::shared_mutex> wl(s->mu);
+  if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
+  s->params.search_width = width;
+  for (ehx_space* c : s->shards) {
+    int rc = ehx_space_set_search_width(c, width);
     if (rc) return rc;
   }
   return EHX_OK;

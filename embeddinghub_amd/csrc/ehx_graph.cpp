@@ -450,6 +450,15 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   a.entry_point = s->g_entry;
   a.max_level = s->g_maxlevel;
   a.metric = s->metric;
+  // The wide walk expands `width` entries of a list of ef at once: with a short list that is a large share of it, and the
+  // walk fetches rows the strict order would have pruned (200 k x 768 structured rows, ef 10 / 20 / 40, rows fetched against
+  // the strict walk: width 2 +9 / +4 / +2 %, width 4 +30 / +16 / +7 %; profiles/r06_b_wide_gate.jsonl; 6.25 M x 128, ef 50:
+  // width 4 fetches 9 % more rows than width 2 for the same kernel time, profiles/r06_d_graph_6250k128.jsonl).  Hence
+  // two expansions per step from ef = 16 on, four from ef = 64 on; ef < 16 — the reference's default ef = 10 among them —
+  // is always walked strictly.
+  a.width = env().graph_width ? env().graph_width : (s->params.search_width > 1 ? s->params.search_width : 1);
+  if (a.width >= 4 && ef < 64) a.width = 2;
+  if (a.width >= 2 && ef < 16) a.width = 1;
   if (one) {
     a.q_raw = one->q_host;
     a.done_flag = one->done_flag;

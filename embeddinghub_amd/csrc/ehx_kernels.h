@@ -433,6 +433,31 @@ __device__ __forceinline__ void canon_dist_group_pair(const float* __restrict__ 
   }
 }
 
+// Four rows of exactly 16 * N16 floats (N16 <= 8: rows of up to 128 dims) by one 4-lane group, all 4 * N16 loads of the lane
+// in flight before the first product: 64 rows per pass of a wave (the wide graph walk, k_graphw.hip, evaluates up to 64
+// fresh rows per merge — one memory round trip instead of two).  Same arithmetic and order per row as canon_dist_group_t.
+template <int METRIC01, int N16, bool SCALE = false>
+__device__ __forceinline__ void canon_dist_group_quad(const float* __restrict__ qp, const float* const (&x)[4], int sub,
+                                                      float (&res)[4], const float (&sc)[4]) {
+  const float4* q4 = (const float4*)qp + sub;
+  float4 r[4][N16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4* x4 = (const float4*)x[j] + sub;
+#pragma unroll
+    for (int i = 0; i < N16; ++i) r[j][i] = x4[i * 4];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float p = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N16; ++i) canon_group_step<METRIC01, SCALE>(r[j][i], q4[i * 4], p, 4, sc[j]);
+    const float t0 = __shfl(p, 0, 4), t1 = __shfl(p, 1, 4), t2 = __shfl(p, 2, 4), t3 = __shfl(p, 3, 4);
+    res[j] = ex_add(ex_add(ex_add(t0, t1), t2), t3);
+    if (METRIC01 != 0) res[j] = ex_sub(1.0f, res[j]);
+  }
+}
+
 // Canonical distances of the search-copy rows ids_l[0..count) (LDS) to the permuted query qs (LDS), by one wave:
 // lane p (< count) returns the distance of row p, other lanes +inf.  16 rows per pass, one 4-lane group per row
 // (canon_dist_group_t); rows of 32 / 64 / 96 / 128 / 192 / 256 dims go 32 per pass, two per group, with the loads
@@ -440,12 +465,37 @@ __device__ __forceinline__ void canon_dist_group_pair(const float* __restrict__ 
 // one memory round trip per expansion instead of two (6.25 M x 128-class workloads: -20 % kernel time).
 // xscale (optional): per-row scale applied to the row's elements on the fly (single-copy graph spaces, cosine:
 // inv_norm) — nullptr: the rows are used as stored.
-template <int METRIC01, bool SCALE>
+// QUAD (the wide graph walk): more than 32 rows of 32 / 64 / 96 / 128 dims go 64 per pass, four per group.
+template <int METRIC01, bool SCALE, bool QUAD = false>
 __device__ __forceinline__ float wave_group_dists_t(const float* __restrict__ qs, const float* __restrict__ Xs, uint32_t ld,
                                                     uint32_t dims, const uint32_t* ids_l, uint32_t count, int lane,
                                                     const float* __restrict__ xscale) {
   float mine = __builtin_inff();
   const bool pairable = dims <= 256 && (dims == 32 || dims == 64 || dims == 96 || dims == 128 || dims == 192 || dims == 256);
+  if (QUAD && pairable && dims <= 128 && count > 32) {   // (count <= 64: one pass)
+    const uint32_t r0 = (uint32_t)lane >> 2;
+    const float* x[4];
+    float sc[4], res[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t rj = r0 + 16u * (uint32_t)j;
+      const uint32_t id = ids_l[rj < count ? rj : r0];   // a missing row: the group's first one again, result dropped
+      sc[j] = SCALE ? __hip_atomic_load(xscale + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 1.0f;
+      x[j] = Xs + (size_t)id * ld;
+    }
+    const int sub = lane & 3;
+    switch (dims) {
+      case 32: canon_dist_group_quad<METRIC01, 2, SCALE>(qs, x, sub, res, sc); break;
+      case 64: canon_dist_group_quad<METRIC01, 4, SCALE>(qs, x, sub, res, sc); break;
+      case 96: canon_dist_group_quad<METRIC01, 6, SCALE>(qs, x, sub, res, sc); break;
+      default: canon_dist_group_quad<METRIC01, 8, SCALE>(qs, x, sub, res, sc); break;
+    }
+    const int src = (lane & 15) << 2;
+    const float g0 = __shfl(res[0], src, 64), g1 = __shfl(res[1], src, 64), g2 = __shfl(res[2], src, 64),
+                g3 = __shfl(res[3], src, 64);
+    if ((uint32_t)lane < count) mine = (lane & 32) ? ((lane & 16) ? g3 : g2) : ((lane & 16) ? g1 : g0);
+    return mine;
+  }
   if (pairable && count > 16) {
     for (uint32_t base = 0; base < count; base += 32) {
       const uint32_t ra = base + ((uint32_t)lane >> 2), rb = ra + 16;
@@ -489,12 +539,12 @@ __device__ __forceinline__ float wave_group_dists_t(const float* __restrict__ qs
   }
   return mine;
 }
-template <int METRIC01>
+template <int METRIC01, bool QUAD = false>
 __device__ __forceinline__ float wave_group_dists(const float* __restrict__ qs, const float* __restrict__ Xs, uint32_t ld,
                                                   uint32_t dims, const uint32_t* ids_l, uint32_t count, int lane,
                                                   const float* __restrict__ xscale = nullptr) {
-  if (METRIC01 == 1 && xscale) return wave_group_dists_t<METRIC01, true>(qs, Xs, ld, dims, ids_l, count, lane, xscale);
-  return wave_group_dists_t<METRIC01, false>(qs, Xs, ld, dims, ids_l, count, lane, nullptr);
+  if (METRIC01 == 1 && xscale) return wave_group_dists_t<METRIC01, true, QUAD>(qs, Xs, ld, dims, ids_l, count, lane, xscale);
+  return wave_group_dists_t<METRIC01, false, QUAD>(qs, Xs, ld, dims, ids_l, count, lane, nullptr);
 }
 
 // runtime-dispatch form (metric: 0 = L2^2, 1 = 1 - inner product; scale_x: cosine rows) used by the
@@ -797,7 +847,7 @@ hipError_t launch_gen_rows(uint64_t seed, uint64_t row0, uint64_t n_rows, uint32
                            int normalize, float* out, hipStream_t st, uint64_t row_stride = 1);
 
 // graph-mode search (k_graph.hip): one wave per query
-constexpr uint32_t kGraphCounters = 12;  // n_dist, n_hops0, n_hops_up, n_prefetch_hit, [4..11] profile builds
+constexpr uint32_t kGraphCounters = 12;  // n_dist, n_hops0, n_hops_up, n_prefetch_hit, [4..11] profile builds (wide walk: [4] = steps)
 struct GraphArgs {
   const float* Q;           // prepared queries [nq][ld]
   const float* X;           // rows [cap][ld]
@@ -822,8 +872,12 @@ struct GraphArgs {
   const float* q_raw = nullptr;
   uint32_t* done_flag = nullptr;
   uint32_t seq = 0;
+  // Expansions per step of the level-0 search (ehx_params.search_width): 1 = the strict walk (hnswlib's order, one node at
+  // a time: graph_search_kernel); 2 / 4 = the wide walk (k_graphw.hip: the `width` closest unexpanded entries of the
+  // result list are expanded together — same ef bound and termination, fewer dependent memory round trips per query).
+  uint32_t width = 1;
 };
-size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap);
+size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap, uint32_t width = 1);
 hipError_t launch_graph_search(const GraphArgs& a, hipStream_t st);
 
 // graph-mode insertion (k_insert.hip)

@@ -28,108 +28,16 @@
 //     words when it is done — a few thousand stores instead of a 1.3-GB memset per batch (a query that outgrows
 //     its log clears its whole bitmap instead);
 //   * work counters as SURVEY §8d: n_dist = rows actually fetched, n_hops0 / n_hops_up = expansions.
-#include "ehx_env.h"
-#include "ehx_kernels.h"
-#include "k_prep_query.h"
+#include "k_graph_common.h"
 
 namespace ehx {
 
-namespace {
-
-constexpr uint32_t kNoNode = 0xFFFFFFFFu;
-
-// -DEHX_GRAPH_PROFILE (ablation builds, scripts/gpu_graph_profile.sh): per-phase wall-clock ticks (100 MHz)
-// of the level-0 loop, summed over all query waves into counters[4..11]: pick next node | adjacency +
-// visited | row fetch + distances | rank fresh keys | decide next + request | insertion points | move R | tail.
-// A/B switches of the level-0 loop (ablation builds only; the defaults are the shipped kernel)
-#ifndef EHX_G_COOP
-#define EHX_G_COOP 1        // rows read by 4-lane groups from the search copy (coalesced 64-byte pieces) instead of
-#endif                      // one private row of X per lane
-#ifndef EHX_G_NEXT_EARLY
-#define EHX_G_NEXT_EARLY 1  // decide the next node before the merge and request its adjacency / visited words there
-#endif
-
-#ifndef EHX_G_WSYNC
-#define EHX_G_WSYNC 1       // one wave per workgroup: LDS accesses of a wave execute in order, so a compiler-level
-#endif                      // fence orders write -> read across lanes; no s_barrier, no drain of the LDS queue
-#ifndef EHX_G_UNIFORM
-#define EHX_G_UNIFORM 1     // wave-uniform values that come out of a shuffle or LDS are moved to scalar registers
-#endif                      // (readfirstlane): the loop bookkeeping then runs on the scalar unit, with scalar branches
-
-#if EHX_G_WSYNC
-#define EHX_GSYNC() wave_lds_sync()
-#else
-#define EHX_GSYNC() __syncthreads()
-#endif
-
-#if EHX_G_UNIFORM
-#define EHX_UNIFORM(x) wave_uniform((uint32_t)(x))
-#else
-#define EHX_UNIFORM(x) ((uint32_t)__shfl((int)(x), 0, 64))
-#endif
-
-#ifdef EHX_GRAPH_PROFILE
-#define EHX_PROF_DECL unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t_ = wall_clock64()
-#define EHX_PROF(i)                              \
-  {                                              \
-    const unsigned long long now_ = wall_clock64(); \
-    prof_[i] += now_ - prof_t_;                  \
-    prof_t_ = now_;                              \
-  }
-#else
-#define EHX_PROF_DECL
-#define EHX_PROF(i)
-#endif
-
-__device__ __forceinline__ uint64_t wave_sort64g(uint64_t key, int lane) {
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const uint64_t other = __shfl_xor(key, j, 64);
-      const bool up = (lane & k) == 0;
-      const bool lower = (lane & j) == 0;
-      const uint64_t mn = key < other ? key : other;
-      const uint64_t mx = key < other ? other : key;
-      key = (lower == up) ? mn : mx;
-    }
-  }
-  return key;
-}
-
-// number of entries of the ascending array a[0..n) that are < key
-// Prefetch-style load: a relaxed atomic load (wavefront scope: no cache-policy bits) is an ordered memory
-// reference for the compiler, so it is issued where it is written — a plain load whose first use comes an
-// LDS-heavy phase later is a candidate for the compiler's code sinking, which would expose the HBM round
-// trip the early issue is meant to overlap.
-__device__ __forceinline__ uint32_t load_here(const uint32_t* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-
-// value of a 64-bit register in lane l (wave-uniform l)
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
-  return ((uint64_t)hi << 32) | lo;
-}
-
-__device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* a, uint32_t n, uint64_t key) {
-  uint32_t lo = 0, hi = n;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (a[mid] < key) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo;
-}
-
-}  // namespace
-
 // LDS: q[ld] floats | R[ef_cap] u64 | S[64] u64 (sorted fresh keys) | batch[64] u64 | ids[64] u32 |
 //      F[ef_cap] u8 (slots of R a fresh key lands on, during a merge)
-//      then (two-wave form) hd[64] f32 (the helper wave's distances) | ctrl[4] u32
-size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap) {
-  return (size_t)ld * 4 + (size_t)ef_cap * 8 + 64 * 8 * 2 + 64 * 4 + (((size_t)ef_cap + 15) & ~(size_t)15) + 64 * 4 + 16;
+// (the wide walk, k_graphw.hip, holds 32 ids per expansion of a step: ids[32 * width])
+size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap, uint32_t width) {
+  const size_t n_ids = width > 2 ? 32 * (size_t)width : 64;
+  return (size_t)ld * 4 + (size_t)ef_cap * 8 + 64 * 8 * 2 + n_ids * 4 + (((size_t)ef_cap + 15) & ~(size_t)15) + 64;
 }
 
 // A/B builds: cap the registers so that this many waves share a SIMD (0 = the compiler's choice).  Measured in round 3:
@@ -138,20 +46,17 @@ size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap) {
 #ifndef EHX_GRAPH_WAVES
 #define EHX_GRAPH_WAVES 0
 #endif
-// WAVES = 2 (round 4, VERDICT r01-r03 "intra-query parallelism"): a HELPER wave per query.  At batch 1024 a SIMD holds
-// one query wave and long rows take two passes of 16 rows per expansion (27 fresh neighbours on average, one 4-lane
-// group per row): the row phase is ~70 % of an expansion at d = 768.  The helper takes rows 16.. of every distance batch
-// — the same 4-lane-group arithmetic on the same rows, so traversal, ids, distances and counters stay bit-identical —
-// and the two passes run side by side on two SIMDs.  Protocol: wave 0 publishes (ids_l, count), barrier, both compute,
-// barrier, wave 0 reads the helper's distances from LDS.  Everything else (R, visited, merge) is wave 0's alone.
-template <int METRIC01, bool SCALE, int WAVES>
+// (Round 4 built a HELPER wave per query — rows 16.. of every distance batch on a second SIMD, same arithmetic, bit-identical
+// — and measured -1..2 % at batch 1024, +1..3 % at 2048 (profiles/r04_j_graph_*_helper{0,1}.jsonl): the row phase is bound
+// by the memory system, not by the loads one wave keeps in flight.  Removed in round 6; the lever that pays at batch 1024 is
+// fewer dependent steps per query: k_graphw.hip.)
+template <int METRIC01, bool SCALE>
 #if EHX_GRAPH_WAVES
 __attribute__((amdgpu_waves_per_eu(EHX_GRAPH_WAVES, EHX_GRAPH_WAVES)))
 #endif
-__global__ __launch_bounds__(64 * WAVES) void graph_search_kernel(const GraphArgs a) {
+__global__ __launch_bounds__(64) void graph_search_kernel(const GraphArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t qi = blockIdx.x;
   float* qs = (float*)smem;
   uint64_t* R = (uint64_t*)(smem + (size_t)a.ld * 4);
@@ -159,15 +64,12 @@ __global__ __launch_bounds__(64 * WAVES) void graph_search_kernel(const GraphArg
   uint64_t* batch = S + 64;
   uint32_t* ids_l = (uint32_t*)(batch + 64);
   uint8_t* F = (uint8_t*)(ids_l + 64);
-  float* hd = (float*)(F + (((size_t)a.ef_cap + 15) & ~(size_t)15));
-  volatile uint32_t* ctrl = (volatile uint32_t*)(hd + 64);
   uint32_t* vis = a.visited + (size_t)qi * a.vis_words;
   uint32_t* vlog = a.vislog + (size_t)qi * a.vislog_cap;
   uint32_t n_logged = 0;  // rows marked visited so far (wave-uniform)
-  if (wv == 0)
-    for (uint32_t i = lane; i < a.ef_cap; i += 64) F[i] = 0;
+  for (uint32_t i = lane; i < a.ef_cap; i += 64) F[i] = 0;
 
-  if (WAVES == 1 && a.q_raw) {
+  if (a.q_raw) {
     // one query per call, one launch: the raw query comes from host-visible memory and is prepared here, by this wave,
     // into the device scratch row the loads below read (the same arithmetic as prep_queries_kernel: identical bytes)
     prep_query_row(a.q_raw, 1u, a.dims, a.ld, a.metric, const_cast<float*>(a.Q), 0u, lane);
@@ -175,27 +77,11 @@ __global__ __launch_bounds__(64 * WAVES) void graph_search_kernel(const GraphArg
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   }
 #if EHX_G_COOP
-  for (uint32_t i = threadIdx.x; i < a.ld; i += 64 * WAVES) qs[search_copy_pos(i)] = a.Q[(size_t)qi * a.ld + i];
+  for (uint32_t i = lane; i < a.ld; i += 64) qs[search_copy_pos(i)] = a.Q[(size_t)qi * a.ld + i];
 #else
-  for (uint32_t i = threadIdx.x; i < a.ld; i += 64 * WAVES) qs[i] = a.Q[(size_t)qi * a.ld + i];
+  for (uint32_t i = lane; i < a.ld; i += 64) qs[i] = a.Q[(size_t)qi * a.ld + i];
 #endif
-  if (WAVES > 1) __syncthreads();
-  else EHX_GSYNC();
-#if EHX_G_COOP
-  if (WAVES > 1 && wv == 1) {  // the helper wave: rows 16.. of every distance batch wave 0 publishes
-    for (;;) {
-      __syncthreads();  // A: ids_l and the count are published
-      const uint32_t cnt = ctrl[0];
-      if (cnt == 0xFFFFFFFFu) break;
-      if (cnt > 16) {
-        const float d = wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l + 16, cnt - 16, lane, a.xscale);
-        if ((uint32_t)lane < cnt - 16) hd[lane] = d;
-      }
-      __syncthreads();  // B: the distances are published
-    }
-    return;
-  }
-#endif
+  EHX_GSYNC();
 
   unsigned long long n_dist = 0, n_hops0 = 0, n_hops_up = 0;
 
@@ -205,14 +91,6 @@ __global__ __launch_bounds__(64 * WAVES) void graph_search_kernel(const GraphArg
   // canonical distances of rows ids_l[0..count): 16 rows per pass, one 4-lane group per row reading the
   // search copy (canon_dist_group_t); lane p (< count) gets the distance of row p
   auto lane_dist = [&](uint32_t count) -> float {
-    if (WAVES > 1) {
-      if (lane == 0) ctrl[0] = count;
-      __syncthreads();  // A
-      float d = wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l, count < 16 ? count : 16, lane, a.xscale);
-      __syncthreads();  // B
-      if (lane >= 16 && (uint32_t)lane < count) d = hd[lane - 16];
-      return d;
-    }
     return wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l, count, lane, a.xscale);
   };
 #else
@@ -487,10 +365,6 @@ __global__ __launch_bounds__(64 * WAVES) void graph_search_kernel(const GraphArg
     EHX_PROF(7)
   }
 
-  if (WAVES > 1) {  // release the helper wave
-    if (lane == 0) ctrl[0] = 0xFFFFFFFFu;
-    __syncthreads();
-  }
   // ---- leave the visited bitmap all-zero: clear the words of the logged rows (or everything, if the log overflowed)
   // (the log was written by other lanes, through global memory: a real fence, once per query)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -526,31 +400,19 @@ __global__ __launch_bounds__(64 * WAVES) void graph_search_kernel(const GraphArg
   }
 }
 
+hipError_t launch_graph_search_wide(const GraphArgs& a, hipStream_t st);  // k_graphw.hip
+
 hipError_t launch_graph_search(const GraphArgs& a, hipStream_t st) {
-  const size_t lds = graph_lds_bytes(a.ld, a.ef_cap);
+  // the wide walk serves lists of up to 32 ids (M <= 16: one half wave per expanded node)
+  if (a.width > 1 && a.M0 <= 32) return launch_graph_search_wide(a, st);
+  const size_t lds = graph_lds_bytes(a.ld, a.ef_cap, 1);
   static DynLdsAttr attr;
-  const void* fns[6] = {(const void*)graph_search_kernel<0, false, 1>, (const void*)graph_search_kernel<1, true, 1>,
-                        (const void*)graph_search_kernel<1, false, 1>, (const void*)graph_search_kernel<0, false, 2>,
-                        (const void*)graph_search_kernel<1, true, 2>, (const void*)graph_search_kernel<1, false, 2>};
-  if (hipError_t e = attr.ensure(fns, 6, lds); e != hipSuccess) return e;
-  // The helper wave (EHX_GRAPH_HELPER=1) is OFF by default: measured on GPU-built indexes, same box, batch 1024
-  // (profiles/r04_j_graph_*_helper{0,1}.jsonl): 2 M x 768 ef 100 2.311 -> 2.257 ms, ef 400 7.83 -> 7.74 ms, 1 M x 384
-  // ef 200 2.094 -> 2.057 ms (-1..2 %), batch 2048 +1..3 %.  Splitting an expansion's row fetches over two waves does not
-  // shorten them: at 3-KB rows the kernel already moves 4.7-5.1 TB/s of RANDOM rows, 80-86 % of what the part delivers
-  // for that access pattern with every SIMD full of gather waves (scripts/ubench/gather_rows.hip: 5.9 TB/s) — the row
-  // phase is bound by the memory system, not by how many loads one wave keeps in flight.
-  const int helper_env = env().graph_helper;
-  const bool pairable = a.dims <= 256 && (a.dims == 32 || a.dims == 64 || a.dims == 96 || a.dims == 128 || a.dims == 192 || a.dims == 256);
-  const bool helper = helper_env != 0 && !pairable && a.nq <= 2048;
-  if (helper) {
-    if (a.metric == 0) hipLaunchKernelGGL((graph_search_kernel<0, false, 2>), dim3(a.nq), dim3(128), lds, st, a);
-    else if (a.metric == 2) hipLaunchKernelGGL((graph_search_kernel<1, true, 2>), dim3(a.nq), dim3(128), lds, st, a);
-    else hipLaunchKernelGGL((graph_search_kernel<1, false, 2>), dim3(a.nq), dim3(128), lds, st, a);
-  } else {
-    if (a.metric == 0) hipLaunchKernelGGL((graph_search_kernel<0, false, 1>), dim3(a.nq), dim3(64), lds, st, a);
-    else if (a.metric == 2) hipLaunchKernelGGL((graph_search_kernel<1, true, 1>), dim3(a.nq), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((graph_search_kernel<1, false, 1>), dim3(a.nq), dim3(64), lds, st, a);
-  }
+  const void* fns[3] = {(const void*)graph_search_kernel<0, false>, (const void*)graph_search_kernel<1, true>,
+                        (const void*)graph_search_kernel<1, false>};
+  if (hipError_t e = attr.ensure(fns, 3, lds); e != hipSuccess) return e;
+  if (a.metric == 0) hipLaunchKernelGGL((graph_search_kernel<0, false>), dim3(a.nq), dim3(64), lds, st, a);
+  else if (a.metric == 2) hipLaunchKernelGGL((graph_search_kernel<1, true>), dim3(a.nq), dim3(64), lds, st, a);
+  else hipLaunchKernelGGL((graph_search_kernel<1, false>), dim3(a.nq), dim3(64), lds, st, a);
   return hipGetLastError();
 }
 

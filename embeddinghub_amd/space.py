@@ -23,7 +23,7 @@ def _f32(a):
 class Space:
     def __init__(self, name, dims, metric=_lib.METRIC_L2SQ, mode=_lib.MODE_FLAT, M=0, ef_construction=0,
                  ef=0, seed=0, initial_capacity=0, build_batch=0, dtype=_lib.DTYPE_F32, scan=_lib.SCAN_AUTO, shards=0,
-                 _handle=None):
+                 search_width=0, _handle=None):
         self._L = _lib.load()
         self.name, self.dims, self.metric = name, int(dims), metric
         self._M = M or 16
@@ -31,7 +31,8 @@ class Space:
             self._h = _handle
             return
         p = Params(mode=mode, M=M, ef_construction=ef_construction, ef=ef, seed=seed,
-                   initial_capacity=initial_capacity, build_batch=build_batch, scan=scan, shards=shards)
+                   initial_capacity=initial_capacity, build_batch=build_batch, scan=scan, shards=shards,
+                   search_width=search_width)
         h = C.c_void_p()
         nm = name.encode()
         check(self._L.ehx_space_create(nm, len(nm), self.dims, metric, dtype, C.byref(p), C.byref(h)))
@@ -141,6 +142,10 @@ class Space:
 
     def set_ef(self, ef):
         check(self._L.ehx_space_set_ef(self._h, ef))
+
+    def set_search_width(self, width):
+        """graph spaces: level-0 expansions per search step (1 = the strict, hnswlib-order walk; 2 / 4 = the wide walk)"""
+        check(self._L.ehx_space_set_search_width(self._h, width))
 
     def set_scan(self, scan):
         check(self._L.ehx_space_set_scan(self._h, scan))

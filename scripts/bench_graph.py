@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--efs", default="10,50,200")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--widths", default="1",
+                    help="comma list of ehx_params.search_width values measured on the same index: 1 = the strict "
+                         "(hnswlib-order) walk, 2 / 4 = the wide walk (k_graphw.hip)")
     ap.add_argument("--gpu-build", action="store_true", help="build the graph on the GPU (batched insertion); no oracle")
     ap.add_argument("--build-batch", type=int, default=0)
     ap.add_argument("--data", default="gauss",
@@ -105,8 +108,9 @@ def main():
     Q_all, truth_all = Q, truth
     for B in batches:
         Q, truth = Q_all[:B], truth_all[:B]
-        for ef in [int(x) for x in args.efs.split(",")]:
+        for ef, width in [(int(x), int(w)) for x in args.efs.split(",") for w in args.widths.split(",")]:
             g.set_ef(ef)
+            g.set_search_width(width)
             if h is not None:
                 h.set_ef(ef)
             ids, dist, cnt = g.knn(Q, k)  # warm-up
@@ -131,6 +135,7 @@ def main():
             print(json.dumps({
                 "workload": "%dx%d %s, graph (%s, M=16 efC=200, build %.1fs), batch=%d k=%d ef=%d" % (
                     n, d, args.metric, builder, build_s, B, k, ef),
+                "search_width": width, "expansions_per_step": round(gc[1] / gc[4], 3) if width > 1 and gc[4] else 1.0,
                 "qps_host_pointers": round(B / wall, 1), "qps_kernel": round(B / (kern_ms * 1e-3), 1),
                 "kernel_ms": round(kern_ms, 4), "recall_at_k": round(recall, 4), "oracle_recall_at_k": orecall,
                 "queries_identical_to_oracle": same,
@@ -140,7 +145,10 @@ def main():
                 # -DEHX_GRAPH_PROFILE builds only: mean microseconds per level-0 expansion spent in
                 # (pick next node, adjacency + visited, row fetch + distances, rank fresh keys, decide next + request,
                 #  insertion points, move R, tail)
-                "phase_us_per_hop": [round(v / 100.0 / max(gc[1], 1), 3) for v in gc[4:12]] if gc[4] else None,
+                "phase_us_per_hop": [round(v / 100.0 / max(gc[1], 1), 3) for v in gc[4:12]] if gc[4] and width <= 1 else None,
+                # wide walk, -DEHX_GRAPH_PROFILE builds: microseconds per STEP spent in (pick, adjacency + visited +
+                # compaction, row fetch + distances, rank + prediction, insertion points, move R, rest)
+                "phase_us_per_step": [round(v / 100.0 / max(gc[4], 1), 3) for v in gc[5:12]] if width > 1 and gc[5] else None,
                 "bytes_per_query": round(bytes_q, 1),
                 "roofline": {"bound": "hbm", "achieved": round(bytes_q * B / (kern_ms * 1e-3) / 1e9, 2), "peak": 8000.0,
                              "unit": "GB/s", "frac": round(bytes_q * B / (kern_ms * 1e-3) / 8e12, 5)},

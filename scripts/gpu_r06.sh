@@ -1,0 +1,63 @@
+#!/bin/bash
+# Round 6 GPU sessions, ONE parametrised runner (no more one-file-per-session scripts):
+#     gpurun --timeout N -- 'bash scripts/gpu_r06.sh <session>'
+# Every session writes under gpurun_out/ (merged back by gpurun); what is to be judged is copied into profiles/r06_<session>_*.
+export TMPDIR=/tmp
+S=$1
+O=gpurun_out
+mkdir -p $O
+graph_bench() {  # tag rows dims metric efs widths [extra args]
+  local tag=$1 rows=$2 dims=$3 metric=$4 efs=$5 widths=$6; shift 6
+  timeout 1500 python scripts/bench_graph.py --gpu-build --rows $rows --dims $dims --metric $metric --efs $efs --widths $widths "$@" \
+    > $O/r06_${S}_graph_${tag}.jsonl 2> $O/r06_${S}_graph_${tag}.err
+  python - <<PY
+import json
+for l in open("$O/r06_${S}_graph_${tag}.jsonl"):
+    r = json.loads(l)
+    print("%-8s ef=%-5s w=%d B=%s kern %.4f ms frac %.3f recall %.4f rows/q %.0f exp/step %.2f pf %.2f" % (
+        "$tag", r["workload"].split("ef=")[1], r["search_width"], r["workload"].split("batch=")[1].split()[0], r["kernel_ms"],
+        r["roofline"]["frac"], r["recall_at_k"], r["n_dist_per_query"], r["expansions_per_step"], r["prefetch_hit_rate"]))
+PY
+}
+case "$S" in
+a)  # first light of the wide walk: model parity, contract, strict parity untouched, then the two VERDICT shapes
+  timeout 1200 python -m pytest tests/test_graph_wide.py -x -q -k "models_walk or contract" 2>&1 | tail -15
+  timeout 900 python -m pytest tests/test_graph_parity.py tests/test_fuzz_graph.py -x -q 2>&1 | tail -5
+  graph_bench 6250k128 6250000 128 l2 50,200,800 1,2,4
+  graph_bench 2m768 2000000 768 cosine 100,400 1,2,4
+  ;;
+b)  # the recall gate at scale
+  EHX_SCALE_REPORT=$O/r06_b_wide_gate.jsonl timeout 2400 python -m pytest tests/test_graph_wide.py -x -q -k "gate" -s 2>&1 | tail -15
+  ;;
+c)  # where a step's time goes: phase timers (-DEHX_GRAPH_PROFILE build) on the two shapes
+  export EHX_LIB=$PWD/embeddinghub_amd/lib/libehx_gprof.so
+  graph_bench 6250k128_gprof 6250000 128 l2 200 1,2,4
+  graph_bench 2m768_gprof 2000000 768 cosine 400 1,2,4
+  python - <<PY
+import json, glob
+for f in sorted(glob.glob("$O/r06_c_graph_*_gprof.jsonl")):
+    for l in open(f):
+        r = json.loads(l)
+        print(f.split("graph_")[1][:12], "w=%d" % r["search_width"], "per hop" if r["phase_us_per_hop"] else "per step", r["phase_us_per_hop"] or r["phase_us_per_step"])
+PY
+  ;;
+d)  # the wide walk with 64 rows per distance pass on short rows, entering keys compacted before the ranking, width <= ef / 8
+  timeout 1200 python -m pytest tests/test_graph_wide.py -x -q -k "models_walk or contract" 2>&1 | tail -5
+  graph_bench 6250k128 6250000 128 l2 50,200,800 1,2,4
+  EHX_LIB=$PWD/embeddinghub_amd/lib/libehx_gprof.so graph_bench 6250k128_gprof 6250000 128 l2 200 2,4
+  python - <<PY
+import json
+for l in open("$O/r06_d_graph_6250k128_gprof.jsonl"):
+    r = json.loads(l)
+    print("w=%d" % r["search_width"], "per step", r["phase_us_per_step"])
+PY
+  EHX_SCALE_REPORT=$O/r06_d_wide_gate.jsonl timeout 2400 python -m pytest tests/test_graph_wide.py -x -q -k "gate" 2>&1 | tail -5
+  ;;
+e)  # A/B: early touch of the next step's visited words (EHX_GW_WARM), same box, same index shape
+  timeout 600 python -m pytest tests/test_graph_wide.py -x -q -k "models_walk" 2>&1 | tail -3
+  graph_bench 6250k128_warm 6250000 128 l2 50,200,800 2,4
+  EHX_LIB=$PWD/embeddinghub_amd/lib/libehx_nowarm.so graph_bench 6250k128_nowarm 6250000 128 l2 50,200,800 2,4
+  graph_bench 6250k128_warm2 6250000 128 l2 50,200,800 2,4
+  ;;
+*) echo "unknown session $S"; exit 2;;
+esac

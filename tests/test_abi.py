@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.ehx_abi_version() == 4
+    assert lib.ehx_abi_version() == 5
 
 
 def test_struct_layouts_match_header(tmp_path):
