@@ -63,6 +63,8 @@ SYMBOLS = {
     "ehx_space_reserve": (C.c_int, [_vp, C.c_uint64]),
     "ehx_space_set_ef": (C.c_int, [_vp, C.c_uint32]),
     "ehx_space_set_search_width": (C.c_int, [_vp, C.c_uint32]),
+    "ehx_fill_manifold": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int]),
+    "ehx_gen_manifold_rows_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _vp]),
     "ehx_space_set_scan": (C.c_int, [_vp, C.c_uint32]),
     "ehx_space_scan_engine": (C.c_int, [_vp, _u32p]),
     "ehx_set": (C.c_int, [_vp, C.c_char_p, C.c_size_t, _f32p]),

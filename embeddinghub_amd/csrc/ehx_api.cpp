@@ -3,6 +3,7 @@
 // No vector arithmetic happens on the host: if the device is unavailable every compute entry point fails with
 // EHX_ENODEVICE.
 #include "ehx_internal.h"
+#include "../../include/ehx_datagen.h"
 
 extern "C" {
 
@@ -96,8 +97,8 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
     // fly — bit-identical results, half the HBM (10 M x 768: 61 -> 31 GB).  The scale must be REQUESTED BEFORE the
     // row's ring loads (ehx_kernels.h, wave_group_dists_t): sunk below them it is the youngest load when the first
     // product needs it and the wait drains the ring — that cost 13 % at 2 M x 768 (profiles/r04_r_*); requested first
-    // the cost is 2 % (profiles/r04_s_*, r04_t_*).  EHX_GRAPH_TWO_COPIES=1: raw rows + search copy as in rounds 1-3.
-    s->x_perm = params && params->mode == EHX_MODE_GRAPH && !s->x_half && !env().graph_two_copies;
+    // the cost is 2 % (profiles/r04_s_*, r04_t_*).  (The two-copy layout of rounds 1-3 stayed selectable by an environment switch until round 6; profiles/r04_q-u hold its A/B.)
+    s->x_perm = params && params->mode == EHX_MODE_GRAPH && !s->x_half;
   }
   if (parent) s->params.shards = params->shards;
   if (s->params.mode != EHX_MODE_FLAT && s->params.mode != EHX_MODE_GRAPH)
@@ -418,11 +419,24 @@ int ehx_gen_rows_device(void* stream, uint64_t seed, uint64_t row0, uint64_t n_r
   return EHX_OK;
 }
 
+int ehx_gen_manifold_rows_device(void* stream, uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims,
+                                 uint32_t latent_dims, int normalize, float* d_out) {
+  if (!d_out && n_rows) return fail(EHX_EINVAL, "NULL device pointer");
+  if (dims % 4 != 0) return fail(EHX_EINVAL, "ehx_gen_manifold_rows_device needs dims %% 4 == 0 (got %u)", dims);
+  if (latent_dims == 0 || latent_dims > EHX_MANIFOLD_MAX_LATENT)
+    return fail(EHX_EINVAL, "latent_dims %u outside [1, %u]", latent_dims, EHX_MANIFOLD_MAX_LATENT);
+  int rc = ehx_init(nullptr, 0);
+  if (rc) return rc;
+  HIP_TRY(launch_gen_rows(seed, row0, n_rows, dims, dims, normalize, d_out, (hipStream_t)stream, 1, latent_dims));
+  return EHX_OK;
+}
+
 }  // extern "C"
 
 namespace ehx_impl {
 // rows row0, row0 + stride, ... of dataset `seed` appended to the space (locked exclusively by the caller)
-int fill_synthetic_locked(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize, uint64_t stride) {
+int fill_synthetic_locked(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize, uint64_t stride,
+                          uint32_t latent) {
   if (s->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
   if (!s->implicit_keys && s->n != 0)
     return fail(EHX_EINVAL, "space '%s' already holds keyed rows", s->name.c_str());
@@ -438,13 +452,13 @@ int fill_synthetic_locked(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n
     if ((rc = tmp.ensure(std::min<uint64_t>(slab, n_rows) * s->ld))) return rc;
     for (uint64_t r0 = 0; r0 < n_rows; r0 += slab) {
       const uint64_t m = std::min<uint64_t>(slab, n_rows - r0);
-      HIP_TRY(launch_gen_rows(seed, row0 + r0 * stride, m, s->dims, s->ld, normalize, tmp.p, s->stream, stride));
+      HIP_TRY(launch_gen_rows(seed, row0 + r0 * stride, m, s->dims, s->ld, normalize, tmp.p, s->stream, stride, latent));
       HIP_TRY(launch_store_rows_f16(tmp.p, s->ld, nullptr, s->n + r0, m, s->dims, s->ld, (__half*)s->dX, s->stream));
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     tmp.release();
   } else {
-    HIP_TRY(launch_gen_rows(seed, row0, n_rows, s->dims, s->ld, normalize, (float*)s->xrow(s->n), s->stream, stride));
+    HIP_TRY(launch_gen_rows(seed, row0, n_rows, s->dims, s->ld, normalize, (float*)s->xrow(s->n), s->stream, stride, latent));
     if (s->x_perm) HIP_TRY(launch_permute_blocks((float*)s->dX, s->ld, s->n, n_rows, nullptr, s->stream));
   }
   HIP_TRY(launch_row_stats(s->dX, s->x_half, s->n, n_rows, s->dims, s->ld, s->metric, s->dInv, s->dRowp, s->dMaxSumsq,
@@ -462,15 +476,25 @@ int fill_synthetic_locked(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n
 
 extern "C" {
 
-int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize) {
+static int fill_generated(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize, uint32_t latent) {
   if (!valid_space(s)) return fail(EHX_EINVAL, "space is NULL");
   if (n_rows == 0) return EHX_OK;
   std::lock_guard<std::mutex> wg(s->wmu);
   std::unique_lock<std::shared_mutex> wl(s->mu);
   if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
   if (s->keyless) return fail(EHX_EINVAL, "a shard is written through its parent space");
-  if (is_parent(s)) return sharded_fill_synthetic(s, seed, row0, n_rows, normalize);
-  return fill_synthetic_locked(s, seed, row0, n_rows, normalize, 1);
+  if (is_parent(s)) return sharded_fill_synthetic(s, seed, row0, n_rows, normalize, latent);
+  return fill_synthetic_locked(s, seed, row0, n_rows, normalize, 1, latent);
+}
+
+int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize) {
+  return fill_generated(s, seed, row0, n_rows, normalize, 0);
+}
+
+int ehx_fill_manifold(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t latent_dims, int normalize) {
+  if (latent_dims == 0 || latent_dims > EHX_MANIFOLD_MAX_LATENT)
+    return fail(EHX_EINVAL, "latent_dims %u outside [1, %u]", latent_dims, EHX_MANIFOLD_MAX_LATENT);
+  return fill_generated(s, seed, row0, n_rows, normalize, latent_dims);
 }
 
 int ehx_graph_import(ehx_space* s, uint64_t n, const uint32_t* level0, const int32_t* levels, uint64_t n_upper,

@@ -843,8 +843,9 @@ hipError_t launch_store_rows_f16(const float* src, uint32_t src_ld, const uint64
 hipError_t launch_load_row_f16(const __half* X, uint64_t row, uint32_t dims, uint32_t ld, float* out, hipStream_t st);
 
 // EHX-GAUSS-1 rows row0, row0 + row_stride, ... generated straight into a [*, ld] matrix (optionally L2-normalised)
+// latent != 0: EHX-MANIFOLD-1 rows on a `latent`-dimensional linear subspace + 5 % noise (include/ehx_datagen.h)
 hipError_t launch_gen_rows(uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims, uint32_t ld,
-                           int normalize, float* out, hipStream_t st, uint64_t row_stride = 1);
+                           int normalize, float* out, hipStream_t st, uint64_t row_stride = 1, uint32_t latent = 0);
 
 // graph-mode search (k_graph.hip): one wave per query
 constexpr uint32_t kGraphCounters = 12;  // n_dist, n_hops0, n_hops_up, n_prefetch_hit, [4..11] profile builds (wide walk: [4] = steps)

@@ -88,7 +88,7 @@ int sharded_set_batch(ehx_space* p, size_t n, const char* const* keys, const siz
   return EHX_OK;
 }
 
-int sharded_fill_synthetic(ehx_space* p, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize) {
+int sharded_fill_synthetic(ehx_space* p, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize, uint32_t latent) {
   if (p->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
   if (!p->implicit_keys && p->n != 0) return fail(EHX_EINVAL, "space '%s' already holds keyed rows", p->name.c_str());
   const uint64_t G = p->shards.size(), n0 = p->n;
@@ -100,7 +100,7 @@ int sharded_fill_synthetic(ehx_space* p, uint64_t seed, uint64_t row0, uint64_t 
     ehx_space* c = p->shards[i];
     std::lock_guard<std::mutex> cg(c->wmu);
     std::unique_lock<std::shared_mutex> wl(c->mu);
-    return fill_synthetic_locked(c, seed, row0 + (g0 - n0), cnt, normalize, G);
+    return fill_synthetic_locked(c, seed, row0 + (g0 - n0), cnt, normalize, G, latent);
   });
   if (rc) return rc;
   p->implicit_keys = true;

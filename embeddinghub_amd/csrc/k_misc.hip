@@ -7,6 +7,8 @@
 #include "../../include/ehx_datagen.h"
 #include "ehx_kernels.h"
 #include "k_prep_query.h"
+#include <map>
+#include <mutex>
 
 namespace ehx {
 
@@ -824,9 +826,122 @@ __global__ __launch_bounds__(64) void normalize_rows_tiled_kernel(uint64_t n_row
   }
 }
 
+// ---- EHX-MANIFOLD-1 (include/ehx_datagen.h): rows on an R-dimensional linear subspace + 5 % noise ------------------
+// the basis b[j][c] (R x ld floats, padding columns 0), once per (device, R, dims, ld): one thread per 4 columns
+__global__ __launch_bounds__(256) void manifold_basis_kernel(uint32_t R, uint32_t dims, uint32_t ld, float* __restrict__ basis) {
+  const uint32_t cbs = ld / 4;
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= R * cbs) return;
+  const uint32_t j = gid / cbs, cb = gid - j * cbs;
+  float b[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (cb * 4 < dims) {
+    ehx_datagen::manifold_basis4(j, cb, R, b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (cb * 4 + i >= dims) b[i] = 0.0f;
+  }
+  *(float4*)(basis + (size_t)j * ld + cb * 4) = make_float4(b[0], b[1], b[2], b[3]);
+}
+
+// rows: a workgroup takes kManifoldRows rows — their latents once into LDS, then one thread per (row, 4 columns): the
+// noise block (one Philox call, the EHX-GAUSS-1 element), R basis values per column from the L2-resident basis, the
+// sequential non-fused sum of the spec
+constexpr uint32_t kManifoldRows = 8;
+__global__ __launch_bounds__(256) void gen_manifold_rows_kernel(uint64_t seed, uint64_t row0, uint64_t row_stride, uint64_t n_rows,
+                                                                uint32_t dims, uint32_t ld, uint32_t R,
+                                                                const float* __restrict__ basis, float* __restrict__ out) {
+  __shared__ float lat[kManifoldRows][EHX_MANIFOLD_MAX_LATENT];
+  const uint64_t r0 = (uint64_t)blockIdx.x * kManifoldRows;
+  const uint32_t rows = (uint32_t)(n_rows - r0 < kManifoldRows ? n_rows - r0 : kManifoldRows);
+  const uint32_t jbs = (R + 3) / 4;
+  for (uint32_t t = threadIdx.x; t < rows * jbs; t += blockDim.x) {
+    const uint32_t rr = t / jbs, jb = t - rr * jbs;
+    float l[4];
+    ehx_datagen::manifold_latent4(seed, row0 + (r0 + rr) * row_stride, jb, l);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (jb * 4 + i < EHX_MANIFOLD_MAX_LATENT) lat[rr][jb * 4 + i] = l[i];
+  }
+  __syncthreads();
+  const uint32_t cbs = ld / 4;
+  for (uint32_t t = threadIdx.x; t < rows * cbs; t += blockDim.x) {
+    const uint32_t rr = t / cbs, cb = t - rr * cbs;
+    float x[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (cb * 4 < dims) {
+      float e[4];
+      ehx_datagen::normal4(seed, row0 + (r0 + rr) * row_stride, cb, e);
+      float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (uint32_t j = 0; j < R; ++j) {
+        const float4 b = *(const float4*)(basis + (size_t)j * ld + cb * 4);
+        const float lj = lat[rr][j];
+        acc[0] = ex_add(acc[0], ex_mul(lj, b.x));
+        acc[1] = ex_add(acc[1], ex_mul(lj, b.y));
+        acc[2] = ex_add(acc[2], ex_mul(lj, b.z));
+        acc[3] = ex_add(acc[3], ex_mul(lj, b.w));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[i] = cb * 4 + i < dims ? ex_add(acc[i], ex_mul(0.05f, e[i])) : 0.0f;
+    }
+    *(float4*)(out + (r0 + rr) * ld + cb * 4) = make_float4(x[0], x[1], x[2], x[3]);
+  }
+}
+
+namespace {
+// one basis per (device, R, dims, ld), made on first use and kept (R * ld * 4 bytes: 49 KB at R = 16, d = 768)
+struct BasisKey {
+  int dev;
+  uint32_t R, dims, ld;
+  bool operator<(const BasisKey& o) const {
+    if (dev != o.dev) return dev < o.dev;
+    if (R != o.R) return R < o.R;
+    if (dims != o.dims) return dims < o.dims;
+    return ld < o.ld;
+  }
+};
+std::mutex g_basis_mu;
+std::map<BasisKey, float*> g_basis;
+hipError_t manifold_basis(uint32_t R, uint32_t dims, uint32_t ld, hipStream_t st, const float** out) {
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  std::lock_guard<std::mutex> g(g_basis_mu);
+  const BasisKey key{dev, R, dims, ld};
+  auto it = g_basis.find(key);
+  if (it != g_basis.end()) {
+    *out = it->second;
+    return hipSuccess;
+  }
+  float* b = nullptr;
+  if (hipError_t e = hipMalloc((void**)&b, (size_t)R * ld * sizeof(float)); e != hipSuccess) return e;
+  const uint32_t work = R * (ld / 4);
+  hipLaunchKernelGGL(manifold_basis_kernel, dim3((work + 255) / 256), dim3(256), 0, st, R, dims, ld, b);
+  if (hipError_t e = hipStreamSynchronize(st); e != hipSuccess) {   // (other streams may use it from now on)
+    (void)hipFree(b);
+    return e;
+  }
+  g_basis[key] = b;
+  *out = b;
+  return hipSuccess;
+}
+}  // namespace
+
 hipError_t launch_gen_rows(uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims, uint32_t ld,
-                           int normalize, float* out, hipStream_t st, uint64_t row_stride) {
+                           int normalize, float* out, hipStream_t st, uint64_t row_stride, uint32_t latent) {
   if (n_rows == 0) return hipSuccess;
+  if (latent) {   // EHX-MANIFOLD-1
+    const float* basis = nullptr;
+    if (hipError_t e = manifold_basis(latent, dims, ld, st, &basis); e != hipSuccess) return e;
+    const uint64_t max_rows = (uint64_t)(1u << 30) * kManifoldRows;
+    for (uint64_t done = 0; done < n_rows;) {
+      const uint64_t rows = n_rows - done < max_rows ? n_rows - done : max_rows;
+      hipLaunchKernelGGL(gen_manifold_rows_kernel, dim3((uint32_t)((rows + kManifoldRows - 1) / kManifoldRows)), dim3(256), 0, st,
+                         seed, row0 + done * row_stride, row_stride, rows, dims, ld, latent, basis, out + done * ld);
+      done += rows;
+    }
+    if (normalize)
+      hipLaunchKernelGGL(normalize_rows_tiled_kernel, dim3((uint32_t)((n_rows + 63) / 64)), dim3(64), 0, st, n_rows, dims, ld,
+                         out);
+    return hipGetLastError();
+  }
   const uint64_t work = n_rows * (ld / 4);
   // grid.x limit: chunk the launch if needed
   const uint64_t max_blocks = 1u << 30;

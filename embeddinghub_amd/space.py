@@ -159,6 +159,11 @@ class Space:
     def fill_synthetic(self, seed, row0, n_rows, normalize):
         check(self._L.ehx_fill_synthetic(self._h, seed, row0, n_rows, int(bool(normalize))))
 
+    def fill_manifold(self, seed, row0, n_rows, latent_dims, normalize):
+        """EHX-MANIFOLD-1 rows (include/ehx_datagen.h) generated on the device: a latent_dims-dimensional linear subspace
+        + 5 % noise"""
+        check(self._L.ehx_fill_manifold(self._h, seed, row0, n_rows, latent_dims, int(bool(normalize))))
+
     # ---- reads ----
     def get(self, key):
         k = key.encode() if isinstance(key, str) else bytes(key)

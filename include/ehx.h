@@ -249,6 +249,14 @@ int ehx_merge_topk_strided_device(void* stream, size_t n_queries, uint32_t k, ui
 int ehx_fill_synthetic(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize);
 int ehx_gen_rows_device(void* stream, uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims,
                         int normalize, float* d_out /* n_rows x dims */);
+/* EHX-MANIFOLD-1 (include/ehx_datagen.h): rows WITH STRUCTURE — points of a latent_dims-dimensional (1..64) linear
+ * subspace of the dims-dimensional space plus 5 % isotropic noise — the workload on which a graph index meets a recall
+ * target at a small ef (isotropic Gaussian rows at d = 768 defeat any graph: SURVEY.md §7).  Generated on
+ * the device like ehx_fill_synthetic — a 10 M x 768 corpus never exists on the host; the host-side restatement
+ * (oracle/datagen_oracle.hpp) produces the same bytes. */
+int ehx_fill_manifold(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t latent_dims, int normalize);
+int ehx_gen_manifold_rows_device(void* stream, uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dims,
+                                 uint32_t latent_dims, int normalize, float* d_out /* n_rows x dims */);
 
 /* ---- graph import (graph mode; persistence and strict-parity checks).  Graph spaces also build their
  * graph on the GPU as rows are Set (hnswlib addPoint semantics, k_insert.hip). ----

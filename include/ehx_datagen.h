@@ -21,6 +21,19 @@
  * hnswlib-python convention: norm = 1/(sqrt(sum_i x_i^2) + 1e-30f) (sequential fp32 sum,
  * non-fused), x_i *= norm.  Corpus seed 20250211, query seed 20250212.
  *
+ * EHX-MANIFOLD-1 (round 6): rows WITH STRUCTURE — points of an R-dimensional linear subspace of the `dims`-dimensional
+ * space plus 5 % isotropic noise — on which a graph index reaches recall >= 0.95 at a small ef (isotropic Gaussian rows
+ * at d = 768 are adversarial for any graph: SURVEY.md §7).  Same building blocks, so host and device agree bit for bit:
+ *
+ *   basis   b[j][c] = N4( key = EHX_SEED_BASIS, counter = (j, 0, c/4, 1) )[c%4] * rs,   rs = 1 / sqrt_rn(float(R))   j < R
+ *   latent  l[r][j] = N4( key = seed,           counter = (r_lo, r_hi, j/4, 2) )[j%4]                                 j < R
+ *   noise   e[r][c] = N4( key = seed,           counter = (r_lo, r_hi, c/4, 0) )[c%4]          (the EHX-GAUSS-1 element)
+ *   x[r][c] = ( ... ((0 + l0*b0c) + l1*b1c) ... + l(R-1)*b(R-1)c ) + 0.05f * e[r][c]     (sequential, non-fused, fp32)
+ *
+ * (N4 = the Philox4x32-10 -> Box-Muller block above with the counter's last word as the STREAM: 0 = EHX-GAUSS-1.)
+ * Cosine workloads normalise rows as above.  Queries: the same generator with the query seed — drawn independently of
+ * the rows (erratum of round 3).
+ *
  * This header is the product's implementation (device + host inline); oracle/datagen_oracle.hpp
  * is an independent restatement of the same spec used only by the tests.
  */
@@ -31,6 +44,8 @@
 
 #define EHX_SEED_CORPUS 20250211ull
 #define EHX_SEED_QUERY 20250212ull
+#define EHX_SEED_BASIS 20250213ull  /* EHX-MANIFOLD-1: the subspace is the same for every dataset seed */
+#define EHX_MANIFOLD_MAX_LATENT 64u
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -180,13 +195,13 @@ EHX_HD void det_sincos(float a, float* s, float* c) {
   *c = pc;
 }
 
-/* z[0..3] = columns 4*cb .. 4*cb+3 of row `row`. */
-EHX_HD void normal4(uint64_t seed, uint64_t row, uint32_t cb, float z[4]) {
+/* z[0..3] = columns 4*cb .. 4*cb+3 of row `row` of stream `stream` (0 = EHX-GAUSS-1). */
+EHX_HD void normal4_stream(uint64_t seed, uint64_t row, uint32_t cb, uint32_t stream, float z[4]) {
   u32x4 ctr;
   ctr.x = (uint32_t)row;
   ctr.y = (uint32_t)(row >> 32);
   ctr.z = cb;
-  ctr.w = 0u;
+  ctr.w = stream;
   const u32x4 r = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
   const uint32_t xs[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -204,6 +219,22 @@ EHX_HD void normal4(uint64_t seed, uint64_t row, uint32_t cb, float z[4]) {
     z[2 * p] = f_mul(rad, cs);
     z[2 * p + 1] = f_mul(rad, sn);
   }
+}
+EHX_HD void normal4(uint64_t seed, uint64_t row, uint32_t cb, float z[4]) { normal4_stream(seed, row, cb, 0u, z); }
+
+/* EHX-MANIFOLD-1 pieces: b[j][4 cb .. 4 cb + 3] of the R-dimensional basis, and l[row][4 jb .. 4 jb + 3] */
+EHX_HD void manifold_basis4(uint32_t j, uint32_t cb, uint32_t R, float b[4]) {
+  normal4_stream(EHX_SEED_BASIS, (uint64_t)j, cb, 1u, b);
+  const float rs = f_div(1.0f, f_sqrt((float)R));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = f_mul(b[i], rs);
+}
+EHX_HD void manifold_latent4(uint64_t seed, uint64_t row, uint32_t jb, float l[4]) { normal4_stream(seed, row, jb, 2u, l); }
+/* x[row][4 cb + i] from the row's latents l[0..R), the basis column values bcol[j] = b[j][4 cb + i] and the noise e */
+EHX_HD float manifold_element(const float* l, const float* bcol, uint32_t R, float e) {
+  float acc = 0.0f;
+  for (uint32_t j = 0; j < R; ++j) acc = f_add(acc, f_mul(l[j], bcol[j]));
+  return f_add(acc, f_mul(0.05f, e));
 }
 
 }  // namespace ehx_datagen

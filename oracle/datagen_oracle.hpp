@@ -98,9 +98,10 @@ static inline void det_sincos(float a, float* s, float* c) {
   *c = pc;
 }
 
-// Four N(0,1) values for (seed, row, column block cb) = columns 4cb..4cb+3.
-static inline void normal4(uint64_t seed, uint64_t row, uint32_t cb, float z[4]) {
-  U4 ctr = {{(uint32_t)row, (uint32_t)(row >> 32), cb, 0u}};
+// Four N(0,1) values for (seed, row, column block cb) = columns 4cb..4cb+3; `stream` = the counter's last word
+// (0: EHX-GAUSS-1; 1 / 2: the basis and the latents of EHX-MANIFOLD-1).
+static inline void normal4(uint64_t seed, uint64_t row, uint32_t cb, float z[4], uint32_t stream = 0u) {
+  U4 ctr = {{(uint32_t)row, (uint32_t)(row >> 32), cb, stream}};
   U4 x = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
   for (int p = 0; p < 2; p++) {
     uint32_t xa = x.v[2 * p], xb = x.v[2 * p + 1];
@@ -130,6 +131,44 @@ static inline void gen_row(uint64_t seed, uint64_t row, size_t dim, bool normali
     float z[4];
     normal4(seed, row, (uint32_t)cb, z);
     for (int j = 0; j < 4 && cb * 4 + j < dim; j++) out[cb * 4 + j] = z[j];
+  }
+  if (normalize) {
+    float norm = 0.0f;
+    for (size_t i = 0; i < dim; i++) norm += out[i] * out[i];
+    norm = 1.0f / (sqrtf(norm) + 1e-30f);
+    for (size_t i = 0; i < dim; i++) out[i] = out[i] * norm;
+  }
+}
+
+// EHX-MANIFOLD-1 (include/ehx_datagen.h): x[r][c] = sum_j l[r][j] * b[j][c] (sequential, non-fused) + 0.05 * e[r][c] with
+// basis b (seed 20250213, stream 1, scaled by 1 / sqrt(R)), latents l (stream 2) and the EHX-GAUSS-1 noise e of the same
+// seed; optionally L2-normalised like gen_row.  `basis` (R x dim, from manifold_basis) is shared by all rows.
+static inline void manifold_basis(size_t dim, uint32_t R, float* basis) {
+  const float rs = 1.0f / sqrtf((float)R);
+  for (uint32_t j = 0; j < R; j++)
+    for (size_t cb = 0; cb * 4 < dim; cb++) {
+      float z[4];
+      normal4(20250213ull, (uint64_t)j, (uint32_t)cb, z, 1u);
+      for (int i = 0; i < 4 && cb * 4 + i < dim; i++) basis[(size_t)j * dim + cb * 4 + i] = z[i] * rs;
+    }
+}
+static inline void gen_manifold_row(uint64_t seed, uint64_t row, size_t dim, uint32_t R, const float* basis, bool normalize,
+                                    float* out) {
+  float lat[64 + 4];
+  for (uint32_t jb = 0; jb * 4 < R; jb++) normal4(seed, row, jb, lat + jb * 4, 2u);
+  for (size_t cb = 0; cb * 4 < dim; cb++) {
+    float e[4];
+    normal4(seed, row, (uint32_t)cb, e, 0u);
+    for (int i = 0; i < 4 && cb * 4 + i < dim; i++) {
+      const size_t c = cb * 4 + i;
+      float acc = 0.0f;
+      for (uint32_t j = 0; j < R; j++) {
+        const float prod = lat[j] * basis[(size_t)j * dim + c];
+        acc = acc + prod;
+      }
+      const float ne = 0.05f * e[i];
+      out[c] = acc + ne;
+    }
   }
   if (normalize) {
     float norm = 0.0f;

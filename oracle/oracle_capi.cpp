@@ -411,4 +411,14 @@ void orc_gen_rows(uint64_t seed, uint64_t row0, size_t n_rows, size_t dim, int n
                [&](size_t i, int) { datagen::gen_row(seed, row0 + i, dim, normalize != 0, out + i * dim); });
 }
 
+void orc_gen_manifold_rows(uint64_t seed, uint64_t row0, size_t n_rows, size_t dim, uint32_t latent, int normalize,
+                           float* out, int threads) {
+  if (latent == 0 || latent > 64) return;
+  std::vector<float> basis((size_t)latent * dim);
+  datagen::manifold_basis(dim, latent, basis.data());
+  parallel_for(n_rows, threads, [&](size_t i, int) {
+    datagen::gen_manifold_row(seed, row0 + i, dim, latent, basis.data(), normalize != 0, out + i * dim);
+  });
+}
+
 }  // extern "C"

@@ -84,6 +84,7 @@ def lib():
         L.orc_levels.argtypes = [C.c_uint32, C.c_size_t, i32p, C.c_size_t]
         L.orc_philox.argtypes = [u32p, u32p, u32p]
         L.orc_gen_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_size_t, C.c_int, f32p, C.c_int]
+        L.orc_gen_manifold_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int, f32p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -312,4 +313,13 @@ def gen_rows(seed, row0, n_rows, dim, normalize=False, threads=None):
     out = np.zeros((n_rows, dim), dtype=np.float32)
     lib().orc_gen_rows(seed, row0, n_rows, dim, int(bool(normalize)), _ptr(out, C.c_float),
                        threads or os.cpu_count() or 1)
+    return out
+
+
+def gen_manifold_rows(seed, row0, n_rows, dim, latent, normalize=False, threads=None):
+    """EHX-MANIFOLD-1 rows (include/ehx_datagen.h): points of a `latent`-dimensional linear subspace + 5 % noise"""
+    assert 1 <= latent <= 64
+    out = np.zeros((n_rows, dim), dtype=np.float32)
+    lib().orc_gen_manifold_rows(seed, row0, n_rows, dim, latent, int(bool(normalize)), _ptr(out, C.c_float),
+                                threads or os.cpu_count() or 1)
     return out

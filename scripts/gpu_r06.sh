@@ -59,5 +59,19 @@ e)  # A/B: early touch of the next step's visited words (EHX_GW_WARM), same box,
   EHX_LIB=$PWD/embeddinghub_amd/lib/libehx_nowarm.so graph_bench 6250k128_nowarm 6250000 128 l2 50,200,800 2,4
   graph_bench 6250k128_warm2 6250000 128 l2 50,200,800 2,4
   ;;
+f)  # EHX-MANIFOLD-1 on the device == the oracle; then the default bench run with the 10 M x 768 structured graph leg
+  timeout 600 python -m pytest tests/test_datagen.py -x -q 2>&1 | tail -3
+  timeout 900 python bench.py > $O/r06_f_bench_line.json 2> $O/r06_f_bench.err; echo "bench rc=$?"
+  cp $O/bench_detail.json $O/r06_f_bench_detail.json 2>/dev/null
+  grep -E "leg done|structured|skipp" $O/r06_f_bench.err | tail -30
+  python - <<PY
+import json
+l = json.load(open("$O/r06_f_bench_line.json"))
+print(json.dumps({k: l.get(k) for k in ("value", "ms_per_step", "roofline", "graph_path", "graph_path_structured", "graph_path_structured_10m", "skipped")}, indent=0)[:3000])
+d = json.load(open("$O/r06_f_bench_detail.json"))
+for c in d.get("graph_path_structured_10m", {}).get("recall_vs_ef", []):
+    print({k: c[k] for k in ("ef", "search_width", "recall_at_10", "value", "kernel_ms", "rows_fetched_per_query", "frac_of_8TBps")})
+PY
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac

@@ -40,6 +40,10 @@ class FakeSpace:
             rows = rows.astype(np.float16).astype(np.float32)
         self.X = np.concatenate([self.X, rows])
 
+    def fill_manifold(self, seed, row0, n, latent, normalize):
+        rows = pyoracle.gen_manifold_rows(seed, row0, n, self.dims, latent, normalize=bool(normalize))
+        self.X = np.concatenate([self.X, rows])
+
     def set_batch(self, keys, X):
         self.X = np.concatenate([self.X, np.asarray(X, dtype=np.float32)])
 
@@ -91,6 +95,9 @@ class FakeSpace:
     def set_ef(self, ef):
         self.ef = ef
 
+    def set_search_width(self, width):
+        self.width = width
+
     def stats(self):
         return dict(self._st)
 
@@ -124,6 +131,12 @@ class FakeLib:
     @staticmethod
     def ehx_gen_rows_device(stream, seed, row0, n, d, normalize, ptr):
         rows = pyoracle.gen_rows(seed, row0, n, d, normalize=bool(normalize))
+        C.memmove(ptr.value, rows.ctypes.data, rows.nbytes)
+        return 0
+
+    @staticmethod
+    def ehx_gen_manifold_rows_device(stream, seed, row0, n, d, latent, normalize, ptr):
+        rows = pyoracle.gen_manifold_rows(seed, row0, n, d, latent, normalize=bool(normalize))
         C.memmove(ptr.value, rows.ctypes.data, rows.nbytes)
         return 0
 
