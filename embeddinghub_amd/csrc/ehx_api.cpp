@@ -438,7 +438,7 @@ namespace ehx_impl {
 int fill_synthetic_locked(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n_rows, int normalize, uint64_t stride,
                           uint32_t latent) {
   if (s->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
-  if (!s->implicit_keys && s->n != 0)
+  if (s->implicit_n != s->n)   // (generated rows form the head of a space: their keys are their decimal row ids)
     return fail(EHX_EINVAL, "space '%s' already holds keyed rows", s->name.c_str());
   HIP_TRY(hipSetDevice(s->device));
   if (s->n + n_rows >= (1ull << 32)) return fail(EHX_EUNSUPPORTED, "a shard holds at most 2^32-1 rows");
@@ -467,6 +467,10 @@ int fill_synthetic_locked(ehx_space* s, uint64_t seed, uint64_t row0, uint64_t n
   if ((rc = refresh_scan16(s, s->n, n_rows, nullptr, true, s->n + n_rows))) return rc;
   const uint64_t old_n = s->n;
   s->n += n_rows;
+  {
+    std::unique_lock<std::shared_mutex> kl(s->kmu);
+    s->implicit_n = s->n;
+  }
   if (s->params.mode == EHX_MODE_GRAPH && s->g_n == old_n && s->params.build_batch != 0xFFFFFFFFu) {
     if ((rc = graph_insert(s, old_n, n_rows, s->params.build_batch))) return rc;
   }

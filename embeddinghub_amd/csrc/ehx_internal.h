@@ -183,7 +183,9 @@ struct ehx_space {
   bool dropped = false;        // ehx_space_drop ran: HBM released, the host object stays (tombstone) so that a
                                // thread still holding the handle fails with EHX_ENOTFOUND instead of touching
                                // freed memory; reclaimed by ehx_shutdown
-  bool implicit_keys = false;  // rows appended by ehx_fill_synthetic: key == decimal row id
+  bool implicit_keys = false;  // rows appended by ehx_fill_synthetic / ehx_fill_manifold: key == decimal row id ...
+  uint64_t implicit_n = 0;     // ... for rows [0, implicit_n); rows Set afterwards (unsharded spaces) carry their own keys:
+                               // id_to_key[id - implicit_n].  A Set of the key "123" on such a space rewrites row 123.
   std::atomic<bool> poisoned{false};  // single-copy graph space (x_perm): an in-place overwrite of committed rows failed
                                // between the raw upload and the permutation — those rows sit in raw order inside a
                                // permuted store; searches and Gets refuse (EHX_EINTERNAL) instead of answering wrongly
@@ -563,6 +565,7 @@ inline bool is_parent(const ehx_space* s) { return !s->shards.empty(); }
 int wait_searches_in_flight(ehx_space* s, hipStream_t st);
 int key_for_id(ehx_space* s, uint64_t id, std::string* out);
 int lookup_key(ehx_space* s, const char* key, size_t klen, uint64_t* id);
+bool implicit_id(const ehx_space* s, const char* key, size_t klen, uint64_t* id);  // (caller holds kmu or mu)
 void resolve_keys(ehx_space* s, size_t n, const char* const* keys, const size_t* klens, std::vector<uint64_t>* ids,
                          uint64_t* next_out, std::vector<std::string>* new_keys);
 

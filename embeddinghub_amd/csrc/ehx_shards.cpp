@@ -105,6 +105,10 @@ int sharded_fill_synthetic(ehx_space* p, uint64_t seed, uint64_t row0, uint64_t 
   if (rc) return rc;
   p->implicit_keys = true;
   p->n += n_rows;
+  {
+    std::unique_lock<std::shared_mutex> kl(p->kmu);
+    p->implicit_n = p->n;
+  }
   return EHX_OK;
 }
 

@@ -183,31 +183,34 @@ int wait_searches_in_flight(ehx_space* s, hipStream_t st) {
 
 int key_for_id(ehx_space* s, uint64_t id, std::string* out) {
   std::shared_lock<std::shared_mutex> kl(s->kmu);
-  if (id < s->id_to_key.size() && !s->implicit_keys) {
-    *out = s->id_to_key[id];
+  if (id < s->implicit_n) {
+    *out = std::to_string(id);
     return EHX_OK;
   }
-  if (s->implicit_keys && id < s->n) {
-    *out = std::to_string(id);
+  if (id - s->implicit_n < s->id_to_key.size()) {
+    *out = s->id_to_key[id - s->implicit_n];
     return EHX_OK;
   }
   return EHX_ENOTFOUND;
 }
 
-int lookup_key(ehx_space* s, const char* key, size_t klen, uint64_t* id) {
-  if (s->implicit_keys) {
-    // decimal row id
-    if (klen == 0 || klen > 20) return EHX_ENOTFOUND;
-    uint64_t v = 0;
-    for (size_t i = 0; i < klen; ++i) {
-      if (key[i] < '0' || key[i] > '9') return EHX_ENOTFOUND;
-      v = v * 10 + (uint64_t)(key[i] - '0');
-    }
-    if (v >= s->n) return EHX_ENOTFOUND;
-    *id = v;
-    return EHX_OK;
+// the row a decimal key names among the implicitly keyed rows [0, implicit_n) (canonical decimals only: "007" is a key
+// of its own)
+bool implicit_id(const ehx_space* s, const char* key, size_t klen, uint64_t* id) {
+  if (s->implicit_n == 0 || klen == 0 || klen > 20 || (klen > 1 && key[0] == '0')) return false;
+  uint64_t v = 0;
+  for (size_t i = 0; i < klen; ++i) {
+    if (key[i] < '0' || key[i] > '9') return false;
+    v = v * 10 + (uint64_t)(key[i] - '0');
   }
+  if (v >= s->implicit_n) return false;
+  *id = v;
+  return true;
+}
+
+int lookup_key(ehx_space* s, const char* key, size_t klen, uint64_t* id) {
   std::shared_lock<std::shared_mutex> kl(s->kmu);
+  if (implicit_id(s, key, klen, id)) return EHX_OK;
   auto it = s->key_to_id.find(std::string(key, klen));
   if (it == s->key_to_id.end()) return EHX_ENOTFOUND;
   *id = it->second;
@@ -229,6 +232,7 @@ void resolve_keys(ehx_space* s, size_t n, const char* const* keys, const size_t*
   new_keys->reserve(n);
   for (size_t i = 0; i < n; ++i) {
     std::string k(keys[i], klens[i]);
+    if (implicit_id(s, keys[i], klens[i], &(*ids)[i])) continue;
     auto it = s->key_to_id.find(k);
     if (it != s->key_to_id.end()) {
       (*ids)[i] = it->second;

@@ -25,7 +25,7 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
       std::shared_lock<std::shared_mutex> rl(s->mu);
       if (s->dropped) return fail(EHX_ENOTFOUND, "Not found");
       if (s->keyless) return fail(EHX_EINVAL, "a shard is written through its parent space");
-      if (!s->frozen && !s->implicit_keys) {
+      if (!s->frozen) {
         resolve_keys(s, n, keys, klens, &ids, &next, &new_keys);
         fast = new_keys.size() == n && all_fresh_keys(s, n, ids);
       }
@@ -47,7 +47,8 @@ int ehx_set_batch(ehx_space* s, size_t n, const char* const* keys, const size_t*
       std::shared_lock<std::shared_mutex> kl(s->kmu);
       for (size_t i = 0; i < n && !rewrite; ++i) {
         std::string k(keys[i], klens[i]);
-        rewrite = s->key_to_id.count(k) != 0 || !seen.insert(std::move(k)).second;
+        uint64_t known = 0;
+        rewrite = implicit_id(s, keys[i], klens[i], &known) || s->key_to_id.count(k) != 0 || !seen.insert(std::move(k)).second;
       }
     }
     if (rewrite) {
@@ -167,7 +168,6 @@ extern "C" {
 
 static int set_batch_locked(ehx_space* s, size_t n, const char* const* keys, const size_t* klens, const float* vecs) {
   if (s->frozen) return fail(EHX_EIMMUTABLE, "Cannot write to immutable space");
-  if (s->implicit_keys) return fail(EHX_EINVAL, "space '%s' holds synthetic rows with implicit keys", s->name.c_str());
   std::vector<uint64_t> ids;
   std::vector<std::string> new_keys;
   uint64_t next = 0;

@@ -73,5 +73,23 @@ for c in d.get("graph_path_structured_10m", {}).get("recall_vs_ef", []):
     print({k: c[k] for k in ("ef", "search_width", "recall_at_10", "value", "kernel_ms", "rows_fetched_per_query", "frac_of_8TBps")})
 PY
   ;;
+g)  # keyed rows after a generated base; configs[4] with the Set stream on the fp16 shard; lock-step A/B (EHX_I8_SYNC=2) on
+    # the headline and under concurrent Sets, same box
+  timeout 600 python -m pytest tests/test_generated_base.py tests/test_concurrent_set.py -x -q 2>&1 | tail -3
+  for sync in 0 2 0 2; do
+    EHX_I8_SYNC=$sync timeout 900 python bench.py --graph-rows 0 --structured-rows 0 --structured-big-rows 0 --single-query 0 \
+      --reference-benchmark 0 --no-cpu-baseline --steps 20 --warmup 5 --detail-file $O/r06_g_sync${sync}_detail.json \
+      > $O/r06_g_sync${sync}_line.json 2> $O/r06_g_sync${sync}.err; echo "sync=$sync rc=$?"
+    python - <<PY
+import json
+l = json.load(open("$O/r06_g_sync${sync}_line.json"))
+c4 = l["configs"]["configs[4]"]
+print("sync=$sync headline %.3f ms/step kernel %.3f frac %.4f | one caller %s | c1 %.3f c3 %.3f c4 %.3f ms | set_concurrent(c4) %s | set_concurrent(1M) %s" % (
+    l["ms_per_step"], l["roofline"]["kernel_ms"], l["roofline"]["frac"], l.get("one_caller_ms_per_step"),
+    l["configs"]["configs[1]"]["ms_per_step"], l["configs"]["configs[3]"]["ms_per_step"], c4["ms_per_step"],
+    c4.get("set_concurrent"), l.get("set_concurrent")))
+PY
+  done
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac

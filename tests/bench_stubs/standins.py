@@ -17,10 +17,12 @@ from oracle import pyoracle
 
 class FakeSpace:
     spaces = {}
+    _wmu = __import__("threading").Lock()
 
     def __init__(self, name, dims, metric=0, mode=0, initial_capacity=0, shards=0, dtype=0, build_batch=0, **kw):
         self.name, self.dims, self.metric, self.mode = name, dims, metric, mode
         self.X = np.zeros((0, dims), dtype=np.float32)
+        self.keys = []
         self.half = dtype == 1     # an fp16-row space holds its rows rounded to binary16
         self.ef, self._scan, self._st = 10, 0, self._zero()
         FakeSpace.spaces[name] = self
@@ -38,6 +40,7 @@ class FakeSpace:
         rows = pyoracle.gen_rows(seed, row0, n, self.dims, normalize=bool(normalize))
         if self.half:
             rows = rows.astype(np.float16).astype(np.float32)
+        self.keys += [str(i) for i in range(self.X.shape[0], self.X.shape[0] + n)]
         self.X = np.concatenate([self.X, rows])
 
     def fill_manifold(self, seed, row0, n, latent, normalize):
@@ -45,7 +48,15 @@ class FakeSpace:
         self.X = np.concatenate([self.X, rows])
 
     def set_batch(self, keys, X):
-        self.X = np.concatenate([self.X, np.asarray(X, dtype=np.float32)])
+        X = np.asarray(X, dtype=np.float32)
+        if self.half:
+            X = X.astype(np.float16).astype(np.float32)
+        with FakeSpace._wmu:      # (the engine serialises writers of a space: ehx_space::wmu)
+            self.keys += [k.decode() if isinstance(k, bytes) else str(k) for k in keys]
+            self.X = np.concatenate([self.X, X])
+
+    def key_of(self, i):
+        return self.keys[i]
 
     def prepare_batch(self, keys, X):
         return keys, np.asarray(X, dtype=np.float32)

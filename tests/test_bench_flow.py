@@ -170,6 +170,26 @@ def test_config_legs_report_three_more_shapes_with_exactness_and_roofline_before
     assert keys.index("configs") < keys.index("cpu_baseline")
 
 
+def test_configs4_leg_streams_sets_into_the_fp16_shard_while_searching_and_checks_both_sides(bench_on_stand_ins):
+    """VERDICT r05 #3 — BASELINE configs[4] as written, "streamed Set + concurrent GetNeighbors" on the fp16 x 1536 shard:
+    four writer threads stream chunks through set_batch into the SAME space the callers search; a batch answered during
+    the writes is checked against the oracle's truth over the rows that were complete, one answered after the last Set
+    against its truth over everything; rows/s and the search rate beside the un-contended one are in the line"""
+    argv = [a for a in SMALL]
+    argv[argv.index("--config-legs") + 1] = "1"
+    argv[argv.index("--set-concurrent") + 1] = "131072"
+    r = bench_on_stand_ins(argv + ["--config-legs-rows-div", "5000", "--graph-rows", "0", "--structured-rows", "0",
+                                   "--no-cpu-baseline"])
+    sc = r["configs"]["configs[4]"]["set_concurrent"]
+    assert sc["rows_written_meanwhile"] == 131072 // 5000 and sc["writer_threads"] == 4 and sc["error"] is None
+    assert sc["oracle_during_writes"]["consistent_with_the_complete_prefix"] is True
+    assert sc["oracle_after_writes"]["ok"] is True and "identical" in sc["oracle_after_writes"]["how"]
+    assert sc["set_rows_per_s_meanwhile"] > 0 and sc["search_batches_meanwhile"] >= 2
+    c = bench_on_stand_ins.line["configs"]["configs[4]"]["set_concurrent"]
+    assert c["oracle_during"] is True and c["oracle_after"] is True and c["writers"] == 4
+    assert "set_concurrent" not in r["configs"]["configs[1]"]
+
+
 def test_an_oracle_mismatch_ends_the_run(bench_on_stand_ins, monkeypatch):
     """fail-closed: ids or distance bytes that differ from the oracle's abort the run — recall alone
     does not decide.  Here the fp16 leg's stand-in space 'forgets' to round its rows: same ids almost everywhere, other
@@ -288,6 +308,7 @@ def test_multi_rank_flow_rank0_prints_the_line(bench_on_stand_ins, monkeypatch):
     monkeypatch.setattr(dist, "init_process_group", lambda *a, **kw: calls.append("init"))
     monkeypatch.setattr(dist, "barrier", lambda *a, **kw: calls.append("barrier"))
     monkeypatch.setattr(dist, "all_reduce", lambda t, op=None: calls.append("all_reduce"))
+    monkeypatch.setattr(dist, "all_gather", lambda lst, t: [x.copy_(t) for x in lst] and calls.append("all_gather"))
     monkeypatch.setattr(dist, "destroy_process_group", lambda *a, **kw: calls.append("destroy"))
     monkeypatch.setattr(dist, "get_world_size", lambda *a, **kw: 2)
     real_tensor, real_device = torch.tensor, torch.device
@@ -370,6 +391,36 @@ def test_gpus_4_dry_run_ranks_partition_gather_and_only_rank0_does_host_legs(tmp
     for leg in ("cpu_baseline", "graph_path", "graph_path_structured", "configs", "single_query", "set_concurrent"):
         assert leg not in out, leg
     assert "device_resident_queries" in out        # (the same steps from HBM-resident batches, every rank)
+
+
+def test_gpus_8_dry_run_the_drivers_scaling_shape(tmp_path):
+    """`bench.py --gpus 8` as the driver's SCALE run launches it, dry — eight real processes under
+    torch.distributed.run, gloo collectives, the product's sharded.py; uneven shards (3005 rows over 8 ranks), rank 0 alone
+    on the host legs, the world size the process group reports, the rows of all ranks adding up, and every rank's own
+    ms_per_step in the line so that a straggler is visible in the first real run.  (No hardware claim: SCALE stays
+    "unmeasured" until a record with N > 1 exists.)"""
+    import time as _t
+    t0 = _t.time()
+    r = _run_bench_subprocess(SMALL + ["--gpus", "8", "--rows", "3005"], devices=8, detail=tmp_path / "d.json")
+    wall = _t.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert wall < 300, wall
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert len(lines[0]) <= 4096 and line["n_gpus"] == 8 and line["config"]["world_size"] == 8
+    assert len(line["config"]["rank_ms"]) == 8 and all(x > 0 for x in line["config"]["rank_ms"])
+    assert line["config"]["rank_spread"] >= 1.0
+    assert line["exactness"]["ids_identical_to_oracle"] and line["exactness"]["recall_at_10"] == 1.0
+    for leg in ("cpu_baseline", "graph_path", "graph_path_structured", "graph_path_structured_10m", "configs", "single_query",
+                "set_concurrent"):
+        assert leg not in line, leg
+    with open(tmp_path / "d.json") as f:
+        out = json.load(f)
+    assert out["config"]["world_size"] == 8 and sum(out["config"]["rows_per_rank"]) == 3005 == out["config"]["rows_total"]
+    assert len(set(out["config"]["rows_per_rank"])) > 1          # uneven shards
+    assert out["scaling"] == "strong" and "row-shard x8" in out["config"]["parallelism"]
+    assert "launching 8 ranks" in r.stderr
 
 
 def test_gpus_2_on_a_one_gpu_box_fails_loudly():
