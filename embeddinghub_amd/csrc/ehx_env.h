@@ -21,7 +21,7 @@ struct Env {
   // ---- int8 filter scan ----
   uint32_t i8_growth = 0;         // EHX_I8_GROWTH [2, 64]: rows of pass i+1 / rows of pass i (0: automatic, ehx_flat.cpp)
   double i8_safety = 2.0;         // EHX_I8_SAFETY >= 1: slack of the rank a middle pass's threshold is taken at
-  int i8_sync = 0;                // EHX_I8_SYNC: 0 off, N > 0 lock-step by tile with tolerance N, "rev" (-1) by ring revolution
+  int i8_sync = 0;                // EHX_I8_SYNC: 0 off, N > 0 lock-step by tile with tolerance N tiles
   long i8_kprime = 0;             // EHX_I8_KPRIME >= 64: fixed logical length of the candidate list (0: automatic)
   uint32_t i8_first_tiles = 0;    // EHX_I8_FIRST_TILES [64, 65536]: tiles of the cascade's first pass (0: automatic)
   uint64_t i8_first_keys = 0;     // EHX_I8_FIRST_KEYS: keys per query the first pass aims for (0: automatic)
@@ -31,10 +31,9 @@ struct Env {
   bool i8_trace = false;          // EHX_I8_TRACE: every adaptation of the candidate list on stderr
   bool i8_count = false;          // EHX_I8_COUNT: (builds with -DEHX_I8_COUNT=1) epilogue counters per batch on stderr
   bool i8_debug = false;          // EHX_I8_DEBUG: what the uncertified queries of a batch look like, on stderr
-  bool i8_fused = true;           // EHX_I8_FUSED=0: (builds with -DEHX_I8_FUSED=1) the fused epilogue off
   bool i8_qres = true;            // EHX_I8_QRES=0: short rows through the query ring instead of the resident query tile
   bool i8_half = true;            // EHX_I8_HALF=0: rows of <= 128 dims through full-tile workgroups (one per CU)
-  uint32_t i8_skew = 56;          // EHX_I8_SKEW: half-tile workgroups: start skew of a SIMD's second wave, x 64 cycles (0: none)
+  uint32_t i8_skew = 64;          // EHX_I8_SKEW: half-tile workgroups: start skew of a SIMD's second wave, x 64 cycles (0: none)
   bool rerank_staged = true;      // EHX_RERANK_STAGED=0: every lane of the re-rank walks its own row
   // ---- graph mode ----
   uint64_t build_div = 0;         // EHX_BUILD_DIV >= 2: a bulk-build round is at most 1/DIV of the graph it joins
@@ -69,11 +68,8 @@ inline const Env& env() {
       v.i8_safety = x < 1.0 ? 1.0 : x;
     }
     if (const char* g = str("EHX_I8_SYNC")) {
-      if (!strcmp(g, "rev")) v.i8_sync = -1;
-      else {
-        const int x = atoi(g);
-        v.i8_sync = x < 0 ? 0 : (x > 64 ? 64 : x);
-      }
+      const int x = atoi(g);
+      v.i8_sync = x < 0 ? 0 : (x > 64 ? 64 : x);
     }
     if (const char* g = str("EHX_I8_KPRIME")) v.i8_kprime = atol(g);
     if (const char* g = str("EHX_I8_FIRST_TILES")) {
@@ -96,7 +92,6 @@ inline const Env& env() {
     v.i8_trace = str("EHX_I8_TRACE") != nullptr;
     v.i8_count = str("EHX_I8_COUNT") != nullptr;
     v.i8_debug = str("EHX_I8_DEBUG") != nullptr;
-    v.i8_fused = flag("EHX_I8_FUSED", true);
     v.i8_qres = flag("EHX_I8_QRES", true);
     v.i8_half = flag("EHX_I8_HALF", true);
     if (const char* g = str("EHX_I8_SKEW")) {

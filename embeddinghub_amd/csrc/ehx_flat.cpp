@@ -277,11 +277,10 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
     // batch, 0 fallbacks over 25 batches; 1.5: 7.44; 1: a query falls to the next engine (profiles/r03_e_i8_safety_sweep.jsonl)
     return env().i8_safety;  // (EHX_I8_SAFETY; 1e9: always the 256th best)
   }();
-  // EHX_I8_SYNC: lock-step of the query-tile workgroups that stream one row chunk (k_flati8.hip).  "rev": by ring
-  // revolution (rounds 2-4: 9 % of the scan time in round 2, 60 % on round 4's kernel); N > 0: by tile, tolerance N tiles
-  // (round 5); 0 / unset: off.
+  // EHX_I8_SYNC = N > 0: lock-step by tile of the query-tile workgroups that stream one row chunk, tolerance N tiles
+  // (k_flati8.hip); 0 / unset: off.
   const int sync_mode = env().i8_sync;
-  const bool use_sync = sync_mode != 0;
+  const bool use_sync = sync_mode > 0;
   constexpr uint32_t kSampleTiles = 8;
   // The int8 bound leaves ~60-75 rows per query ON AVERAGE that it cannot exclude from the top-10 at 10 M rows
   // (scripts/studies/int8_filter_bound.py), with a heavy tail — a query whose 10th neighbour is unusually far has
@@ -422,7 +421,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   // (one record per mark: sc.ev[1] / ev[2] — "scan start / end of the LAST batch" for ehx_stats — are the ring's own events
   // of this batch; a second marker packet at the same place cost ~5 us of queue time each, twice per batch)
   HIP_TRY(hipEventRecord(pr[0], st));
-  sc.last_scan[0] = pr[0];
+  sc.last_scan[0] = sc.last_scan[1] = nullptr;   // (a pass that fails half way leaves no half pair for ehx_stats)
   {  // sample pass: lower bounds of the first 2048 rows -> thr[q] = the k'-th best of them
     ScanPlan sp = plan_scan((uint32_t)nq, kSampleTiles, k, E.n_cus);
     a.dump = sc.dSample8.p;
@@ -435,14 +434,16 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   for (size_t i = 0; i < passes.size(); ++i) {
     const bool last = i + 1 == passes.size();
     a.sync = nullptr;
-    if (use_sync && passes[i].plan.xcd_map && p.q_tiles > 1 && passes[i].plan.tiles_per_chunk >= 4) {
+    if (use_sync && passes[i].plan.xcd_map && p.q_tiles > 1 && passes[i].plan.tiles_per_chunk >= 4 &&
+        passes[i].plan.n_chunks * 4u <= kSyncWordsI8) {   // (four progress words per chunk: ADVICE r05)
       a.sync = sync;
-      a.sync_tol = sync_mode > 0 ? (uint32_t)sync_mode : 0u;
+      a.sync_tol = (uint32_t)sync_mode;
       if (i > 0) HIP_TRY(hipMemsetAsync(sync, 0, kSyncWordsI8 * sizeof(uint32_t), st));
     }
     HIP_TRY(scan(passes[i].plan, passes[i].tile0));
     if (last) {  // (the last select and the re-rank are outside the timed scan phase, like flat_pass's final merge)
       HIP_TRY(hipEventRecord(pr[1], st));
+      sc.last_scan[0] = pr[0];   // both marks of THIS batch, set together
       sc.last_scan[1] = pr[1];
       sc.ring_count++;
     }
@@ -696,7 +697,10 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     std::unique_lock<std::mutex> set_lock(s->i8set[0].mu, std::defer_lock);
     if (kind == kI8) set_lock.lock();
     if (kind == kExhaustive) rc = exhaustive_pass(s, st, m, q, k, oi, od, oc);
-    else if (kind == kI8) rc = flat_pass8(s, 0, st, m, q, k, oi, od, oc, count_stats, &i8_kprime);
+    else if (kind == kI8) {   // (enqueued as one block, like a pipelined host batch's: per-batch scan windows stay clean)
+      std::lock_guard<std::mutex> ql(s->i8_enqueue_mu);
+      rc = flat_pass8(s, 0, st, m, q, k, oi, od, oc, count_stats, &i8_kprime);
+    }
     else rc = flat_pass(s, st, m, q, k, oi, od, oc, kind == kFilter, count_stats);
     if (rc) return rc;
     unsigned long long* d_unc = kind == kI8 ? s->i8set[0].dUncert : s->dUncert16;

@@ -339,7 +339,7 @@ struct ehx_space {
     DevBuf<float2> dQuv;
     DevBuf<float> dThr8, dSample8;
     DevBuf<uint64_t> dPool, dMerged8;
-    DevBuf<uint32_t> dI8Ctl;  // [q_rows] pool counts | [q_rows] overflow flags | [256] lock-step counters
+    DevBuf<uint32_t> dI8Ctl;  // [q_rows] pool counts | [q_rows] overflow flags | [kSyncWordsI8] lock-step progress words
     DevBuf<uint32_t> dUflags;
     DevBuf<uint64_t> dCnt;    // [8] epilogue counters of diagnosis builds (EHX_I8_COUNT); the set's own: nothing shared
     unsigned long long* dUncert = nullptr;

@@ -413,6 +413,7 @@ int ehx_knn_keys(ehx_space* s, size_t n_queries, const float* queries, uint32_t 
 int ehx_knn_by_key(ehx_space* s, const char* key, size_t klen, uint32_t k, uint64_t* out_ids, float* out_dist,
                    uint32_t* out_count) {
   if (!valid_space(s) || !key || !out_count) return fail(EHX_EINVAL, "NULL argument");
+  if (k > EHX_MAX_K_PAGED) return fail(EHX_EUNSUPPORTED, "k=%u exceeds %u", k, EHX_MAX_K_PAGED);  // (before k + 1, before any allocation)
   uint64_t id;
   std::vector<float> v(s->dims);
   {
@@ -448,6 +449,7 @@ int ehx_knn_by_key(ehx_space* s, const char* key, size_t klen, uint32_t k, uint6
 int ehx_knn_by_key_keys(ehx_space* s, const char* key, size_t klen, uint32_t k, uint64_t* out_ids, float* out_dist,
                         uint32_t* out_count, char* key_arena, size_t arena_cap, uint64_t* key_off) {
   if (!key_off || !out_count || (!key_arena && arena_cap)) return fail(EHX_EINVAL, "NULL argument");
+  if (k > EHX_MAX_K_PAGED) return fail(EHX_EUNSUPPORTED, "k=%u exceeds %u", k, EHX_MAX_K_PAGED);
   std::vector<uint64_t> ids(k ? k : 1);
   int rc = ehx_knn_by_key(s, key, klen, k, ids.data(), out_dist, out_count);
   if (rc) return rc;
@@ -457,7 +459,10 @@ int ehx_knn_by_key_keys(ehx_space* s, const char* key, size_t klen, uint32_t k, 
   std::string nk;
   for (uint32_t j = 0; j < k; ++j) {
     key_off[j] = off;
-    if (j < *out_count && key_for_id(s, ids[j], &nk) == EHX_OK) {
+    if (j < *out_count) {
+      // (a returned row without a key cannot be answered as "": the RPC would hand back an empty neighbour key)
+      if (key_for_id(s, ids[j], &nk) != EHX_OK)
+        return fail(EHX_EINTERNAL, "row %llu was returned by the search but has no key", (unsigned long long)ids[j]);
       if (off + nk.size() > arena_cap) return fail(EHX_ERANGE, "key arena too small");
       memcpy(key_arena + off, nk.data(), nk.size());
       off += nk.size();

@@ -41,13 +41,13 @@
 //   query — the next engine of the chain answers it.
 // A cascade of passes x4 in rows keeps the hits at ~2-3 k' per query and pass.
 //
-// Lock-step (optional, ScanArgsI8::sync, OFF): the q_tiles workgroups that stream the same row chunk sit on one XCD and
-// share its L2, but nothing keeps them together, and once they drift apart by more than the L2 holds every one of
-// them fetches the rows from HBM again (round 4's kernel: 1.2-1.5 x the algorithmic traffic).  Each workgroup
-// announces every finished ring revolution on a per-chunk counter and does not run more than ~2 revolutions ahead
-// of its slowest sibling; the poll is an asynchronous 4-byte global->LDS load issued a revolution before its value
-// is looked at.  The wait is bounded (a sibling that is not resident must not hang the launch).  It removes the
-// re-reads (1.03 x) and costs 60 % of the scan time on the round-4 kernel.
+// Lock-step (optional, ScanArgsI8::sync / sync_tol, EHX_I8_SYNC=N): the q_tiles workgroups that stream the same row chunk
+// sit on one XCD and share its L2, but nothing keeps them together, and once they drift apart by more than the L2 holds
+// every one of them fetches the rows from HBM again (1.13 x the algorithmic traffic at 10 M x 768).  By TILE: each
+// workgroup publishes how many tiles it has finished in a word of its own and does not run more than N tiles ahead of
+// its slowest sibling (details at after_tile).  1.04 x the traffic for +1.3 % time (profiles/r05_m_*); the default is
+// decided by measurement with something else on the bus.  (Rounds 2-4 synchronised by ring REVOLUTION with
+// one shared counter: superseded, removed in round 6 — profiles/r05_l_sync.jsonl is its record.)
 #include "ehx_env.h"
 #include "ehx_kernels.h"
 #include "k_scan_common.h"
@@ -107,18 +107,9 @@ static_assert(kTileRows16 == 256 && kTileQ == 256, "kernel geometry is hard-wire
 #ifndef EHX_I8_COUNT
 #define EHX_I8_COUNT 0
 #endif
-// EHX_I8_FUSED (round 4 experiment, NOT in the shipped library: build with EHX_DEFS=-DEHX_I8_FUSED=1, then the
-// environment variable EHX_I8_FUSED=0/1 switches at run time): the epilogue of tile t-1 runs INSIDE the first stage of
-// tile t, row block by row block, its vector instructions between that stage's MFMAs ("fused epilogue" in the kernel).
-// Bit-identical results (243 parity tests, equal id checksums) and 1-5 % SLOWER on every shape measured on one box
-// (profiles/r04_v_ab_flat.jsonl: 10 M x 768 6.25 -> 6.33 ms, 1.25 M x 768 1.14 -> 1.17, 6.25 M x 128 1.19 -> 1.22,
-// 4 M x 384 1.73 -> 1.81): the instructions of the epilogue do not hide behind the MFMAs of their own SIMD (two waves
-// per SIMD already alternate on the matrix pipe with one filler per gap; four more per gap cost issue time), and where
-// the clock is power-limited (1.7 GHz at d = 768) overlap cannot shorten what is an energy bill.  Kept as a switch
-// because it is the obvious next idea and the measurement says no.
-#ifndef EHX_I8_FUSED
-#define EHX_I8_FUSED 0
-#endif
+// (Round 4 built a FUSED epilogue — tile t-1's alarm tests inside the first stage of tile t, between its MFMAs: bit-identical
+// and 1-5 % slower on every shape (profiles/r04_v_ab_flat.jsonl: the epilogue's instructions do not hide behind the MFMAs of
+// their own SIMD, and where the clock is power-limited overlap cannot shorten an energy bill).  Removed in round 6.)
 #if EHX_I8_COUNT
 #define EHX_CNT(I) do { if (lane == 0) atomicAdd((unsigned long long*)a.cand + (I), 1ull); } while (0)
 #else
@@ -247,9 +238,9 @@ size_t scan_i8_lds_bytes() { return I8L<false>::kLdsBytes; }
 // registers each; a stage row's 64 bytes are ONE k-step: lane l holds bytes [16 (l >> 4), +16) of row / query l & 15 of
 // its block — one ds_read_b128 per block and stage, twelve per stage as before.  Every block gets exactly one MFMA
 // per stage.  An accumulator block holds, per lane, rows 4 (l >> 4) + 0..3 of its 16 rows for query l & 15.
-template <bool DUMP, bool REV, bool FUSE, bool QRES = false, bool HALF = false>
+template <bool DUMP, bool REV, bool QRES = false, bool HALF = false>
 __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(const ScanArgsI8 a) {
-  static_assert(!QRES || (!REV && !FUSE && !DUMP), "QRES: the run-time-slot loop of the plain scan only");
+  static_assert(!QRES || (!REV && !DUMP), "QRES: the run-time-slot loop of the plain scan only");
   static_assert(!HALF || QRES, "HALF: short rows, the query tile resident in LDS");
   using L = I8L<HALF>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -522,118 +513,13 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     }
   };
 
-  // =============================== fused epilogue (EHX_I8_FUSED) ===============================
-  // The tile epilogue above sits between two tiles: ~160 vector instructions per wave during which the matrix pipe of
-  // its SIMD idles (both waves of a SIMD are there at the same time — the stage barriers keep them in step), 10 % of a
-  // 768-dim tile and more than half of a 128-dim one.  Fused form: when tile t is done only its four LEVELS are
-  // computed (epi_levels: ti4[cb], one per query of the lane); the accumulators are looked at during the FIRST stage of
-  // tile t+1, whose MFMAs start every block from zero and overwrite it: just before row block rb's four MFMAs, the
-  // lane's 16 accumulators of that row block are compared with their levels (EHX_E1: max, max3, compare per block,
-  // issued between the MFMAs of row block rb-1) and, if any lane of the wave has an alarm, judged exactly
-  // (epi_row_slow: the same hit path as above, the candidates of one 16-row block at a time — their registers are
-  // named statically, no select over the eight row blocks).  Same alarms, same hits; only the order in which a wave
-  // stages them differs (pools are sets).  Only row block 0's test and the levels remain outside the MFMA stream.
-  int ti4[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};  // (no tile waiting: nothing alarms)
-  uint32_t epi_tile_row0 = 0u, epi_rp_off = L::kRowpOff;
-  bool epi_al = false;
-  auto epi_levels = [&](uint32_t t) {  // tile t is complete; its parameters are tp_cur / tg_cur, its rows' in rp_slot
-    epi_tile_row0 = (tile_begin + t) * kTileRows16;
-    epi_rp_off = L::kRowpOff + rp_slot * L::kRowpSlot;
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int j15 = lane_e & 15, qd = lane_e >> 4;
-    const float4 tg = tg_cur;
-    const float gm = qd == 0 ? tg.x : (qd == 1 ? tg.y : (qd == 2 ? tg.z : tg.w));
-    // (v_rcp_f32 is good to 1 ulp: three roundings against a margin of 2e-6 — the level still errs low)
-    const float rgm = (1.0f - 2e-6f) * __builtin_amdgcn_rcpf(gm);
-    const float k_own = i8_alarm_k(tp_cur, qp_lds[wc * 64 + lane_e], qinv_lds[wc * 64 + lane_e]);
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-      // (ds_bpermute directly: __shfl derives its address from the lane id, a loop invariant the compiler then keeps
-      // alive across the stage loop — in scratch)
-      const float kq = __int_as_float(__builtin_amdgcn_ds_bpermute((cb * 16 + j15) << 2, __float_as_int(k_own)));
-      ti4[cb] = (int)fminf(fmaxf(kq * rgm, -2.1e9f), 2.1e9f);
-    }
-  };
-  auto epi_row_slow = [&](const i32x4 (&c)[4], const int rb) {
-    EHX_CNT(1);
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int j15 = lane_e & 15, qd = lane_e >> 4;
-    const uint32_t rbase = (uint32_t)(wr * 128) + 4u * (uint32_t)qd + 16u * (uint32_t)rb;
-    uint32_t pend = 0u;  // bit 4 cb + r
-#pragma unroll
-    for (int cb = 3; cb >= 0; --cb) {
-      uint32_t nib = 0u;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) nib |= (c[cb][r] >= ti4[cb]) ? (1u << r) : 0u;
-      pend = (pend << 4) | nib;
-    }
-    while (__any(pend != 0u)) {
-      EHX_CNT(3);
-      const bool hi = pend != 0u;
-      int v = 0;
-      uint32_t cbv = 0u, r = 0u;
-      if (hi) {
-        const int b = __builtin_ctz(pend);
-        pend &= pend - 1u;
-        cbv = (uint32_t)b >> 2;
-        r = (uint32_t)b & 3u;
-        i32x4 c4 = c[0];
-#pragma unroll
-        for (int cb = 1; cb < 4; ++cb) {
-          const bool pick = cbv == (uint32_t)cb;
-          c4[0] = pick ? c[cb][0] : c4[0];
-          c4[1] = pick ? c[cb][1] : c4[1];
-          c4[2] = pick ? c[cb][2] : c4[2];
-          c4[3] = pick ? c[cb][3] : c4[3];
-        }
-        v = r == 0u ? c4[0] : (r == 1u ? c4[1] : (r == 2u ? c4[2] : c4[3]));
-      }
-      const int ql = (int)(cbv * 16u) + j15;
-      const float4 qq = qp_lds[wc * 64 + ql];
-      i8_hit<HALF>(v, hi, rbase + r, epi_tile_row0, epi_rp_off, qq, ql, w, a.n, stg_n);
-    }
-  };
-#if EHX_I8_ABL & 1
-#define EHX_E1(RB, CB) do { } while (0)
-#define EHX_EGO(RB) do { } while (0)
-#else
-#define EHX_E1(RB, CB)                                                                       \
-  do {                                                                                       \
-    const i32x4 c_ = acc[RB][CB];                                                            \
-    epi_al |= max(max(c_[0], c_[1]), max(c_[2], c_[3])) >= ti4[CB];                          \
-  } while (0)
-#if EHX_I8_ABL & 2
-#define EHX_EGO(RB)                                       \
-  do {                                                    \
-    if (__any(epi_al)) asm volatile("" ::: "memory");     \
-    epi_al = false;                                       \
-  } while (0)
-#else
-#define EHX_EGO(RB)                                       \
-  do {                                                    \
-    EHX_CNT(0);                                           \
-    if (__any(epi_al)) epi_row_slow(acc[RB], RB);         \
-    epi_al = false;                                       \
-  } while (0)
-#endif
-#endif
-  // every row block of the waiting tile, outside any stage (the last tile of the chunk)
-  auto epi_all_rows = [&]() {
-#define EHX_EROW(RB) do { EHX_E1(RB, 0); EHX_E1(RB, 1); EHX_E1(RB, 2); EHX_E1(RB, 3); EHX_EGO(RB); } while (0)
-    EHX_EROW(0); EHX_EROW(1); EHX_EROW(2); EHX_EROW(3); EHX_EROW(4); EHX_EROW(5); EHX_EROW(6); EHX_EROW(7);
-#undef EHX_EROW
-  };
-
   // ---- lock-step with the sibling workgroups of this chunk (see the header) ----
-  const bool sync_by_tile = a.sync_tol > 0u;   // per-sibling progress words, checked once per tile (REV loop only)
-  uint32_t* const sync_ctr = (a.sync && a.xcd_map && a.q_tiles > 1 && (!sync_by_tile || (REV && a.q_tiles <= 4)))
-                                 ? a.sync + (sync_by_tile ? chunk * 4u : chunk)
+  // per-sibling progress words [chunk][4], checked once per tile (REV loop only; the launcher guarantees n_chunks * 4 words)
+  uint32_t* const sync_ctr = (a.sync && a.sync_tol > 0u && a.xcd_map && a.q_tiles > 1 && REV && a.q_tiles <= 4)
+                                 ? a.sync + chunk * 4u
                                  : nullptr;
   bool sync_on = sync_ctr != nullptr && !DUMP && !HALF;
-  uint32_t sync_m0 = L::kSyncOff;
-  uint32_t sync_voff = 0u;
+  const uint32_t sync_m0 = L::kSyncOff;
 
   __syncthreads();  // state init visible
   if constexpr (HALF) {
@@ -646,8 +532,10 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     if (a.skew && my_tiles >= 16u) {
       uint32_t hwid;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-      if (hwid & 1u)
-        for (uint32_t i = 0; i < a.skew; i += 32) __builtin_amdgcn_s_sleep(32);
+      if (hwid & 1u) {   // (s_sleep N = 64 N cycles; whole blocks of 32, then the remainder in steps of 1: EHX_I8_SKEW is exact)
+        for (uint32_t i = 32; i <= a.skew; i += 32) __builtin_amdgcn_s_sleep(32);
+        for (uint32_t i = 0; i < (a.skew & 31u); ++i) __builtin_amdgcn_s_sleep(1);
+      }
     }
   }
   if (my_tiles > 0) {  // (a chunk past the end of the pass has nothing to scan and must not touch memory)
@@ -778,65 +666,6 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
                      EHX_SDMA_Q1(sd));                                                                   \
   } while (0)
 
-  // Fused first stage of a tile (EHX_I8_FUSED): the stage body with every block's first MFMA (from zero), row block
-  // rb+1's alarm test between the MFMAs of row block rb, and the (rare) exact judgement of a row block right before
-  // its accumulators are overwritten.
-#define EHX_STAGE16_FUSED(BC, BN, AN, BNX, DX0, DQ0, DX1, DQ1)                                           \
-  do {                                                                                                   \
-    EHX_E1(0, 0); EHX_E1(0, 1); EHX_E1(0, 2); EHX_E1(0, 3); EHX_EGO(0); EHX_SB();                        \
-    EHX_MFZ(BC, 0, 0); DX0; EHX_E1(1, 0);                  EHX_SB();                                     \
-    EHX_MFZ(BC, 0, 1);      EHX_E1(1, 1);                  EHX_SB();                                     \
-    EHX_MFZ(BC, 0, 2); DQ0; EHX_E1(1, 2);                  EHX_SB();                                     \
-    EHX_MFZ(BC, 0, 3);      EHX_E1(1, 3);                  EHX_SB();                                     \
-    EHX_EGO(1);                                            EHX_SB();                                     \
-    EHX_MFZ(BC, 1, 0); DX1; EHX_E1(2, 0);                  EHX_SB();                                     \
-    EHX_MFZ(BC, 1, 1);      EHX_E1(2, 1);                  EHX_SB();                                     \
-    EHX_MFZ(BC, 1, 2); DQ1; EHX_E1(2, 2);                  EHX_SB();                                     \
-    EHX_MFZ(BC, 1, 3);      EHX_E1(2, 3);                  EHX_SB();                                     \
-    EHX_EGO(2);                                            EHX_SB();                                     \
-    EHX_MFZ(BC, 2, 0);      EHX_E1(3, 0);                  EHX_SB();                                     \
-    EHX_MFZ(BC, 2, 1);      EHX_E1(3, 1);                  EHX_SB();                                     \
-    EHX_MFZ(BC, 2, 2);      EHX_E1(3, 2);                  EHX_SB();                                     \
-    EHX_MFZ(BC, 2, 3);      EHX_E1(3, 3);                  EHX_SB();                                     \
-    EHX_EGO(3);                                            EHX_SB();                                     \
-    EHX_MFZ(BC, 3, 0);      EHX_E1(4, 0);                  EHX_SB();                                     \
-    EHX_MFZ(BC, 3, 1);      EHX_E1(4, 1);                  EHX_SB();                                     \
-    EHX_MFZ(BC, 3, 2);      EHX_E1(4, 2);                  EHX_SB();                                     \
-    EHX_MFZ(BC, 3, 3);      EHX_E1(4, 3);                  EHX_SB();                                     \
-    EHX_EGO(4);                                            EHX_SB();                                     \
-    wait_vmcnt<kStageWait>();                                                                            \
-    EHX_STAGE_BARRIER();                                                                                 \
-    EHX_SB();                                                                                            \
-    EHX_MFZ(BC, 4, 0); BN[0] = EHX_FR(smem + (BNX));        EHX_E1(5, 0); EHX_SB();                      \
-    EHX_MFZ(BC, 4, 1); BN[1] = EHX_FR(smem + (BNX) + 1024); EHX_E1(5, 1); EHX_SB();                      \
-    EHX_MFZ(BC, 4, 2); BN[2] = EHX_FR(smem + (BNX) + 2048); EHX_E1(5, 2); EHX_SB();                      \
-    EHX_MFZ(BC, 4, 3); BN[3] = EHX_FR(smem + (BNX) + 3072); EHX_E1(5, 3); EHX_SB();                      \
-    EHX_EGO(5);                                            EHX_SB();                                     \
-    EHX_MFZ(BC, 5, 0); fa[0] = EHX_FR(smem + (AN));         EHX_E1(6, 0); EHX_SB();                      \
-    EHX_MFZ(BC, 5, 1); fa[1] = EHX_FR(smem + (AN) + 1024);  EHX_E1(6, 1); EHX_SB();                      \
-    EHX_MFZ(BC, 5, 2); fa[2] = EHX_FR(smem + (AN) + 2048);  EHX_E1(6, 2); EHX_SB();                      \
-    EHX_MFZ(BC, 5, 3); fa[3] = EHX_FR(smem + (AN) + 3072);  EHX_E1(6, 3); EHX_SB();                      \
-    EHX_EGO(6);                                            EHX_SB();                                     \
-    EHX_MFZ(BC, 6, 0); fa[4] = EHX_FR(smem + (AN) + 4096);  EHX_E1(7, 0); EHX_SB();                      \
-    EHX_MFZ(BC, 6, 1); fa[5] = EHX_FR(smem + (AN) + 5120);  EHX_E1(7, 1); EHX_SB();                      \
-    EHX_MFZ(BC, 6, 2);                                      EHX_E1(7, 2); EHX_SB();                      \
-    EHX_MFZ(BC, 6, 3);                                      EHX_E1(7, 3); EHX_SB();                      \
-    EHX_EGO(7);                                            EHX_SB();                                     \
-    EHX_MFZ(BC, 7, 0); fa[6] = EHX_FR(smem + (AN) + 6144); EHX_SB();                                     \
-    EHX_MFZ(BC, 7, 1);                                     EHX_SB();                                     \
-    EHX_MFZ(BC, 7, 2);                                     EHX_SB();                                     \
-    EHX_MFZ(BC, 7, 3);                                     EHX_SB();                                     \
-    fa[7] = EHX_FR(smem + (AN) + 7168);                    EHX_SB();                                     \
-  } while (0)
-#define EHX_STAGE16_FUSED_CT(S, BC, BN)                                                                  \
-  do {                                                                                                   \
-    constexpr uint32_t sn = (uint32_t)(((S) + 1) & 3) * kStageI8;                                        \
-    constexpr int sd = ((S) + 3) & 3;                                                                    \
-    EHX_STAGE16_FUSED(BC, BN, a_off + sn, b_off + sn, EHX_SDMA_X0(sd), EHX_SDMA_Q0(sd), EHX_SDMA_X1(sd), \
-                      EHX_SDMA_Q1(sd));                                                                  \
-  } while (0)
-  constexpr bool kFused = FUSE && !DUMP;
-
   // Two loops over the same stage body.  REV (a tile is a whole number of ring revolutions, ld % 256 == 0: d = 768, 1536,
   // 1024, 512, 256 ...): the ring slot of every stage is a compile-time constant.  Otherwise (d = 128, 384, 640 ...):
   // one loop over single stages whose slot is a scalar.
@@ -847,7 +676,6 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     // row parameters of tile 1 (consumed by its epilogue, a whole tile from now)
     rsrc += kTileRows16 * 16;
     if (w < (int)L::kRowpWaves) EHX_DMA(rdst, L::kRowpSlot, voff, rsrc);
-    uint32_t q = 0;
     // Lock-step by TILE (round 5; a.sync_tol = the tolerance in tiles): each of the chunk's query-tile workgroups
     // publishes how many tiles it has completed in a word of its own (a plain store: no read-modify-write, no return
     // value to wait for) and, once per tile, looks at a snapshot of its siblings' words taken a tile earlier (an
@@ -857,7 +685,7 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     // (sync_tol + 1) tiles x 192 KiB at d = 768.  One foreign store per tile in the vmcnt queue (see the header: more
     // than one outstanding could let a counted wait pass early; a tile is ~10 us, the store retires in ~1).
     auto after_tile = [&](const uint32_t t) {
-      if (sync_on && sync_by_tile && w == 0) {
+      if (sync_on && w == 0) {
         // (the snapshot is read with a REAL LDS instruction: through the volatile generic pointer the compiler emitted
         // flat_load_dword + s_waitcnt vmcnt(0) — the whole DMA look-ahead of the wave drained at every look, which is what
         // the lock-step "cost" in rounds 2-4 and in this round's first measurement: +7.7 % by tile, +60 % by revolution)
@@ -896,62 +724,25 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
                      : "memory");
       }
     };
-    auto after_revolution = [&]() {
-      if (sync_on && !sync_by_tile && w == 0) {
-        // revolution q is done.  The snapshot taken after revolution q-1 (landed long ago: four stage waits have
-        // passed) must show every sibling through revolution q-2; then announce q and take the next snapshot.
-        uint32_t seen;
-        {
-          const uint32_t snap_at = L::kSyncOff;   // (a real ds_read: see after_tile)
-          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(snap_at) : "memory");
-        }
-        seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
-        const uint32_t need = q >= 2 ? a.q_tiles * (q - 1) : 0u;
-        if (seen < need) {
-          uint32_t spins = 0;
-          while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <
-                 need) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > 4000u) {  // a sibling is not resident (or died): never hang, just stop synchronising
-              sync_on = false;
-              break;
-            }
-          }
-        }
-        if (lane == 0) __hip_atomic_fetch_add(sync_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1"
-                     :
-                     : "s"(sync_m0), "v"(sync_voff), "s"(sync_ctr)
-                     : "memory");
-      }
-      ++q;
-    };
     for (uint32_t t = 0; t < my_tiles; ++t) {
-      if constexpr (kFused) EHX_STAGE16_FUSED_CT(0, fb0, fb1);
-      else EHX_STAGE16_CT(0, EHX_MFZ, fb0, fb1);
+      EHX_STAGE16_CT(0, EHX_MFZ, fb0, fb1);
       EHX_STAGE16_CT(1, EHX_MF, fb1, fb0);
       EHX_STAGE16_CT(2, EHX_MF, fb0, fb1);
       EHX_STAGE16_CT(3, EHX_MF, fb1, fb0);
-      after_revolution();
       for (uint32_t kq = 1; kq < kquads; ++kq) {
         EHX_STAGE16_CT(0, EHX_MF, fb0, fb1);
         EHX_STAGE16_CT(1, EHX_MF, fb1, fb0);
         EHX_STAGE16_CT(2, EHX_MF, fb0, fb1);
         EHX_STAGE16_CT(3, EHX_MF, fb1, fb0);
-        after_revolution();
       }
       // (the lock-step's store and snapshot load go out BEFORE the epilogue: the rows of tile t are consumed — that is
       // what the siblings' L2 window is about — and the store, which retires out of order and makes the next counted wait
       // one entry stricter while it is in flight, gets the epilogue and half a stage to come back: issued after the
       // epilogue it cost 5 % of the scan time, profiles/r05_l_sync.jsonl)
       after_tile(t);
-      if constexpr (kFused) {
-        epi_levels(t);  // (the accumulators are judged inside the next tile's first stage, or after the loop)
-      } else {
 #if !(EHX_I8_ABL & 1)
-        epilogue(t);
+      epilogue(t);
 #endif
-      }
       // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
       // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
       qsrc = qbase + 3 * kStageI8;
@@ -966,7 +757,6 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
         EHX_DMA(rd, 0, voff, rsrc);
       }
     }
-    if constexpr (kFused) epi_all_rows();  // the chunk's last tile
   } else {
     // One flat loop over the stages of the chunk; a tile is `ktiles` of them (ld / 64: any number).  The tile boundary
     // work hangs off a counter and may fall anywhere in a revolution: nothing in the ring depends on where a tile starts
@@ -978,10 +768,6 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     rsrc += kTileRows16 * 16;
     if (w < (int)L::kRowpWaves) EHX_DMA(rdst, L::kRowpSlot, voff, rsrc);
     uint32_t ks = 0, t = 0, slot = 0;
-    // (FUSE needs tiles of two stages or more — the launcher sees to it: the row parameters of the tile after next are
-    // copied over the previous tile's at the end of a tile, and only a later stage barrier of the same tile guarantees
-    // that every wave has finished judging the previous one)
-    constexpr bool fuse = kFused;
     // one stage whose ring slot is a run-time value: STAGE is the stage body to use (first stage of a tile or not)
 #define EHX_RT_DX0 EHX_SDMA(dx0, voff, xsrc)
 #define EHX_RT_DQ0 do { if constexpr (!QRES) EHX_SDMA(dq0, voff, qsrc); } while (0)
@@ -1000,44 +786,12 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     if constexpr (!QRES) qsrc += kStageI8;                                                   \
     _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) fb0[cb] = fb1[cb];                      \
     slot = (slot + 1u) & 3u;                                                                 \
-    if (sync_on && w == 0 && slot == 0u) after_revolution_rt(st >> 2);                       \
     ++st;                                                                                    \
   } while (0)
-    auto after_revolution_rt = [&](const uint32_t q) {
-      // revolution q is done.  The snapshot taken after revolution q-1 (landed long ago: four stage waits have
-      // passed) must show every sibling through revolution q-2; then announce q and take the next snapshot.
-      uint32_t seen;
-      {
-        const uint32_t snap_at = L::kSyncOff;   // (a real ds_read: see after_tile)
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(snap_at) : "memory");
-      }
-      seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
-      const uint32_t need = q >= 2 ? a.q_tiles * (q - 1) : 0u;
-      if (seen < need) {
-        uint32_t spins = 0;
-        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <
-               need) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++spins > 4000u) {  // a sibling is not resident (or died): never hang, just stop synchronising
-            sync_on = false;
-            break;
-          }
-        }
-      }
-      if (lane == 0) __hip_atomic_fetch_add(sync_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1"
-                   :
-                   : "s"(sync_m0), "v"(sync_voff), "s"(sync_ctr)
-                   : "memory");
-    };
     auto tile_done = [&]() {  // t: the tile that has just been completed
-      if constexpr (fuse) {
-        epi_levels(t);
-      } else {
 #if !(EHX_I8_ABL & 1)
-        epilogue(t);
+      epilogue(t);
 #endif
-      }
       ++t;
       // next tile: its stage 3 is the next one to issue (stages 0..2 came from the repeated blocks); row
       // parameters of the tile after it (past the last tile: the array's two tiles of tail padding)
@@ -1054,29 +808,15 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
       }
     };
     uint32_t st = 0;
-    if constexpr (fuse) {
-      // tile by tile: the first stage (with the previous tile's epilogue inside) and the others are separate code — one
-      // loop over both forms behind a branch cost the accumulators their fixed registers (copies and scratch)
 #pragma unroll 1
-      for (uint32_t tt = 0; tt < my_tiles; ++tt) {
+    while (st < total_stages) {
+      if (ks == 0u)
+        EHX_RT_STAGE(EHX_STAGE16_BODY(EHX_MFZ, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
+      else
+        EHX_RT_STAGE(EHX_STAGE16_BODY(EHX_MF, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
+      if (++ks == ktiles) {
         ks = 0;
-        EHX_RT_STAGE(EHX_STAGE16_FUSED(fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
-#pragma unroll 1
-        for (ks = 1; ks < ktiles; ++ks)
-          EHX_RT_STAGE(EHX_STAGE16_BODY(EHX_MF, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
         tile_done();
-      }
-    } else {
-#pragma unroll 1
-      while (st < total_stages) {
-        if (ks == 0u)
-          EHX_RT_STAGE(EHX_STAGE16_BODY(EHX_MFZ, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
-        else
-          EHX_RT_STAGE(EHX_STAGE16_BODY(EHX_MF, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
-        if (++ks == ktiles) {
-          ks = 0;
-          tile_done();
-        }
       }
     }
 #undef EHX_RT_STAGE
@@ -1084,7 +824,6 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
 #undef EHX_RT_DQ0
 #undef EHX_RT_DX1
 #undef EHX_RT_DQ1
-    if constexpr (fuse) epi_all_rows();  // the chunk's last tile
   }
   }  // my_tiles > 0
 #undef EHX_MF
@@ -1098,10 +837,6 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
 #undef EHX_SDMA_Q1
 #undef EHX_STAGE16_CT
 #undef EHX_STAGE16_BODY
-#undef EHX_STAGE16_FUSED_CT
-#undef EHX_STAGE16_FUSED
-#undef EHX_E1
-#undef EHX_EGO
 #undef EHX_STAGE_BARRIER
 #undef EHX_MFZ
 #undef EHX_DMA_X0
@@ -1120,44 +855,31 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
 
 hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st) {
   static DynLdsAttr attr;
-  const void* fns[] = {(const void*)flat_scan_i8_kernel<false, true, false>, (const void*)flat_scan_i8_kernel<false, false, false>,
-                       (const void*)flat_scan_i8_kernel<true, true, false>, (const void*)flat_scan_i8_kernel<true, false, false>,
-                       (const void*)flat_scan_i8_kernel<false, false, false, true>,
-                       (const void*)flat_scan_i8_kernel<false, false, false, true, true>,
-#if EHX_I8_FUSED
-                       (const void*)flat_scan_i8_kernel<false, true, true>, (const void*)flat_scan_i8_kernel<false, false, true>,
-#endif
-  };
+  const void* fns[] = {(const void*)flat_scan_i8_kernel<false, true>, (const void*)flat_scan_i8_kernel<false, false>,
+                       (const void*)flat_scan_i8_kernel<true, true>, (const void*)flat_scan_i8_kernel<true, false>,
+                       (const void*)flat_scan_i8_kernel<false, false, true>,
+                       (const void*)flat_scan_i8_kernel<false, false, true, true>};
   if (hipError_t e = attr.ensure(fns, (int)(sizeof(fns) / sizeof(fns[0])), I8L<false>::kLdsBytes); e != hipSuccess) return e;
   if (a.ld == 0 || a.ld % kRowBI8) return hipErrorInvalidValue;
   const uint32_t grid = a.q_tiles * a.n_chunks;
   const bool rev = a.ld % (4 * kRowBI8) == 0;  // whole ring revolutions per tile: the compile-time-slot loop
-#define EHX_LAUNCH_I8(D, R, F) \
-  hipLaunchKernelGGL((flat_scan_i8_kernel<D, R, F>), dim3(grid), dim3(I8L<false>::kThreads), I8L<false>::kLdsBytes, st, a)
-#if EHX_I8_FUSED
-  // the epilogue inside the next tile's first stage: tiles of at least two stages (see the kernel), never the sample pass
-  const bool fused_on = env().i8_fused;
-  if (fused_on && !a.dump && a.ld >= 2 * kRowBI8) {
-    if (rev) EHX_LAUNCH_I8(false, true, true);
-    else EHX_LAUNCH_I8(false, false, true);
-    return hipGetLastError();
-  }
-#endif
+#define EHX_LAUNCH_I8(D, R) \
+  hipLaunchKernelGGL((flat_scan_i8_kernel<D, R>), dim3(grid), dim3(I8L<false>::kThreads), I8L<false>::kLdsBytes, st, a)
   // short rows (a tile of at most four stages): the query tile resident in LDS (QRES in the kernel); EHX_I8_QRES=0: off
   const bool qres_on = env().i8_qres;
   if (a.dump) {
-    if (rev) EHX_LAUNCH_I8(true, true, false);
-    else EHX_LAUNCH_I8(true, false, false);
+    if (rev) EHX_LAUNCH_I8(true, true);
+    else EHX_LAUNCH_I8(true, false);
   } else {
     // short rows of at most two stages: two half-tile workgroups per CU (HALF in the kernel); EHX_I8_HALF=0: off
     const bool half_on = env().i8_half;
-    if (rev) EHX_LAUNCH_I8(false, true, false);
+    if (rev) EHX_LAUNCH_I8(false, true);
     else if (qres_on && half_on && a.ld <= 2 * kRowBI8)
-      hipLaunchKernelGGL((flat_scan_i8_kernel<false, false, false, true, true>), dim3(2 * grid), dim3(I8L<true>::kThreads),
+      hipLaunchKernelGGL((flat_scan_i8_kernel<false, false, true, true>), dim3(2 * grid), dim3(I8L<true>::kThreads),
                          I8L<true>::kLdsBytes, st, a);
     else if (qres_on && a.ld <= 4 * kRowBI8)
-      hipLaunchKernelGGL((flat_scan_i8_kernel<false, false, false, true>), dim3(grid), dim3(I8L<false>::kThreads), I8L<false>::kLdsBytes, st, a);
-    else EHX_LAUNCH_I8(false, false, false);
+      hipLaunchKernelGGL((flat_scan_i8_kernel<false, false, true>), dim3(grid), dim3(I8L<false>::kThreads), I8L<false>::kLdsBytes, st, a);
+    else EHX_LAUNCH_I8(false, false);
   }
 #undef EHX_LAUNCH_I8
   return hipGetLastError();

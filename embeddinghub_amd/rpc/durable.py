@@ -132,11 +132,19 @@ class DurableSpace:
         self._inner, self._log, self._owner, self._name = inner, log, owner, name
         self.dims = inner.dims
         self._mu = threading.Lock()
+        self._freeze_waiting = 0   # FreezeSpace calls waiting for the space: writers stand back while it is > 0
 
     def set(self, key, vec):
         self.set_batch([key], [vec])
 
     def set_batch(self, keys, vecs):
+        # A pending freeze goes first: under back-to-back writes the space's lock is free for microseconds at a time and a
+        # freeze that only TRIES the lock (below) could miss it for ever.  A writer that finds a freeze waiting
+        # steps aside until it is through — and is then refused by the engine ("Cannot write to immutable space"), as the
+        # reference's mutex order would have it.
+        import time as _time
+        while self._freeze_waiting:
+            _time.sleep(0.001)
         with self._mu:  # the log order is the apply order
             # log first, then apply: a write is never served without being persisted.  If the engine refuses the
             # rows (immutable space, allocation failure ...) the log is cut back, so a restart does not replay them.
@@ -157,17 +165,24 @@ class DurableSpace:
         # thread sleeps before the next try — Python locks are not fair: a loop that re-took the store's lock at once kept
         # it away from everybody else for as long as the space stayed busy.
         import time as _time
-        while True:
-            with self._owner._mu:
-                if self._mu.acquire(blocking=False):
-                    try:
-                        self._inner.freeze()
-                        if self._owner._spaces.get(self._name) is self:  # (a stale handle of a deleted space records nothing)
-                            self._owner._catalog(_FREEZE, self._name, self.dims)
-                    finally:
-                        self._mu.release()
-                    return
-            _time.sleep(0.01)
+        deadline = _time.monotonic() + 120.0
+        self._freeze_waiting += 1      # (under the GIL; writers poll it before they take the space's lock)
+        try:
+            while True:
+                with self._owner._mu:
+                    if self._mu.acquire(blocking=False):
+                        try:
+                            self._inner.freeze()
+                            if self._owner._spaces.get(self._name) is self:  # (a stale handle of a deleted space records nothing)
+                                self._owner._catalog(_FREEZE, self._name, self.dims)
+                        finally:
+                            self._mu.release()
+                        return
+                if _time.monotonic() > deadline:   # (one write cannot take this long; a bounded wait, not a hang)
+                    raise TimeoutError("FreezeSpace(%r): the space stayed busy for 120 s" % self._name)
+                _time.sleep(0.002)
+        finally:
+            self._freeze_waiting -= 1
 
     def __getattr__(self, name):  # get / nearest / keys_sorted / __len__ ... : straight through
         return getattr(self._inner, name)
