@@ -110,6 +110,10 @@ static_assert(kTileRows16 == 256 && kTileQ == 256, "kernel geometry is hard-wire
 // (Round 4 built a FUSED epilogue — tile t-1's alarm tests inside the first stage of tile t, between its MFMAs: bit-identical
 // and 1-5 % slower on every shape (profiles/r04_v_ab_flat.jsonl: the epilogue's instructions do not hide behind the MFMAs of
 // their own SIMD, and where the clock is power-limited overlap cannot shorten an energy bill).  Removed in round 6.)
+// A/B build: static issue priority for the second-resident wave of every SIMD (measured in round 6: DESIGN.md)
+#ifndef EHX_I8_PRIO
+#define EHX_I8_PRIO 0
+#endif
 #if EHX_I8_COUNT
 #define EHX_CNT(I) do { if (lane == 0) atomicAdd((unsigned long long*)a.cand + (I), 1ull); } while (0)
 #else
@@ -522,6 +526,15 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
   const uint32_t sync_m0 = L::kSyncOff;
 
   __syncthreads();  // state init visible
+#if EHX_I8_PRIO
+  // Static priority for the arbitration loser (MI355X_MICROARCH.md, "Two waves per SIMD" item 4): of the two waves a SIMD
+  // holds, the younger one gets the leftover issue slots on every stage; ONE s_setprio 1 for it, no per-stage flips.
+  {
+    uint32_t hwid_p;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_p));
+    if (hwid_p & 1u) __builtin_amdgcn_s_setprio(1);   // (hardware wave slot of the SIMD: the second-resident wave)
+  }
+#endif
   if constexpr (HALF) {
     // Two half-tile workgroups share a CU so that one's tile epilogue (vector ALU) runs beside the other's matrix work —
     // but two identical workgroups launched together run IN PHASE: both in their matrix stages, then both in their

@@ -50,7 +50,9 @@ def main():
     Q = pyoracle.gen_rows(ehx.SEED_QUERY, 0, B, d, normalize=norm)
     h = None
     manifold = None
-    if args.data.startswith("manifold:"):
+    if args.data.startswith("manifold-dev:"):
+        pass
+    elif args.data.startswith("manifold:"):
         R = int(args.data.split(":")[1])
         A = np.random.default_rng(20250213).standard_normal((R, d)).astype(np.float32) / np.sqrt(R)
 
@@ -62,7 +64,19 @@ def main():
                 x /= np.linalg.norm(x, axis=1, keepdims=True)
             return np.ascontiguousarray(x, dtype=np.float32)
         Q = manifold(ehx.SEED_QUERY + 1000, B)  # (+1000: SEED_QUERY + i equals the seed of corpus chunk i — queries drawn with it are noisy copies of corpus rows)
-    if manifold is not None:
+    if args.data.startswith("manifold-dev:"):
+        # EHX-MANIFOLD-1 rows generated on the device (include/ehx_datagen.h), queries by the oracle's restatement of the
+        # same generator under the query seed: what bench.py's graph_path_structured_10m leg runs
+        R = int(args.data.split(":")[1])
+        Q = pyoracle.gen_manifold_rows(ehx.SEED_QUERY, 0, B, d, R, normalize=norm)
+        g = ehx.Space.unique("gbench", d, metric=em, mode=ehx.MODE_GRAPH, initial_capacity=n, build_batch=args.build_batch)
+        t0 = time.perf_counter()
+        g.fill_manifold(ehx.SEED_CORPUS, 0, n, R, norm)
+        build_s = time.perf_counter() - t0
+        flat = ehx.Space.unique("gbench-flat", d, metric=em, initial_capacity=n)
+        flat.fill_manifold(ehx.SEED_CORPUS, 0, n, R, norm)
+        builder = "GPU-built HNSW over EHX-MANIFOLD-1 rows, R = %d (batched insertion, %.0f rows/s)" % (R, n / build_s)
+    elif manifold is not None:
         # host-generated rows through the public write path into a graph space (concurrent insertion rounds,
         # build_batch given explicitly) and a flat space (ground truth)
         g = ehx.Space.unique("gbench", d, metric=em, mode=ehx.MODE_GRAPH, initial_capacity=n,
@@ -94,7 +108,7 @@ def main():
         l0, lv, upper = h.export_graph()
         g.graph_import(l0, lv, upper, h.enterpoint, h.maxlevel)
         builder = "oracle-built HNSW"
-    if manifold is None:
+    if manifold is None and not args.data.startswith("manifold-dev:"):
         flat = ehx.Space.unique("gbench-flat", d, metric=em, initial_capacity=n)
         flat.fill_synthetic(ehx.SEED_CORPUS, 0, n, norm)
     truth, _, _ = flat.knn(Q, k)

@@ -5,7 +5,7 @@
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 R=$(pwd)
-ARGS="--steps 4 --warmup 1 --check-queries 0 --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --single-query 0 --no-cpu-baseline --reference-benchmark 0 $BENCH_ARGS"
+ARGS="--steps 4 --warmup 1 --check-queries 0 --no-f32-engine --graph-rows 0 --structured-rows 0 --set-concurrent 0 --single-query 0 --no-cpu-baseline --reference-benchmark 0 --structured-big-rows 0 $BENCH_ARGS"
 run() {  # name, env, rocprof args...
   local name=$1 envs=$2; shift 2
   rm -rf gpurun_out/prof/$name

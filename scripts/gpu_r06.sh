@@ -91,5 +91,25 @@ print("sync=$sync headline %.3f ms/step kernel %.3f frac %.4f | one caller %s | 
 PY
   done
   ;;
+h)  # rocprofv3 evidence of round 6's code: the headline's launch trace + HBM traffic; the wide walk's trace and traffic on the
+    # configs[3] shard and on the 10 M x 768 structured index
+  R=$PWD
+  mkdir -p $O/prof
+  TAG=r06_h PASSES="trace fetch write" BENCH_ARGS="--config-legs 0" bash scripts/gpu_profile_i8.sh 2>&1 | tail -12
+  cp $O/prof/r06_h_i8_*summary.txt $O/prof/r06_h_i8_traffic.json $O/ 2>/dev/null
+  gtrace() {  # tag rows dims metric efs widths data rocprof-args...
+    local tag=$1 rows=$2 dims=$3 metric=$4 efs=$5 widths=$6 data=$7; shift 7
+    rm -rf $O/prof/$tag
+    (cd /tmp && timeout 1500 rocprofv3 --kernel-trace "$@" -d $R/$O/prof/$tag -o p -- python $R/scripts/bench_graph.py --gpu-build \
+       --rows $rows --dims $dims --metric $metric --efs $efs --widths $widths --data $data --reps 4 > $R/$O/r06_h_${tag}.jsonl 2> $R/$O/prof/$tag.err)
+    python scripts/rocpd_summary.py $O/prof/$tag > $O/r06_h_${tag}_summary.txt 2>&1
+    grep -E "graph_search|^kernel" $O/r06_h_${tag}_summary.txt | cut -c1-150 | head -8
+  }
+  gtrace graph_6250k128_trace 6250000 128 l2 200 1,4 gauss --stats
+  gtrace graph_6250k128_fetch 6250000 128 l2 200 1,4 gauss --pmc FETCH_SIZE
+  gtrace graph_s10m768_trace 10000000 768 cosine 60 1,4 manifold-dev:16 --stats
+  gtrace graph_s10m768_fetch 10000000 768 cosine 60 1,4 manifold-dev:16 --pmc FETCH_SIZE
+  find $O/prof -name "*.db" -size +8M -delete
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
