@@ -110,9 +110,12 @@ static_assert(kTileRows16 == 256 && kTileQ == 256, "kernel geometry is hard-wire
 // (Round 4 built a FUSED epilogue — tile t-1's alarm tests inside the first stage of tile t, between its MFMAs: bit-identical
 // and 1-5 % slower on every shape (profiles/r04_v_ab_flat.jsonl: the epilogue's instructions do not hide behind the MFMAs of
 // their own SIMD, and where the clock is power-limited overlap cannot shorten an energy bill).  Removed in round 6.)
-// A/B build: static issue priority for the second-resident wave of every SIMD (measured in round 6: DESIGN.md)
+// Static issue priority for the second-resident wave of every SIMD (-DEHX_I8_PRIO=0: A/B builds without it).  Same-box
+// ABAB, 40 batches each, scan time per batch (profiles/r06_i_prio_ab.jsonl): 6.25 M x 128 1.0103 / 1.0123 -> 1.0002 /
+// 0.9911 ms (-1.5 %), 10 M x 768 5.9394 / 5.9117 -> 5.9103 / 5.9066 (-0.3 %), 1 M x 768 0.7624 / 0.7652 -> 0.7616 / 0.7644;
+// identical id checksums.
 #ifndef EHX_I8_PRIO
-#define EHX_I8_PRIO 0
+#define EHX_I8_PRIO 1
 #endif
 #if EHX_I8_COUNT
 #define EHX_CNT(I) do { if (lane == 0) atomicAdd((unsigned long long*)a.cand + (I), 1ull); } while (0)

@@ -111,5 +111,23 @@ h)  # rocprofv3 evidence of round 6's code: the headline's launch trace + HBM tr
   gtrace graph_s10m768_fetch 10000000 768 cosine 60 1,4 manifold-dev:16 --pmc FETCH_SIZE
   find $O/prof -name "*.db" -size +8M -delete
   ;;
+i)  # static issue priority for the second-resident wave of a SIMD (EHX_I8_PRIO build), same-box ABAB on three shapes; then
+    # the whole GPU suite on the pruned library
+  for rep in 1 2; do
+    for lib in "" _prio; do
+      for shape in "10000000 768 cosine" "6250000 128 l2" "1000000 768 cosine"; do
+        set -- $shape
+        EHX_LIB=$PWD/embeddinghub_amd/lib/libehx$lib.so timeout 600 python scripts/ab_flat.py --rows $1 --dims $2 --metric $3 --steps 40 --label "prio${lib:-_off}" 2>/dev/null >> $O/r06_i_prio_ab.jsonl
+      done
+    done
+  done
+  python - <<PY
+import json
+for l in open("$O/r06_i_prio_ab.jsonl"):
+    r = json.loads(l)
+    print("%-9s %9d x %4d  %.4f ms/step  kernel %.4f ms  checksum %d" % (r["label"], r["rows"], r["dims"], r["ms_per_step"], r["kernel_ms"], r["ids_checksum_last_batch"]))
+PY
+  timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
