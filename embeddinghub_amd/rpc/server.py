@@ -355,10 +355,21 @@ def main(argv=None):
                     help="keep every space in append-only logs under this directory and rebuild them on start "
                          "(the reference persists to RocksDB under ./embedding_store.dat, server.cc:249)")
     ap.add_argument("--sync", action="store_true", help="fsync the logs on every write")
+    ap.add_argument("--mode", choices=["flat", "graph"], default="flat",
+                    help="flat: exact answers (default); graph: the reference's own index (HNSW M=16 efC=200, index.cc:14-15)")
+    ap.add_argument("--ef", type=int, default=0, help="graph mode: search ef (0 = the reference's 10)")
+    ap.add_argument("--build-batch", type=int, default=0,
+                    help="graph mode: rows per concurrent insertion round of MultiSet (0 = one by one, hnswlib's order)")
+    ap.add_argument("--search-width", type=int, choices=[0, 1, 2, 4], default=0,
+                    help="graph mode: expansions per search step (0 / 1 = hnswlib's order; 2 / 4 = the wide walk, a "
+                         "throughput mode — INTEGRATION.md section 5)")
     args = ap.parse_args(argv)
     import embeddinghub_amd as ehx
     metric = {"l2": ehx.METRIC_L2SQ, "ip": ehx.METRIC_IP, "cosine": ehx.METRIC_COSINE}[args.metric]
-    store = EngineStore(metric=metric)
+    kw = {}
+    if args.mode == "graph":
+        kw = dict(mode=ehx.MODE_GRAPH, ef=args.ef, build_batch=args.build_batch, search_width=args.search_width)
+    store = EngineStore(metric=metric, **kw)
     if args.data_dir:
         from .durable import DurableStore
         store = DurableStore(store, args.data_dir, sync=args.sync)

@@ -41,6 +41,9 @@ type MI355XConfig struct {
 	// graph mode: rows per concurrent insertion round of BatchSet (ehx_params.build_batch; 0 = strictly
 	// sequential, the graph single-threaded hnswlib would build; materialization wants e.g. 4096)
 	BuildBatch uint32 `json:"build_batch"`
+	// graph mode: expansions per search step (ehx_params.search_width; 0 / 1 = hnswlib's order, the default; 2 / 4 = the
+	// wide walk, a throughput mode with recall within BASELINE's gate of the strict walk — INTEGRATION.md §5)
+	SearchWidth uint32 `json:"search_width"`
 }
 
 type mi355xOnlineStore struct {
@@ -118,6 +121,7 @@ func (s *mi355xOnlineStore) create(feature, variant string, dims int32) (*mi355x
 	}
 	p.ef = C.uint32_t(s.cfg.EF)
 	p.build_batch = C.uint32_t(s.cfg.BuildBatch)
+	p.search_width = C.uint32_t(s.cfg.SearchWidth)
 	var sp *C.ehx_space
 	rc := C.ehx_space_create(cname, C.size_t(len(name)), C.uint32_t(dims), s.metric(), C.EHX_DTYPE_F32, &p, &sp)
 	switch rc {

@@ -59,9 +59,10 @@ def space_name(feature, variant):           # mi355x.go: spaceName
 class Mi355xOnlineStore:
     """mi355x.go: mi355xOnlineStore (OnlineStore + VectorStore, provider/online.go:42-59)"""
 
-    def __init__(self, devices=(0,), shards=0, metric="cosine", mode="flat", ef=0, build_batch=0):
+    def __init__(self, devices=(0,), shards=0, metric="cosine", mode="flat", ef=0, build_batch=0, search_width=0):
         # mi355xOnlineStoreFactory
-        self.cfg = dict(Devices=list(devices), Shards=shards, Metric=metric, Mode=mode, EF=ef, BuildBatch=build_batch)
+        self.cfg = dict(Devices=list(devices), Shards=shards, Metric=metric, Mode=mode, EF=ef, BuildBatch=build_batch,
+                        SearchWidth=search_width)
         L = self.L = _lib.load()
         devs = (C.c_int * len(devices))(*devices)
         rc = L.ehx_init(devs if len(devices) else None, len(devices))
@@ -97,6 +98,7 @@ class Mi355xOnlineStore:
             p.mode = _lib.MODE_GRAPH
         p.ef = self.cfg["EF"]
         p.build_batch = self.cfg["BuildBatch"]
+        p.search_width = self.cfg["SearchWidth"]
         sp = C.c_void_p()
         rc = L.ehx_space_create(name, len(name), dims, self.metric(), _lib.DTYPE_F32, C.byref(p), C.byref(sp))
         if rc == _lib.OK:
