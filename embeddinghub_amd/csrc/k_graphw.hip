@@ -241,20 +241,29 @@ __global__ __launch_bounds__(64) void graph_search_wide_kernel(const GraphArgs a
     };
     if (nfresh == 0) request_next();
 
-    // ---- distances and merge, 64 fresh rows at a time ----
-    for (uint32_t f0 = 0; f0 < nfresh; f0 += 64) {
-      const uint32_t cnt = nfresh - f0 < 64 ? nfresh - f0 : 64;
-      const bool last = f0 + 64 >= nfresh;
-      const float d = wave_group_dists<METRIC01, true>(qs, a.Xs, a.ld, a.dims, ids_l + f0, cnt, lane, a.xscale);
-      uint64_t mykey = kKeyInf;
-      if ((uint32_t)lane < cnt) mykey = ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)ids_l[f0 + lane] << 1);
+    // ---- distances of every fresh row (64 per pass), then the merge ----
+    constexpr int NCH = P / 2;   // passes of 64 rows a step can need
+    uint64_t key[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      key[c] = kKeyInf;
+      if ((uint32_t)c * 64u < nfresh) {
+        const uint32_t f0 = (uint32_t)c * 64u;
+        const uint32_t cnt = nfresh - f0 < 64 ? nfresh - f0 : 64;
+        const float d = wave_group_dists<METRIC01, true>(qs, a.Xs, a.ld, a.dims, ids_l + f0, cnt, lane, a.xscale);
+        if ((uint32_t)lane < cnt) key[c] = ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)ids_l[f0 + lane] << 1);
+      }
+    }
+    EHX_PROF(2)
+    // one merge of up to 64 keys (lane p holds key p, +inf: none) into R; `last`: the step's last merge — the next step's
+    // adjacency rows are requested inside it, once its keys are ranked
+    auto merge_keys = [&](const uint64_t mykey, const bool last) {
       const uint64_t bound = nR < ef ? kKeyInf : R[ef - 1];
       const bool can = mykey < bound;  // (a key at or above the worst entry of a full list never enters)
       const bool do_merge = __any(can);
-      EHX_PROF(2)
       if (!do_merge) {
         if (last) request_next();
-        continue;
+        return;
       }
       // Only the keys that can enter go on: compacted into batch[0..ncan) (in the steady state of a search — R full —
       // most fresh keys are worse than R's worst entry, and the ranking below costs a trip per 16 keys).
@@ -339,6 +348,41 @@ __global__ __launch_bounds__(64) void graph_search_wide_kernel(const GraphArgs a
         if (p0 < scan_from) scan_from = p0;
       }
       EHX_PROF(5)
+    };
+    if (nfresh != 0) {
+      if (NCH == 1) {
+        merge_keys(key[0], true);
+      } else {
+        // P = 4: a step holds up to 128 fresh keys, but only those below R's worst entry enter — in the steady state of
+        // a search (R full) a handful.  When at most 64 enter they are compacted across the passes and merged ONCE
+        // (rank, insertion points and the move of R are paid per merge); the early steps, which fill R, merge pass by pass.
+        const uint64_t bound0 = nR < ef ? kKeyInf : R[ef - 1];
+        uint64_t cm[NCH];
+        uint32_t ntot = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          cm[c] = __ballot(key[c] < bound0);
+          ntot += (uint32_t)__builtin_popcountll(cm[c]);
+        }
+        if (ntot == 0) {
+          request_next();
+        } else if (ntot <= 64) {
+          uint32_t off = 0;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            if (key[c] < bound0) batch[off + (uint32_t)__builtin_popcountll(cm[c] & lt_mask)] = key[c];
+            off += (uint32_t)__builtin_popcountll(cm[c]);
+          }
+          EHX_GSYNC();
+          const uint64_t mk = (uint32_t)lane < ntot ? batch[lane] : kKeyInf;
+          EHX_GSYNC();
+          merge_keys(mk, true);
+        } else {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+            if ((uint32_t)c * 64u < nfresh) merge_keys(key[c], (uint32_t)(c + 1) * 64u >= nfresh);
+        }
+      }
     }
   }
 

@@ -129,5 +129,17 @@ for l in open("$O/r06_i_prio_ab.jsonl"):
 PY
   timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
   ;;
+j)  # wide walk, P = 4: ONE merge per step when at most 64 keys enter R
+  timeout 1200 python -m pytest tests/test_graph_wide.py -x -q 2>&1 | tail -4
+  graph_bench 6250k128 6250000 128 l2 50,200,800 1,2,4
+  EHX_LIB=$PWD/embeddinghub_amd/lib/libehx_gprof.so graph_bench 6250k128_gprof 6250000 128 l2 200 4
+  python - <<PY
+import json
+for l in open("$O/r06_j_graph_6250k128_gprof.jsonl"):
+    r = json.loads(l)
+    print("w=%d" % r["search_width"], "per step", r["phase_us_per_step"])
+PY
+  graph_bench 2m768 2000000 768 cosine 100,400 1,4
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
