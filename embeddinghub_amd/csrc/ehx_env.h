@@ -40,6 +40,7 @@ struct Env {
   bool build_trace = false;       // EHX_BUILD_TRACE: build progress on stderr (a stream sync every 128 rounds)
   long long build_scratch_keep = -1;  // EHX_BUILD_SCRATCH_KEEP: bytes of scratch a bulk build may keep (-1: automatic)
   bool graph_vislog = true;       // EHX_GRAPH_VISLOG=0: visited bitmaps cleared by a memset per batch, never by the visit log
+  int graph_help = -1;            // EHX_GRAPH_HELP = 0 | 1: the wide walk's helper wave off / on whatever the shape (-1: by shape)
   uint32_t graph_width = 0;       // EHX_GRAPH_WIDTH = 1 | 2 | 4: expansions per step of every graph search (0: the space's search_width)
 };
 
@@ -106,6 +107,7 @@ inline const Env& env() {
     v.build_trace = str("EHX_BUILD_TRACE") != nullptr;
     if (const char* g = str("EHX_BUILD_SCRATCH_KEEP")) v.build_scratch_keep = atoll(g);
     v.graph_vislog = flag("EHX_GRAPH_VISLOG", true);
+    if (const char* g = str("EHX_GRAPH_HELP")) v.graph_help = atoi(g) != 0;
     if (const char* g = str("EHX_GRAPH_WIDTH")) {
       const long x = atol(g);
       if (x == 1 || x == 2 || x == 4) v.graph_width = (uint32_t)x;

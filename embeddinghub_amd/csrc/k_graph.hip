@@ -37,7 +37,8 @@ namespace ehx {
 // (the wide walk, k_graphw.hip, holds 32 ids per expansion of a step: ids[32 * width])
 size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap, uint32_t width) {
   const size_t n_ids = width > 2 ? 32 * (size_t)width : 64;
-  return (size_t)ld * 4 + (size_t)ef_cap * 8 + 64 * 8 * 2 + n_ids * 4 + (((size_t)ef_cap + 15) & ~(size_t)15) + 64;
+  // (+ the wide walk's helper wave: hd[32] f32 + ctrl[2] u32)
+  return (size_t)ld * 4 + (size_t)ef_cap * 8 + 64 * 8 * 2 + n_ids * 4 + (((size_t)ef_cap + 15) & ~(size_t)15) + 32 * 4 + 16 + 64;
 }
 
 // A/B builds: cap the registers so that this many waves share a SIMD (0 = the compiler's choice).  Measured in round 3:

@@ -27,11 +27,19 @@
 
 namespace ehx {
 
-template <int METRIC01, int P>
-__global__ __launch_bounds__(64) void graph_search_wide_kernel(const GraphArgs a) {
+// HELP (short rows, batches that leave SIMDs empty): a second wave per query takes rows 32.. of every 64-row distance pass.
+// A wave's row phase runs at ~10 GB/s whatever it keeps in flight (e.6 in DESIGN.md: a pass of 64 random 512-byte rows takes
+// 2.8 us, one of 32 rows 1.4 us — an address translation per row), and at batch 1024 every SIMD holds one wave: two waves
+// fetch a step's rows side by side.  Same 4-lane-group arithmetic on the same rows: distances, traversal and counters are
+// bit-identical to the one-wave form.  Protocol: wave 0 publishes (first row slot, count), barrier, both compute, barrier,
+// wave 0 reads the helper's distances from LDS; everything else (R, visited set, merges) is wave 0's alone.  (Round 4 tried
+// the same on the strict walk at 3-KB rows, where the memory system — not the wave — bounds the row phase: no gain.)
+template <int METRIC01, int P, bool HELP>
+__global__ __launch_bounds__(HELP ? 128 : 64) void graph_search_wide_kernel(const GraphArgs a) {
   constexpr int NREG = P / 2;  // adjacency registers per lane: slot 64 r + lane = entry (lane & 31) of node 2 r + (lane >> 5)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t qi = blockIdx.x;
   float* qs = (float*)smem;
   uint64_t* R = (uint64_t*)(smem + (size_t)a.ld * 4);
@@ -39,19 +47,38 @@ __global__ __launch_bounds__(64) void graph_search_wide_kernel(const GraphArgs a
   uint64_t* batch = S + 64;
   uint32_t* ids_l = (uint32_t*)(batch + 64);
   uint8_t* F = (uint8_t*)(ids_l + 32 * P);
+  float* hd = (float*)(F + (((size_t)a.ef_cap + 15) & ~(size_t)15));   // HELP: the helper wave's distances [32]
+  volatile uint32_t* ctrl = (volatile uint32_t*)(hd + 32);               // HELP: (count, first slot) of the pass; ~0: done
   uint32_t* pki = (uint32_t*)batch;  // indices of a step's picks (batch[] is free outside the rank phase)
   uint32_t* vis = a.visited + (size_t)qi * a.vis_words;
   uint32_t* vlog = a.vislog + (size_t)qi * a.vislog_cap;
   uint32_t n_logged = 0;
-  for (uint32_t i = lane; i < a.ef_cap; i += 64) F[i] = 0;
+  if (wv == 0)
+    for (uint32_t i = lane; i < a.ef_cap; i += 64) F[i] = 0;
 
-  if (a.q_raw) {  // one query per call in one launch (k_graph.hip)
+  if (wv == 0 && a.q_raw) {  // one query per call in one launch (k_graph.hip)
     prep_query_row(a.q_raw, 1u, a.dims, a.ld, a.metric, const_cast<float*>(a.Q), 0u, lane);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   }
-  for (uint32_t i = lane; i < a.ld; i += 64) qs[search_copy_pos(i)] = a.Q[(size_t)qi * a.ld + i];
-  EHX_GSYNC();
+  if (HELP) __syncthreads();   // (the prepared query row is wave 0's work)
+  for (uint32_t i = threadIdx.x; i < a.ld; i += (HELP ? 128 : 64)) qs[search_copy_pos(i)] = a.Q[(size_t)qi * a.ld + i];
+  if (HELP) __syncthreads();
+  else EHX_GSYNC();
+  if (HELP && wv == 1) {   // the helper wave: rows 32.. of every pass wave 0 publishes
+    for (;;) {
+      __syncthreads();  // A: (count, first slot) are published
+      const uint32_t cnt = ctrl[0];
+      if (cnt == 0xFFFFFFFFu) break;
+      const uint32_t f0 = ctrl[1];
+      if (cnt > 32) {
+        const float d = wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l + f0 + 32, cnt - 32, lane, a.xscale);
+        if ((uint32_t)lane < cnt - 32) hd[lane] = d;
+      }
+      __syncthreads();  // B: the distances are published
+    }
+    return;
+  }
 
   unsigned long long n_dist = 0, n_hops0 = 0, n_hops_up = 0, n_steps = 0, n_pf_hit = 0;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -250,7 +277,19 @@ __global__ __launch_bounds__(64) void graph_search_wide_kernel(const GraphArgs a
       if ((uint32_t)c * 64u < nfresh) {
         const uint32_t f0 = (uint32_t)c * 64u;
         const uint32_t cnt = nfresh - f0 < 64 ? nfresh - f0 : 64;
-        const float d = wave_group_dists<METRIC01, true>(qs, a.Xs, a.ld, a.dims, ids_l + f0, cnt, lane, a.xscale);
+        float d;
+        if (HELP) {
+          if (lane == 0) {
+            ctrl[0] = cnt;
+            ctrl[1] = f0;
+          }
+          __syncthreads();  // A
+          d = wave_group_dists<METRIC01>(qs, a.Xs, a.ld, a.dims, ids_l + f0, cnt < 32 ? cnt : 32, lane, a.xscale);
+          __syncthreads();  // B
+          if (lane >= 32 && (uint32_t)lane < cnt) d = hd[lane - 32];
+        } else {
+          d = wave_group_dists<METRIC01, true>(qs, a.Xs, a.ld, a.dims, ids_l + f0, cnt, lane, a.xscale);
+        }
         if ((uint32_t)lane < cnt) key[c] = ((uint64_t)f32_to_ordered(d) << 32) | ((uint64_t)ids_l[f0 + lane] << 1);
       }
     }
@@ -386,6 +425,10 @@ __global__ __launch_bounds__(64) void graph_search_wide_kernel(const GraphArgs a
     }
   }
 
+  if (HELP) {  // release the helper wave
+    if (lane == 0) ctrl[0] = 0xFFFFFFFFu;
+    __syncthreads();
+  }
   // ---- leave the visited bitmap all-zero (k_graph.hip) ----
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -424,17 +467,39 @@ hipError_t launch_graph_search_wide(const GraphArgs& a, hipStream_t st) {
   const uint32_t P = a.width >= 4 ? 4 : 2;
   const size_t lds = graph_lds_bytes(a.ld, a.ef_cap, P);
   static DynLdsAttr attr;
-  const void* fns[4] = {(const void*)graph_search_wide_kernel<0, 2>, (const void*)graph_search_wide_kernel<1, 2>,
-                        (const void*)graph_search_wide_kernel<0, 4>, (const void*)graph_search_wide_kernel<1, 4>};
-  if (hipError_t e = attr.ensure(fns, 4, lds); e != hipSuccess) return e;
+  const void* fns[8] = {(const void*)graph_search_wide_kernel<0, 2, false>, (const void*)graph_search_wide_kernel<1, 2, false>,
+                        (const void*)graph_search_wide_kernel<0, 4, false>, (const void*)graph_search_wide_kernel<1, 4, false>,
+                        (const void*)graph_search_wide_kernel<0, 2, true>,  (const void*)graph_search_wide_kernel<1, 2, true>,
+                        (const void*)graph_search_wide_kernel<0, 4, true>,  (const void*)graph_search_wide_kernel<1, 4, true>};
+  if (hipError_t e = attr.ensure(fns, 8, lds); e != hipSuccess) return e;
   const bool l2 = a.metric == 0;
-  if (P == 2) {
-    if (l2) hipLaunchKernelGGL((graph_search_wide_kernel<0, 2>), dim3(a.nq), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((graph_search_wide_kernel<1, 2>), dim3(a.nq), dim3(64), lds, st, a);
-  } else {
-    if (l2) hipLaunchKernelGGL((graph_search_wide_kernel<0, 4>), dim3(a.nq), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((graph_search_wide_kernel<1, 4>), dim3(a.nq), dim3(64), lds, st, a);
+  // The helper wave: rows of the lengths two share a 4-lane group (<= 256 dims: a pass of 32 rows per wave), batches of at most
+  // one query per SIMD, and not the one-query form (its latency is launch + walk, not rows).
+  // EHX_GRAPH_HELP=0 / 1 forces it off / on (A/B runs).
+  const bool short_rows = a.dims <= 256 && (a.dims == 32 || a.dims == 64 || a.dims == 96 || a.dims == 128 || a.dims == 192 || a.dims == 256);
+  // Measured (6.25 M x 128 L2, same box, profiles/r06_k_graph_6250k128_help{0,1}.jsonl): batch 1024, P = 4 — ef 200 0.474 ->
+  // 0.528 of 8 TB/s, ef 800 0.519 -> 0.579, ef 50 0.383 -> 0.392; P = 2 — ef 200 0.440 -> 0.475.  Batch 2048 (two query waves per
+  // SIMD already): 0.557 -> 0.490, so the helper is for batches of at most one query per SIMD.  2 M x 768 (forced on): +1 %.
+  static std::atomic<int> n_simds{0};
+  if (n_simds.load(std::memory_order_relaxed) == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      n_simds.store(cus * 4, std::memory_order_relaxed);
+    else
+      n_simds.store(1024, std::memory_order_relaxed);
   }
+  const int help_env = env().graph_help;
+  const bool help = help_env >= 0 ? help_env != 0 : (short_rows && (int)a.nq <= n_simds.load(std::memory_order_relaxed) && !a.q_raw);
+#define EHX_LAUNCH_W(M, PP, H) \
+  hipLaunchKernelGGL((graph_search_wide_kernel<M, PP, H>), dim3(a.nq), dim3(H ? 128 : 64), lds, st, a)
+  if (help) {
+    if (P == 2) { if (l2) EHX_LAUNCH_W(0, 2, true); else EHX_LAUNCH_W(1, 2, true); }
+    else { if (l2) EHX_LAUNCH_W(0, 4, true); else EHX_LAUNCH_W(1, 4, true); }
+  } else {
+    if (P == 2) { if (l2) EHX_LAUNCH_W(0, 2, false); else EHX_LAUNCH_W(1, 2, false); }
+    else { if (l2) EHX_LAUNCH_W(0, 4, false); else EHX_LAUNCH_W(1, 4, false); }
+  }
+#undef EHX_LAUNCH_W
   return hipGetLastError();
 }
 

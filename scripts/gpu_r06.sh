@@ -141,5 +141,14 @@ for l in open("$O/r06_j_graph_6250k128_gprof.jsonl"):
 PY
   graph_bench 2m768 2000000 768 cosine 100,400 1,4
   ;;
+k)  # wide walk: a helper wave per query for the row passes of short rows (on by shape; EHX_GRAPH_HELP=0: off), same box
+  timeout 1200 python -m pytest tests/test_graph_wide.py -x -q -k "models_walk or contract" 2>&1 | tail -4
+  EHX_GRAPH_HELP=0 graph_bench 6250k128_help0 6250000 128 l2 50,200,800 2,4
+  graph_bench 6250k128_help1 6250000 128 l2 50,200,800 1,2,4
+  EHX_GRAPH_HELP=0 graph_bench 6250k128_help0b 6250000 128 l2 200 4 --batches 2048
+  graph_bench 6250k128_help1b 6250000 128 l2 200 4 --batches 2048
+  EHX_GRAPH_HELP=1 graph_bench 2m768_help1 2000000 768 cosine 400 4
+  graph_bench 2m768_help0 2000000 768 cosine 400 4
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
