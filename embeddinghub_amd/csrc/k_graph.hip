@@ -50,7 +50,10 @@ size_t graph_lds_bytes(uint32_t ld, uint32_t ef_cap, uint32_t width) {
 // (Round 4 built a HELPER wave per query — rows 16.. of every distance batch on a second SIMD, same arithmetic, bit-identical
 // — and measured -1..2 % at batch 1024, +1..3 % at 2048 (profiles/r04_j_graph_*_helper{0,1}.jsonl): the row phase is bound
 // by the memory system, not by the loads one wave keeps in flight.  Removed in round 6; the lever that pays at batch 1024 is
-// fewer dependent steps per query: k_graphw.hip.)
+// fewer dependent steps per query: k_graphw.hip.  Round 6 re-measured the helper on THIS walk at short rows, where it does
+// pay for the wide walk's 64-row passes: 6.25 M x 128, batch 1024, ef 50 / 200 / 800: 0.324 / 0.377 / 0.354 -> 0.294 / 0.344 /
+// 0.331 of 8 TB/s (profiles/r06_l_graph_6250k128_help{0,1}.jsonl) — an expansion's <= 32 rows are ONE pass and one round
+// trip either way, the split only adds two barriers.  Not in the library.)
 template <int METRIC01, bool SCALE>
 #if EHX_GRAPH_WAVES
 __attribute__((amdgpu_waves_per_eu(EHX_GRAPH_WAVES, EHX_GRAPH_WAVES)))

@@ -150,5 +150,11 @@ k)  # wide walk: a helper wave per query for the row passes of short rows (on by
   EHX_GRAPH_HELP=1 graph_bench 2m768_help1 2000000 768 cosine 400 4
   graph_bench 2m768_help0 2000000 768 cosine 400 4
   ;;
+l)  # the helper wave on the STRICT walk at short rows: parity with the oracle, then same-box A/B
+  timeout 1500 python -m pytest tests/test_graph_parity.py tests/test_fuzz_graph.py tests/test_graph_wide.py -x -q 2>&1 | tail -4
+  EHX_GRAPH_HELP=0 graph_bench 6250k128_help0 6250000 128 l2 50,200,800 1
+  graph_bench 6250k128_help1 6250000 128 l2 50,200,800 1,4
+  EHX_GRAPH_HELP=0 graph_bench 6250k128_help0r 6250000 128 l2 50,200,800 1
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
