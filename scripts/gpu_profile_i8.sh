@@ -18,6 +18,13 @@ case " $PASSES " in *" trace "*) SEQ=22 run ${TAG:-r03}_i8_trace "EHX_I8_SYNC=$S
 case " $PASSES " in *" fetch "*) run ${TAG:-r03}_i8_pmc_fetch "EHX_I8_SYNC=$SYNC" --pmc FETCH_SIZE;; esac
 case " $PASSES " in *" write "*) run ${TAG:-r03}_i8_pmc_write "EHX_I8_SYNC=$SYNC" --pmc WRITE_SIZE;; esac
 case " $PASSES " in *" sq "*) run ${TAG:-r03}_i8_pmc_sq "EHX_I8_SYNC=$SYNC" --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE;; esac
+case " $PASSES " in *" sq2 "*)   # what the parked / stalled cycles are made of: instruction mix and the LDS / VMEM issue buckets (names checked against the box's list)
+  WANT="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_I8"
+  rocprofv3 -L > gpurun_out/prof/counters_list.txt 2>&1
+  HAVE=""; n=0
+  for c in $WANT; do if grep -qw "$c" gpurun_out/prof/counters_list.txt && [ $n -lt 8 ]; then HAVE="$HAVE $c"; n=$((n+1)); fi; done
+  echo "sq2 counters:$HAVE"
+  run ${TAG:-r03}_i8_pmc_sq2 "EHX_I8_SYNC=$SYNC" --pmc $HAVE;; esac
 case " $PASSES " in *" clk "*) run ${TAG:-r03}_i8_pmc_clk "EHX_I8_SYNC=$SYNC" --pmc GRBM_GUI_ACTIVE;; esac
 TAG=${TAG:-r03} python - <<'PY'
 import json, re

@@ -156,5 +156,15 @@ l)  # the helper wave on the STRICT walk at short rows: parity with the oracle, 
   graph_bench 6250k128_help1 6250000 128 l2 50,200,800 1,4
   EHX_GRAPH_HELP=0 graph_bench 6250k128_help0r 6250000 128 l2 50,200,800 1
   ;;
+m)  # what the HALF kernel's parked cycles are made of (6.25 M x 128: SQ counters, second set); then the default bench run of the
+    # round's final library
+  TAG=r06_m_6250k128 PASSES="sq sq2" BENCH_ARGS="--config-legs 0 --rows 6250000 --dims 128 --metric-kind l2 --steps 8" bash scripts/gpu_profile_i8.sh 2>&1 | tail -6
+  grep -h "ScanArgsI8E" $O/prof/r06_m_6250k128_i8_pmc_sq_summary.txt $O/prof/r06_m_6250k128_i8_pmc_sq2_summary.txt | grep -v "^#" | cut -c1-170
+  cp $O/prof/r06_m_*summary.txt $O/ 2>/dev/null
+  find $O/prof -name "*.db" -size +4M -delete
+  timeout 900 python bench.py > $O/r06_m_bench_line.json 2> $O/r06_m_bench.err; echo "bench rc=$?"
+  cp $O/bench_detail.json $O/r06_m_bench_detail.json 2>/dev/null
+  grep -E "leg done|structured|skipp" $O/r06_m_bench.err | tail -20
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac

@@ -53,7 +53,7 @@ def bench_on_stand_ins(monkeypatch, tmp_path):
     return run
 
 
-SMALL = ["--structured-big-rows", "0", "--rows", "3000", "--dims", "32", "--batch", "16", "--steps", "3", "--warmup", "1", "--check-queries", "8",
+SMALL = ["--structured-big-rows", "0", "--structured-c3-rows", "0", "--rows", "3000", "--dims", "32", "--batch", "16", "--steps", "3", "--warmup", "1", "--check-queries", "8",
          "--cpu-sample-rows", "3000", "--cpu-sample-queries", "8", "--cpu-hnsw-rows", "500", "--graph-batches", "2",
          "--graph-efs", "10,20", "--reference-benchmark", "0", "--config-legs", "0", "--single-query", "0",
          "--set-concurrent", "0"]
@@ -105,8 +105,8 @@ def test_structured_10m_leg_reports_the_graph_path_at_the_metrics_recall_with_bo
     """BASELINE configs[2] on rows a graph can index: EHX-MANIFOLD-1 rows from the generator (no host
     array in the real run), exact truth checked against the oracle (fail-closed), ef swept for the strict and the wide
     walk, the operating point and both walks' numbers in the compact line"""
-    r = bench_on_stand_ins(SMALL[2:] + ["--structured-big-rows", "900", "--structured-big-efs", "10,20", "--graph-rows", "0",
-                                        "--structured-rows", "0", "--no-cpu-baseline"])
+    r = bench_on_stand_ins(SMALL[4:] + ["--structured-big-rows", "900", "--structured-big-efs", "10,20", "--graph-rows", "0",
+                                        "--structured-rows", "0", "--no-cpu-baseline", "--structured-c3-rows", "700"])
     g = r["graph_path_structured_10m"]
     assert g["rows"] == 900 and g["exact_truth_identical_to_oracle"] is True
     assert g["exact_truth_oracle_check"]["oracle_rows"] == 900
@@ -115,6 +115,9 @@ def test_structured_10m_leg_reports_the_graph_path_at_the_metrics_recall_with_bo
     c = bench_on_stand_ins.line["graph_path_structured_10m"]
     assert c["oracle"] is True and c["meets_recall_0.95"] is True and c["rows"] == 900
     assert "strict_qps" in c and "width" in c and "exact_flat_qps" in c
+    g3 = r["graph_path_structured_c3"]     # the configs[3] shard shape: 128-dim L2 rows, not normalised
+    assert g3["rows"] == 700 and g3["exact_truth_identical_to_oracle"] is True and "x128 l2" in g3["workload"]
+    assert bench_on_stand_ins.line["graph_path_structured_c3"]["meets_recall_0.95"] is True
 
 
 def test_compact_line_stays_bounded_when_every_leg_reports(bench_on_stand_ins):

@@ -173,3 +173,31 @@ def test_dropping_a_sharded_space_under_concurrent_searches():
             assert not t.is_alive()
         assert set(outcomes) <= {"ok", "gone"}, set(outcomes)
         assert "gone" in outcomes or all(o == "ok" for o in outcomes)
+
+
+def test_sharded_space_takes_the_round6_additions():
+    """ehx_fill_manifold on a sharded space is the same corpus as on an unsharded one (global row g = generator row g), and
+    a sharded GRAPH space walks its shards with the width it was given (ehx_params.search_width at creation,
+    ehx_space_set_search_width afterwards, handed down to every shard): with ef >= the shard size either walk is
+    exhaustive per shard, so the merged answer must be the exact one for every width."""
+    n, d, R, nq, k = 20_000, 96, 12, 32, 10
+    s = ehx.Space.unique("shm", d, metric=ehx.METRIC_COSINE, shards=2, initial_capacity=n)
+    s.fill_manifold(ehx.SEED_CORPUS, 0, 12_000, R, True)
+    s.fill_manifold(ehx.SEED_CORPUS, 12_000, n - 12_000, R, True)
+    X = pyoracle.gen_manifold_rows(ehx.SEED_CORPUS, 0, n, d, R, normalize=True)
+    Q = pyoracle.gen_manifold_rows(ehx.SEED_QUERY, 0, nq, d, R, normalize=True)
+    _check(s, X, Q, k, pyoracle.METRIC_COSINE)
+    assert s.get_by_id(n - 1).tobytes() == X[n - 1].tobytes()
+    s.drop()
+    m = 1600
+    g = ehx.Space.unique("shgw", d, metric=ehx.METRIC_COSINE, mode=ehx.MODE_GRAPH, shards=2, ef=1000, search_width=4)
+    g.set_batch(_keys(m), X[:m])
+    oi, od, _ = pyoracle.exhaustive(X[:m], Q, k, pyoracle.METRIC_COSINE)
+    for width in (4, 2, 1):
+        g.set_search_width(width)
+        gi, gd, gc = g.knn(Q, k)
+        np.testing.assert_array_equal(gi, oi, err_msg="width %d" % width)
+        assert gd.tobytes() == od.tobytes()
+    with pytest.raises(Exception):
+        g.set_search_width(3)
+    g.drop()
