@@ -166,5 +166,20 @@ m)  # what the HALF kernel's parked cycles are made of (6.25 M x 128: SQ counter
   cp $O/bench_detail.json $O/r06_m_bench_detail.json 2>/dev/null
   grep -E "leg done|structured|skipp" $O/r06_m_bench.err | tail -20
   ;;
+n)  # the configs[3]-shard graph leg alone (6.25 M x 128 L2 structured rows: strict / wide walk with its helper wave), then the
+    # new sharded test
+  timeout 900 python bench.py --graph-rows 0 --structured-rows 0 --structured-big-rows 0 --single-query 0 --reference-benchmark 0 \
+    --no-cpu-baseline --config-legs 0 --set-concurrent 0 --no-f32-engine --check-queries 0 --rows 1000000 \
+    --detail-file $O/r06_n_detail.json > $O/r06_n_line.json 2> $O/r06_n.err; echo "bench rc=$?"
+  python - <<PY
+import json
+d = json.load(open("$O/r06_n_detail.json"))
+g = d["graph_path_structured_c3"]
+print(g["workload"]); print(g["operating_point"], g["operating_point_strict_walk"], g["exact_flat_engine_same_rows_queries_per_s"], g["exact_truth_oracle_check"]["ids_identical_to_oracle"])
+for c in g["recall_vs_ef"]:
+    print({k: c[k] for k in ("ef", "search_width", "recall_at_10", "value", "kernel_ms", "rows_fetched_per_query", "frac_of_8TBps")})
+PY
+  timeout 900 python -m pytest tests/test_shards_abi.py -x -q 2>&1 | tail -3
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
