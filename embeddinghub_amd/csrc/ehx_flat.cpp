@@ -409,6 +409,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   a.ld = s->ld8;
   a.q_tiles = p.q_tiles;
   a.skew = env().i8_skew;
+  a.group_b = s->metric == EHX_METRIC_L2SQ ? 1u : 0u;   // (cosine / inner product: B_r is one constant, every margin 0)
   auto scan = [&](const ScanPlan& pl, uint32_t tile0) -> hipError_t {
     a.tile0 = tile0;
     a.n_tiles = pl.n_tiles;

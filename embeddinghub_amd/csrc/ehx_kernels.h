@@ -641,7 +641,8 @@ struct ScanArgsI8 {
   const int8_t* X;        // scan copy, scan8_index layout; cap % 256 == 0
   const float4* rowp;     // [cap + 512] (A, B, C, D) per row; padding rows (0, +inf, 0, 0)
   const float4* tilep;    // [cap/256 + 2] (max|A|, max|C|, max|D|, min B) per 256-row tile
-  const float* tileg;     // [cap/256 + 2][16] ([0..8) used) max |A| of each 32-row lane group of the tile (g = 4 wr + (l >> 4))
+  const float* tileg;     // [cap/256 + 2][16]: [0..8) max |A| of each 32-row lane group of the tile (g = 4 wr + (l >> 4)),
+                          // [8..16) the group's B margin: min B of the group - min B of the tile (>= 0; round 6)
   const uint8_t* perm;    // [cap] row index inside its tile of the row stored at each position (identity: unsorted tile)
   const float4* qparams;  // [q_tiles*256] (s_q, e_q, gamma_q, smallest threshold the query was scanned with so far)
   const float* thr;       // [q_tiles*256] score threshold of this pass per query (-inf: padding query)
@@ -660,6 +661,7 @@ struct ScanArgsI8 {
                              // tiles completed by each of the chunk's (<= 4) query-tile workgroups
   uint32_t sync_tol = 0;     // > 0: a workgroup does not run more than this many TILES ahead of its slowest sibling
   uint32_t skew = 0;         // half-tile workgroups: the second-resident wave of a SIMD starts skew x 64 cycles late
+  uint32_t group_b = 0;      // 1: the alarm level of a lane group uses the group's B margin (L2^2: B_r = |x_r|^2 varies)
 };
 // Stage-blocked layout of the int8 scan copy / query tiles: tiles of 256 rows, stages of 64 columns (bytes); one
 // (tile, stage) block is 256 rows x 64 B = 16 KiB in exactly the LDS image of the kernel (16-byte chunk c of row r

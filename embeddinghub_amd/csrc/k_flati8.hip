@@ -404,11 +404,17 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return (cf4p)(((uint64_t)hi << 32) | lo);
   };
-  const cf4p tilep_c = uniform_ptr(a.tilep + tile_begin);
+  // (a chunk past the end of the pass — chunks x tiles_per_chunk rounds up — owns no tile and must not touch memory beyond the
+  // arrays' two padding entries: its look-ahead loads read the pass's first tile instead.  Round 6: the unclamped load of
+  // tile_begin ran up to 15 KiB past a 50-KiB tileg array and faulted once the allocator placed it at the end of a block.)
+  const uint32_t tile_par = my_tiles ? tile_begin : a.tile0;
+  const cf4p tilep_c = uniform_ptr(a.tilep + tile_par);
   float4 tp_cur = ldc(tilep_c, 0);
   // max |A| of this wave's four 32-row lane groups (one per l >> 4) of the current tile: uniform, loaded a tile ahead
-  const cf4p tgp = uniform_ptr(a.tileg + (size_t)tile_begin * 16 + (size_t)wr * 4);
+  const cf4p tgp = uniform_ptr(a.tileg + (size_t)tile_par * 16 + (size_t)wr * 4);
   float4 tg_cur = ldc(tgp, 0);
+  // ... and the B margins of the same four groups (tileg[tile][8 + g]: min B of the group - min B of the tile)
+  float4 tgb_cur = ldc(tgp, 2);
   // =============================== tile epilogue ===============================
   auto epilogue = [&](uint32_t t) {
     const uint32_t tile = tile_begin + t;
@@ -453,13 +459,24 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     // The alarm level K of a (tile, query) is computed ONCE per wave — lane (qd, j15) takes query 16 qd + j15 of the
     // wave's 64 — and handed to the four lanes that hold the query's accumulators by a lane permute.  -inf, +inf or > 0.
     const float k_own = i8_alarm_k(tp, qp_lds[wc * 64 + lane_e], qinv_lds[wc * 64 + lane_e]);
+    // L2^2 (B_r = |x_r|^2 varies inside a tile): every row of this lane's group has B_r >= min B of the tile + dB, so the
+    // group's level is K + dB gamma_q / s_q — the factor per query, erring LOW (towards alarms), handed round like K.
+    // (gamma_q < 0 never happens for L2^2; clamped so that a margin can only ever raise the level soundly.  -inf + inf or
+    // 0 * inf give NaN, which the clamp below turns into "always alarm".)
+    float g_own = 0.0f, dB = 0.0f;
+    if (a.group_b) {
+      const float4 tgb = tgb_cur;
+      dB = qd == 0 ? tgb.x : (qd == 1 ? tgb.y : (qd == 2 ? tgb.z : tgb.w));
+      g_own = fmaxf(qp_lds[wc * 64 + lane_e].z, 0.0f) * qinv_lds[wc * 64 + lane_e] * (1.0f - 1e-4f);
+    }
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
       // ---- phase 1: can ANY of the lane's 32 accumulators of this query belong to a candidate?  I |A_r| >= K with
       // |A_r| = gm for the whole group (K > 0: a negative I never qualifies; K = -inf: always), i.e. I >= K / gm: ONE
       // integer level per lane and query (rounded down: a superset, the hit path judges every key exactly) against the
       // integer maximum ----
-      const float kq = __shfl(k_own, cb * 16 + j15, 64);
+      float kq = __shfl(k_own, cb * 16 + j15, 64);
+      if (a.group_b) kq = __builtin_fmaf(dB, __shfl(g_own, cb * 16 + j15, 64), kq);
       // (clamped before the conversion: -2.1e9 = always, 2.1e9 = never — |I| <= 2048 * 127^2)
       const int ti = (int)fminf(fmaxf(kq * rgm, -2.1e9f), 2.1e9f);
       int m8[8];
@@ -765,6 +782,7 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
       rsrc += kTileRows16 * 16;
       tp_cur = ldc(tilep_c, t + 1);  // (past the last tile: the array's padding entries)
       tg_cur = ldc(tgp, (size_t)(t + 1) * 4);
+      tgb_cur = ldc(tgp, (size_t)(t + 1) * 4 + 2);
       // tile t+2 goes to the slot tile t-1 used: every wave left that epilogue long ago
       const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 2) % 3 == (t - 1) % 3
       rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
@@ -815,6 +833,7 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
       rsrc += kTileRows16 * 16;
       tp_cur = ldc(tilep_c, t);  // (past the last tile: the array's padding entries)
       tg_cur = ldc(tgp, (size_t)t * 4);
+      tgb_cur = ldc(tgp, (size_t)t * 4 + 2);
       // tile t+1 (counting the new t) goes to the slot tile t-2 used: every wave left that epilogue long ago
       const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 1) % 3 == (t - 2) % 3
       rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;

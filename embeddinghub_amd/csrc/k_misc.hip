@@ -384,7 +384,8 @@ __global__ __launch_bounds__(256) void make_scan8_kernel(const XT* __restrict__ 
 // 0 for a row the filter cannot bound): the sort key of the tile ordering
 template <typename XT>
 __global__ __launch_bounds__(256) void scan8_step_kernel(const XT* __restrict__ X, uint64_t row0, uint64_t n, uint32_t dims,
-                                                         uint32_t ld, int metric, float* __restrict__ natA) {
+                                                         uint32_t ld, int metric, float* __restrict__ natA,
+                                                         float* __restrict__ natN) {
   const int lane = threadIdx.x & 63;
   const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
@@ -398,7 +399,10 @@ __global__ __launch_bounds__(256) void scan8_step_kernel(const XT* __restrict__ 
   float amax = 0.0f;
   for (uint32_t c = lane; c < dims; c += 64) amax = fmaxf(amax, fabsf(ld_row(x, c) * inv));
   amax = wave_max(amax);
-  if (lane == 0) natA[i] = ok ? (metric == 2 ? 1.0f : nr) * (amax / 127.0f) : 0.0f;
+  if (lane == 0) {
+    natA[i] = ok ? (metric == 2 ? 1.0f : nr) * (amax / 127.0f) : 0.0f;
+    natN[i] = metric == 0 && ok ? nr : 0.0f;   // the second ordering key: only L2^2 carries the norm in B_r (= |x_r|^2)
+  }
 }
 
 // (max|A|, max|C|, max|D|, min B) over the 256 rows of each tile: one wave per tile, 4 rows per lane
@@ -447,31 +451,74 @@ __device__ __forceinline__ uint32_t i8_pos_of_rank(uint32_t rank) {
 
 // one workgroup per FULL tile (tile index tile0 + blockIdx.x): ranks of the 256 natural |A_r| -> the rows' positions
 // (posn, perm8), the eight group maxima (tileg8) and every row's target |A| = the maximum of its group
-__global__ __launch_bounds__(256) void rank_tiles8_kernel(const float* __restrict__ natA, uint64_t tile0,
-                                                          uint8_t* __restrict__ perm8, float* __restrict__ tileg8,
-                                                          float* __restrict__ tgtA, uint8_t* __restrict__ posn) {
+//
+// Round 6 — rows whose NORMS vary (L2^2 on raw rows: B_r = |x_r|^2, the reference's default metric, index.cc:13): the alarm
+// level of a lane group is K = (min B gamma_q - ...) / s_q against max |A| of the group, and with ONE min B per tile a tile of
+// raw N(0,1) 128-dim rows (norms +-6 %, B +-12 %) alarms in 95 % of its (group, query) pairs against 12 % for normalised rows
+// (scripts/studies/int8_alarm_l2_groups.py).  So (i) every lane group gets its own min B (tileg8[tile][8 + g] = min B of the
+// group - min B of the tile, k_flati8.hip adds it to the level), and (ii) a tile whose norms spread by more than 0.1 % is
+// ordered in FOUR NORM BANDS of 64 rows, each band by step: groups 2 b, 2 b + 1 hold band b's lower and upper half — B
+// within a group tight, |A| within a group half as spread: 36 % alarms in the study (norm only: 41 %, step only + group
+// B: 64 %).  Tiles of (nearly) equal norms — cosine, inner product, normalised rows — keep the pure step order.
+__global__ __launch_bounds__(256) void rank_tiles8_kernel(const float* __restrict__ natA, const float* __restrict__ natN,
+                                                          uint64_t tile0, uint8_t* __restrict__ perm8,
+                                                          float* __restrict__ tileg8, float* __restrict__ tgtA,
+                                                          uint8_t* __restrict__ posn) {
   __shared__ float a_l[256];
-  __shared__ float g_l[8];
+  __shared__ float n_l[256];
+  __shared__ uint32_t g_l[8];
+  __shared__ uint32_t nmm[2];
   const uint32_t tid = threadIdx.x;
   const uint64_t tile = tile0 + blockIdx.x;
-  const size_t i = (size_t)blockIdx.x * 256 + tid;   // index into natA / tgtA / posn (rows from tile0 * 256)
+  const size_t i = (size_t)blockIdx.x * 256 + tid;   // index into natA / natN / tgtA / posn (rows from tile0 * 256)
   const float a = natA[i];
+  const float nrm = natN[i];
   a_l[tid] = a;
+  n_l[tid] = nrm;
+  if (tid < 8) g_l[tid] = 0u;
+  if (tid == 0) {
+    nmm[0] = 0x7F800000u;
+    nmm[1] = 0u;
+  }
   __syncthreads();
+  atomicMin(&nmm[0], __float_as_uint(nrm));   // (non-negative floats order like their bit patterns)
+  atomicMax(&nmm[1], __float_as_uint(nrm));
+  __syncthreads();
+  const float nmin = __uint_as_float(nmm[0]), nmax = __uint_as_float(nmm[1]);
+  const bool banded = nmax > nmin * 1.001f;
   uint32_t rank = 0;
-  for (uint32_t j = 0; j < 256; ++j) {
-    const float b = a_l[j];
-    rank += (b < a || (b == a && j < tid)) ? 1u : 0u;
+  if (!banded) {
+    for (uint32_t j = 0; j < 256; ++j) {
+      const float b = a_l[j];
+      rank += (b < a || (b == a && j < tid)) ? 1u : 0u;
+    }
+  } else {
+    uint32_t rn = 0;    // rank by norm -> band
+    for (uint32_t j = 0; j < 256; ++j) {
+      const float b = n_l[j];
+      rn += (b < nrm || (b == nrm && j < tid)) ? 1u : 0u;
+    }
+    const uint32_t band = rn >> 6;
+    __syncthreads();
+    n_l[tid] = __uint_as_float(band);   // (n_l now holds every row's band)
+    __syncthreads();
+    uint32_t rs = 0;    // rank by step inside the band
+    for (uint32_t j = 0; j < 256; ++j) {
+      const float b = a_l[j];
+      const bool same = __float_as_uint(n_l[j]) == band;
+      rs += (same && (b < a || (b == a && j < tid))) ? 1u : 0u;
+    }
+    rank = band * 64u + rs;
   }
   const uint32_t pos = i8_pos_of_rank(rank);
-  if ((rank & 31u) == 31u) g_l[rank >> 5] = a;
+  atomicMax(&g_l[rank >> 5], __float_as_uint(a));   // the group's |A|: the maximum of its rows' natural steps
   __syncthreads();
-  const float gmax = g_l[rank >> 5];
+  const float gmax = __uint_as_float(g_l[rank >> 5]);
   posn[i] = (uint8_t)pos;
   tgtA[i] = gmax;
   perm8[tile * 256 + pos] = (uint8_t)tid;
-  if (tid < 8) tileg8[tile * 16 + tid] = g_l[tid];
-  else if (tid < 16) tileg8[tile * 16 + tid] = 0.0f;
+  if (tid < 8) tileg8[tile * 16 + tid] = __uint_as_float(g_l[tid]);
+  else if (tid < 16) tileg8[tile * 16 + tid] = 0.0f;   // (the groups' B margins: ident_tiles8_kernel, from the rows as stored)
 }
 
 // tiles kept in row order: perm = identity, group maxima from the rows where they are
@@ -480,16 +527,33 @@ __global__ __launch_bounds__(256) void rank_tiles8_kernel(const float* __restric
 __global__ __launch_bounds__(256) void ident_tiles8_kernel(const float4* __restrict__ rowp8, uint8_t* __restrict__ perm8,
                                                            float* __restrict__ tileg8, const uint64_t* __restrict__ tiles,
                                                            uint64_t tile0) {
-  __shared__ uint32_t gm[16];
+  __shared__ uint32_t gm[8], bm[8];
   const uint32_t tid = threadIdx.x;
   const uint64_t tile = tiles ? tiles[blockIdx.x] : tile0 + blockIdx.x;
-  if (tid < 16) gm[tid] = 0u;  // (groups 8..15 are unused: zero)
+  if (tid < 8) {
+    gm[tid] = 0u;
+    bm[tid] = 0x7F800000u;   // +inf
+  }
   __syncthreads();
-  const float a = fabsf(rowp8[tile * 256 + tid].x);
-  atomicMax(&gm[i8_group_of_pos(tid)], __float_as_uint(a));  // (non-negative floats order like their bit patterns)
+  const float4 p = rowp8[tile * 256 + tid];
+  const uint32_t g = i8_group_of_pos(tid);
+  atomicMax(&gm[g], __float_as_uint(fabsf(p.x)));  // (non-negative floats order like their bit patterns)
+  // B_r >= 0 for every metric (1 - 1e-6, or |x_r|^2 rounded down; +inf: a padding row or one the filter cannot bound);
+  // anything else (never produced) counts as 0: the margin below then is 0, the tile-level bound
+  atomicMin(&bm[g], p.y >= 0.0f ? __float_as_uint(p.y) : 0u);
   if (tiles) perm8[tile * 256 + tid] = (uint8_t)tid;
   __syncthreads();
-  if (tid < 16) tileg8[tile * 16 + tid] = __uint_as_float(gm[tid]);
+  if (tid < 8) tileg8[tile * 16 + tid] = __uint_as_float(gm[tid]);
+  else if (tid < 16) {
+    // tileg8[tile][8 + g] = (min B of group g) - (min B of the tile = tilep8[tile].w, tile_params8_kernel), ROUNDED DOWN:
+    // the scan's alarm level of the group may assume B_r >= min B of the tile + this margin for every row of the group
+    uint32_t tmin = bm[0];
+    for (int j = 1; j < 8; ++j) tmin = bm[j] < tmin ? bm[j] : tmin;
+    const float bt = __uint_as_float(tmin), bg = __uint_as_float(bm[tid - 8]);
+    float margin = 0.0f;
+    if (bt < __builtin_inff()) margin = bg < __builtin_inff() ? (bg - bt) * (1.0f - 1e-6f) : __builtin_inff();
+    tileg8[tile * 16 + tid] = margin > 0.0f ? margin : 0.0f;
+  }
 }
 
 namespace {
@@ -505,13 +569,13 @@ void make_rows8(const XT* X, uint64_t row0, uint64_t n, uint32_t dims, uint32_t 
   }
 }
 template <typename XT>
-void step_rows8(const XT* X, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld, int metric, float* natA,
+void step_rows8(const XT* X, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld, int metric, float* natA, float* natN,
                 hipStream_t st) {
   const uint64_t max_rows = kMaxWorkItems / 64;
   for (uint64_t r0 = 0; r0 < n; r0 += max_rows) {
     const uint64_t m = n - r0 < max_rows ? n - r0 : max_rows;
     hipLaunchKernelGGL(scan8_step_kernel<XT>, dim3((uint32_t)((m + 3) / 4)), dim3(256), 0, st, X, row0 + r0, m, dims, ld,
-                       metric, natA + r0);
+                       metric, natA + r0, natN + r0);
   }
 }
 }  // namespace
@@ -521,7 +585,7 @@ size_t make_scan8_scratch_bytes(uint64_t row0, uint64_t n, uint64_t sort_lo, uin
   const uint64_t s0 = (sort_lo + 255) >> 8, s1 = sort_hi >> 8;
   const uint64_t a0 = s0 > t0 ? s0 : t0, a1 = s1 < t1 ? s1 : t1;
   const uint64_t rows = a1 > a0 ? (a1 - a0) * 256 : 0;
-  return (size_t)rows * 9 + (size_t)(t1 - t0 + 1) * 8 + 64;   // natA f32 | tgtA f32 | posn u8 | tile ids
+  return (size_t)rows * 13 + (size_t)(t1 - t0 + 1) * 8 + 64;   // natA f32 | tgtA f32 | natN f32 | posn u8 | tile ids
 }
 
 hipError_t launch_make_scan8(const void* X, int x_half, uint64_t row0, uint64_t n, uint32_t dims, uint32_t ld,
@@ -547,14 +611,15 @@ hipError_t launch_make_scan8(const void* X, int x_half, uint64_t row0, uint64_t 
     const uint64_t rows = n_sorted * 256, base = a0 * 256;
     float* natA = (float*)scratch;
     float* tgtA = natA + rows;
-    uint8_t* posn = (uint8_t*)(tgtA + rows);
+    float* natN = tgtA + rows;
+    uint8_t* posn = (uint8_t*)(natN + rows);
     tile_list = (uint64_t*)(((uintptr_t)(posn + rows) + 15) & ~(uintptr_t)15);
-    if (x_half) step_rows8((const __half*)X, base, rows, dims, ld, metric, natA, st);
-    else step_rows8((const float*)X, base, rows, dims, ld, metric, natA, st);
+    if (x_half) step_rows8((const __half*)X, base, rows, dims, ld, metric, natA, natN, st);
+    else step_rows8((const float*)X, base, rows, dims, ld, metric, natA, natN, st);
     for (uint64_t c0 = 0; c0 < n_sorted; c0 += 1u << 30) {
       const uint64_t m = n_sorted - c0 < (1u << 30) ? n_sorted - c0 : (1u << 30);
-      hipLaunchKernelGGL(rank_tiles8_kernel, dim3((uint32_t)m), dim3(256), 0, st, natA + c0 * 256, a0 + c0, perm8, tileg8,
-                         tgtA + c0 * 256, posn + c0 * 256);
+      hipLaunchKernelGGL(rank_tiles8_kernel, dim3((uint32_t)m), dim3(256), 0, st, natA + c0 * 256, natN + c0 * 256, a0 + c0,
+                         perm8, tileg8, tgtA + c0 * 256, posn + c0 * 256);
     }
     make(row0, base - row0, nullptr, nullptr, 0);                       // rows before the ordered tiles
     make(base, rows, tgtA, posn, base);                                 // the ordered tiles

@@ -181,5 +181,18 @@ for c in g["recall_vs_ef"]:
 PY
   timeout 900 python -m pytest tests/test_shards_abi.py -x -q 2>&1 | tail -3
   ;;
+o)  # which exact engine serves structured rows fastest (the int8 filter on 128-dim structured L2 rows: 4.9 ms per batch)
+  for shape in "6250000 128 l2 16" "6250000 128 l2 0" "6250000 128 cosine 16" "2000000 768 l2 16" "2000000 768 cosine 16"; do
+    set -- $shape
+    timeout 600 python scripts/structured_engine_ab.py --rows $1 --dims $2 --metric $3 --latent $4 2>/dev/null | tee -a $O/r06_o_structured_engine_ab.jsonl | cut -c1-230
+  done
+  ;;
+p)  # int8 filter on rows whose norms vary (L2^2): group B margins + banded tile order — parity, then the engines on L2 shapes
+  timeout 2400 python -m pytest tests/test_flat_parity.py tests/test_i8_filter.py tests/test_fuzz_parity.py tests/test_exactness.py tests/test_search_copy_layout.py tests/test_concurrent_set.py tests/test_generated_base.py -x -q 2>&1 | tail -4
+  for shape in "6250000 128 l2 0" "6250000 128 l2 16" "2000000 768 l2 16" "6250000 128 cosine 0" "2000000 768 cosine 0"; do
+    set -- $shape
+    timeout 600 python scripts/structured_engine_ab.py --rows $1 --dims $2 --metric $3 --latent $4 --engines auto,f16 2>/dev/null | tee -a $O/r06_p_engine_ab.jsonl | cut -c1-200
+  done
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac

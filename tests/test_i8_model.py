@@ -215,3 +215,73 @@ def test_block_integer_alarm_is_valid_and_pays_once_rows_are_ordered_by_step():
             blocks += 16
         rates[ordered] = alarms / blocks
     assert rates[False] > 0.8 and rates[True] < 0.35, rates
+
+
+def _kernel_order(A, norms):
+    """rank_tiles8_kernel (k_misc.hip, round 6): the positions of a FULL tile's 256 rows — pure step order when the norms
+    spread by less than 0.1 %, else four norm bands of 64 rows, each by step; returns the rows in rank order (rank r sits in
+    lane group r // 32)"""
+    idx = np.arange(256)
+    if norms.max() <= norms.min() * f32(1.001):
+        return idx[np.argsort(np.abs(A), kind="stable")]
+    by_norm = idx[np.argsort(norms, kind="stable")]
+    return np.concatenate([b[np.argsort(np.abs(A[b]), kind="stable")] for b in (by_norm[i * 64:(i + 1) * 64] for i in range(4))])
+
+
+def test_group_b_margin_is_sound_and_pays_on_rows_whose_norms_vary():
+    """Round 6 (L2^2 on raw rows — the reference's default metric on un-normalised data): every 32-row lane group's alarm
+    level uses the group's own min B (tileg8[tile][8 + g] = min B of the group - min B of the tile, rounded down; the
+    kernel adds dB * max(gamma_q, 0) * qinv_q * (1 - 1e-4) to the tile's K) and tiles whose norms vary are ordered in four
+    norm bands.  (1) SOUND on every data set of this file, any threshold: a row with S_lower <= thr always raises its
+    group's alarm.  (2) It pays: on raw N(0,1) 128-dim rows the share of (group, query) pairs that alarm falls from > 0.9
+    (one min B per tile, step order) to < 0.5; on normalised rows nothing changes (pure step order, margins 0)."""
+    d = 128
+    rng = np.random.default_rng(11)
+    raw = rng.standard_normal((256 * 8, d)).astype(f32)
+    unit = (raw / np.linalg.norm(raw, axis=1, keepdims=True)).astype(f32)
+    sets = [("raw gaussian", raw), ("normalised", unit)] + [(n, X) for n, X in _datasets(rng, d, n=256)]
+    rates = {}
+    for name, X in sets:
+        Q = np.concatenate([X[:6] + f32(1e-2) * rng.standard_normal((6, d)).astype(f32), rng.standard_normal((10, d)).astype(f32)])
+        xi, A, B, C, D = _row_params(X, "l2", d)
+        qi, sq, eq, g, u, v = _query_params(Q, "l2", d)
+        norms = np.sqrt((X.astype(f32) ** 2).sum(axis=1, dtype=f32)).astype(f32)
+        I = xi @ qi.T
+        t = (sq[None, :] * I.astype(f32)).astype(f32)
+        S = (A[:, None] * t + (B[:, None] * g[None, :] + (C[:, None] * eq[None, :] + D[:, None]).astype(f32)).astype(f32)).astype(f32)
+        al_new = al_old = groups = 0
+        for t0 in range(0, X.shape[0], 256):
+            sl = np.arange(t0, t0 + 256)
+            order = sl[_kernel_order(A[sl], norms[sl])]
+            # every row's step is raised to its group's maximum (make_scan8_kernel, tgtA): |A_r| of a group = its max
+            Ag = np.abs(A[order]).reshape(8, 32).max(axis=1)
+            finite = np.isfinite(B[order])
+            Bg = np.where(finite, B[order], f32(np.inf)).reshape(8, 32).min(axis=1).astype(f32)
+            Cmax, Dmax, Bmin = np.abs(C[sl]).max(), np.abs(D[sl]).max(), B[sl].min()
+            dB = np.where(np.isfinite(Bg) & np.isfinite(Bmin), ((Bg - Bmin).astype(f32) * f32(1.0 - 1e-6)).astype(f32), f32(0))
+            dB = np.maximum(dB, f32(0))
+            old_order = sl[np.argsort(np.abs(A[sl]), kind="stable")]
+            Ag_old = np.abs(A[old_order]).reshape(8, 32).max(axis=1)
+            for qj in range(Q.shape[0]):
+                col = np.sort(S[sl, qj])
+                qinv = f32(f32(1.0 - 1e-5) / sq[qj]) if sq[qj] > 0 else f32(np.inf)
+                gq = f32(f32(max(g[qj], f32(0)) * qinv) * f32(1.0 - 1e-4))
+                thr_rate = np.sort(S[:, qj])[4]      # (a level like a k'-th best of a big index: 5 rows of the whole set pass)
+                for thr in (thr_rate, col[2], col[20], col[-1], f32(np.inf)):
+                    kq = _alarm_k(Bmin, Cmax, Dmax, g[qj], eq[qj], sq[qj], thr)
+                    for gi in range(8):
+                        with np.errstate(invalid="ignore"):
+                            kg = f32(dB[gi] * gq + kq)                      # fmaf(dB, gq, kq)
+                        level = -2.1e9 if np.isnan(kg) else float(np.clip(np.float64(kg) / np.float64(Ag[gi]) * (1 - 2e-6), -2.1e9, 2.1e9))
+                        rows = order[gi * 32:(gi + 1) * 32]
+                        alarm = bool((I[rows, qj] >= int(level)).any()) if Ag[gi] > 0 else not (kq > -np.inf) or True
+                        hit = bool((S[rows, qj] <= thr).any())
+                        assert alarm or not hit, (name, qj, gi, float(thr))
+                        if thr is thr_rate:
+                            al_new += alarm
+                            lo = -2.1e9 if not np.isfinite(kq) and kq < 0 else float(np.clip(np.float64(kq) / np.float64(Ag_old[gi]), -2.1e9, 2.1e9)) if Ag_old[gi] > 0 else -2.1e9
+                            al_old += bool((I[old_order[gi * 32:(gi + 1) * 32], qj] >= int(lo)).any())
+                            groups += 1
+        rates[name] = (al_old / groups, al_new / groups)
+    assert rates["raw gaussian"][0] > 0.9 and rates["raw gaussian"][1] < 0.5, rates
+    assert abs(rates["normalised"][0] - rates["normalised"][1]) < 0.02, rates
