@@ -142,8 +142,9 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
       HIP_TRY(hipMemset(s->dUnsafe, 0, sizeof(unsigned long long)));
     }
     if (s->has8) {
-      HIP_TRY(hipMalloc((void**)&s->dUnsafe8, sizeof(unsigned long long)));
-      HIP_TRY(hipMemset(s->dUnsafe8, 0, sizeof(unsigned long long)));
+      // [0] rows the int8 filter cannot bound, [1] tiles with a lane group whose B margin matters (L2^2 on rows whose norms vary)
+      HIP_TRY(hipMalloc((void**)&s->dUnsafe8, 2 * sizeof(unsigned long long)));
+      HIP_TRY(hipMemset(s->dUnsafe8, 0, 2 * sizeof(unsigned long long)));
     }
   }
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));

@@ -409,7 +409,9 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   a.ld = s->ld8;
   a.q_tiles = p.q_tiles;
   a.skew = env().i8_skew;
-  a.group_b = s->metric == EHX_METRIC_L2SQ ? 1u : 0u;   // (cosine / inner product: B_r is one constant, every margin 0)
+  // (cosine / inner product: B_r is one constant, every margin 0; L2^2 on normalised rows: no tile has a margin worth the
+  // epilogue's extra permute and multiply-add per query block — 6.25 M x 128: 1.02 -> 1.07 ms per batch with them)
+  a.group_b = s->metric == EHX_METRIC_L2SQ && s->h_margin8 > 0 && env().i8_groupb ? 1u : 0u;
   auto scan = [&](const ScanPlan& pl, uint32_t tile0) -> hipError_t {
     a.tile0 = tile0;
     a.n_tiles = pl.n_tiles;

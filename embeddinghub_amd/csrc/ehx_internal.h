@@ -242,6 +242,7 @@ struct ehx_space {
   uint32_t ld8 = 0;
   unsigned long long* dUnsafe8 = nullptr;
   uint64_t h_unsafe8 = 0;
+  uint64_t h_margin8 = 0;      // tiles written so far with a lane group whose min B lies > 0.1 % above the tile's (dUnsafe8[1])
   uint64_t i8_min_rows = 16384;  // below this the fp16 filter serves (sample pass + cascade need a few thousand rows)
   uint32_t scan_sel = EHX_SCAN_AUTO;  // EHX_SCAN_*: what ehx_space_set_scan selected
 

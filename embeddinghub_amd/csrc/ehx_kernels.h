@@ -690,7 +690,8 @@ constexpr size_t kScan8TailPadBytes = 3u * 256u * 64u;  // X8 tail padding: thre
 size_t scan_i8_lds_bytes();
 hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st);
 // scan copy of rows [row0, row0+n): X8 = int8(x/|x| / s_r), rowp8 = (A, B, C, D); then the tile parameters of
-// every tile touching the range.  Rows the filter cannot bound are counted in *n_unsafe.
+// every tile touching the range.  n_unsafe[2]: [0] += rows the filter cannot bound, [1] += lane groups whose min B lies more
+// than 0.1 % above their tile's (the scan uses the groups' B margins only in spaces that have any).
 // Full tiles inside [sort_lo, sort_hi) (and inside the rows written) are stored ordered by quantisation step, every row's
 // step raised to its 32-row lane group's maximum (perm8[position] = row index inside the tile, tileg8[tile][8 of 16] =
 // |A| of each group: k_misc.hip, "rows of a tile ordered by quantisation step"); every other touched tile keeps the

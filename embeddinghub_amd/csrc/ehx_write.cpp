@@ -120,7 +120,7 @@ int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n, hipStream_t st, bool
   if (s->dXs && !s->x_perm && n)
     HIP_TRY(launch_make_search_copy(s->dX, s->x_half, s->dInv, row0, n, s->ld, s->metric, s->dXs, st));
   if ((!s->has16 && !s->has8) || n == 0) return EHX_OK;  // (kept current whatever engine is selected right now)
-  unsigned long long u = 0, u8 = 0;
+  unsigned long long u = 0, u8[2] = {0, 0};
   if (s->has16) {
     HIP_TRY(launch_make_scan16(s->dX, s->x_half, row0, n, s->dims, s->ld, s->ld16, s->metric, s->dX16, s->dRowp16,
                                s->dUnsafe, st));
@@ -150,14 +150,15 @@ int refresh_scan16(ehx_space* s, uint64_t row0, uint64_t n, hipStream_t st, bool
       HIP_TRY(hipStreamSynchronize(st));
       s->dTileList.release();
     }
-    HIP_TRY(hipMemcpyAsync(&u8, s->dUnsafe8, sizeof(u8), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(u8, s->dUnsafe8, sizeof(u8), hipMemcpyDeviceToHost, st));
   }
   {
     int rcs = sync_stream(s, st);
     if (rcs) return rcs;
   }
   s->h_unsafe = u;
-  s->h_unsafe8 = u8;
+  s->h_unsafe8 = u8[0];
+  if (s->has8) s->h_margin8 = u8[1];   // (cumulative: only ever grows — using the margins is sound either way)
   return EHX_OK;
 }
 

@@ -98,7 +98,8 @@ static_assert(kTileRows16 == 256 && kTileQ == 256, "kernel geometry is hard-wire
 // Ablation builds (scripts/ablate_i8.sh; results are WRONG by construction, only the scan's duration is looked at):
 //   1  no tile epilogue      2  epilogue phase 1 only (alarms never taken)      4  no DMA after the prologue (the ring
 //   keeps its first three stages; no counted wait)      8  no fragment reads (MFMAs on the prologue's fragments)
-//   16 no stage barrier
+//   16 no stage barrier                               32 no epilogue arithmetic (accumulators kept alive: 1 lets the
+//                                                          compiler delete the MFMAs)
 #ifndef EHX_I8_ABL
 #define EHX_I8_ABL 0
 #endif
@@ -449,6 +450,13 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
       }
       return;
     }
+#if EHX_I8_ABL & 32
+    // (ablation: no epilogue arithmetic at all, the accumulators merely kept alive — without a use the compiler deletes the MFMAs)
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb)
+      asm volatile("" : : "v"(acc[rb][0]), "v"(acc[rb][1]), "v"(acc[rb][2]), "v"(acc[rb][3]));
+    return;
+#endif
     const float4 tp = tp_cur;  // uniform: (max|A|, max|C|, max|D|, min B) of the tile's rows (loaded a tile ago)
     // max |A_r| over this lane's 32 rows (tiles ordered by step: every row of the group has exactly this |A_r|)
     const float4 tg = tg_cur;
@@ -843,6 +851,36 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
       }
     };
     uint32_t st = 0;
+    if constexpr (HALF) {
+      // Rows of 128 bytes (d = 128, the shape HALF exists for): a tile is exactly TWO stages, two tiles are one revolution of
+      // the ring — every slot a compile-time constant again, the query fragments change hands by name instead of sixteen
+      // register copies per stage (behind an lgkmcnt(0): the next stage's fragment reads had to LAND before the stage could
+      // end), and the per-stage slot arithmetic is gone.  Same stage body, same order of MFMAs, DMA pieces and fragment
+      // reads as the run-time-slot loop below: bit-identical.  (Round 6.)
+      if (ktiles == 2u) {
+#define EHX_NODMA do { } while (0)
+#define EHX_TILE2_CT(S)                                                                                               \
+  do {                                                                                                                \
+    EHX_STAGE16_BODY(EHX_MFZ, fb0, fb1, a_off + (uint32_t)(((S) + 1) & 3) * L::kXStage, b_off + (1u << 14),           \
+                     EHX_SDMA_X0(((S) + 3) & 3), EHX_NODMA, EHX_SDMA_X1(((S) + 3) & 3), EHX_NODMA);                   \
+    xsrc += kStageI8;                                                                                                 \
+    EHX_STAGE16_BODY(EHX_MF, fb1, fb0, a_off + (uint32_t)(((S) + 2) & 3) * L::kXStage, b_off,                         \
+                     EHX_SDMA_X0(((S) + 4) & 3), EHX_NODMA, EHX_SDMA_X1(((S) + 4) & 3), EHX_NODMA);                   \
+    xsrc += kStageI8;                                                                                                 \
+    tile_done();                                                                                                      \
+  } while (0)
+        uint32_t left = my_tiles;
+#pragma unroll 1
+        for (; left >= 2u; left -= 2u) {
+          EHX_TILE2_CT(0);
+          EHX_TILE2_CT(2);
+        }
+        if (left) EHX_TILE2_CT(0);   // (a third copy of the tile, run once per chunk; folding it into the loop with two exits spilled 164 registers)
+#undef EHX_TILE2_CT
+#undef EHX_NODMA
+        st = total_stages;
+      }
+    }
 #pragma unroll 1
     while (st < total_stages) {
       if (ks == 0u)

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void rank_tiles8_kernel(const float* __restric
 // the row parameters as stored too: the alarm's |A| must bound the rows' ACTUAL |A_r| to the last bit)
 __global__ __launch_bounds__(256) void ident_tiles8_kernel(const float4* __restrict__ rowp8, uint8_t* __restrict__ perm8,
                                                            float* __restrict__ tileg8, const uint64_t* __restrict__ tiles,
-                                                           uint64_t tile0) {
+                                                           uint64_t tile0, unsigned long long* __restrict__ n_margin) {
   __shared__ uint32_t gm[8], bm[8];
   const uint32_t tid = threadIdx.x;
   const uint64_t tile = tiles ? tiles[blockIdx.x] : tile0 + blockIdx.x;
@@ -553,6 +553,8 @@ __global__ __launch_bounds__(256) void ident_tiles8_kernel(const float4* __restr
     float margin = 0.0f;
     if (bt < __builtin_inff()) margin = bg < __builtin_inff() ? (bg - bt) * (1.0f - 1e-6f) : __builtin_inff();
     tileg8[tile * 16 + tid] = margin > 0.0f ? margin : 0.0f;
+    // (n_margin[1]: tiles where a margin is worth having — the scan only spends instructions on them in spaces that have any)
+    if (margin > 1e-3f * bt && margin < __builtin_inff()) atomicAdd(n_margin + 1, 1ull);
   }
 }
 
@@ -634,12 +636,12 @@ hipError_t launch_make_scan8(const void* X, int x_half, uint64_t row0, uint64_t 
     // ids of the tiles of [t0, t1) outside [a0, a1)
     if (hipError_t e = launch_tile_ids(tile_list, t0, t1, n_sorted ? a0 : t1, n_sorted ? a1 : t1, st); e != hipSuccess) return e;
     hipLaunchKernelGGL(ident_tiles8_kernel, dim3((uint32_t)n_ident), dim3(256), 0, st, rowp8, perm8, tileg8,
-                       tile_list + n_sorted, (uint64_t)0);
+                       tile_list + n_sorted, (uint64_t)0, n_unsafe);
   }
   for (uint64_t c0 = 0; c0 < n_sorted; c0 += 1u << 30) {
     const uint64_t m = n_sorted - c0 < (1u << 30) ? n_sorted - c0 : (1u << 30);
     hipLaunchKernelGGL(ident_tiles8_kernel, dim3((uint32_t)m), dim3(256), 0, st, rowp8, perm8, tileg8,
-                       (const uint64_t*)nullptr, a0 + c0);
+                       (const uint64_t*)nullptr, a0 + c0, n_unsafe);
   }
   return hipGetLastError();
 }

@@ -194,5 +194,50 @@ p)  # int8 filter on rows whose norms vary (L2^2): group B margins + banded tile
     timeout 600 python scripts/structured_engine_ab.py --rows $1 --dims $2 --metric $3 --latent $4 --engines auto,f16 2>/dev/null | tee -a $O/r06_p_engine_ab.jsonl | cut -c1-200
   done
   ;;
+q)  # launch-by-launch timeline of one batch of the int8 chain (device-resident queries, one stream): where a small shard's
+    # and a short-row shard's batch goes.  SHAPES="rows dims metric;..." overrides.
+  R=$PWD
+  mkdir -p $O/prof
+  IFS=';' read -ra SH <<< "${SHAPES:-1000000 768 cosine;1250000 768 cosine;6250000 128 l2;10000000 768 cosine}"
+  for shape in "${SH[@]}"; do
+    set -- $shape
+    tag=r06_q_$1x$2_$3
+    rm -rf $O/prof/$tag
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/$O/prof/$tag -o p -- python $R/scripts/ab_flat.py --rows $1 --dims $2 --metric $3 --steps 24 --warmup 6 > $R/$O/prof/$tag.log 2>&1)
+    tail -1 $O/prof/$tag.log | cut -c1-250
+    python scripts/batch_timeline.py $O/prof/$tag | tee $O/${tag}_timeline.txt
+  done
+  find $O/prof -name "*.db" -size +8M -delete
+  ;;
+r)  # generic same-box ABAB of the exact flat path between library builds: LIBS="_prev :" (":" = the default library),
+    # SHAPES="rows dims metric;...", REPS=2; PARITY=1 runs the flat parity suites on the default library first;
+    # COUNT=1 prints the epilogue counters of the -DEHX_I8_COUNT build (libehx_count.so) per shape
+  if [ "${PARITY:-1}" = 1 ]; then
+    timeout 2400 python -m pytest tests/test_flat_parity.py tests/test_i8_filter.py tests/test_fuzz_parity.py tests/test_exactness.py tests/test_search_copy_layout.py tests/test_concurrent_set.py tests/test_generated_base.py tests/test_structured_rows.py -x -q 2>&1 | tail -4
+  fi
+  IFS=';' read -ra SH <<< "${SHAPES:-6250000 128 l2;10000000 768 cosine;1000000 768 cosine}"
+  for rep in $(seq 1 ${REPS:-2}); do
+    for lib in ${LIBS:-_prev :}; do
+      [ "$lib" = ":" ] && lib=""
+      for shape in "${SH[@]}"; do
+        set -- $shape
+        EHX_LIB=$PWD/embeddinghub_amd/lib/libehx$lib.so timeout 600 python scripts/ab_flat.py --rows $1 --dims $2 --metric $3 --steps 40 --label "${TAG:-ab}${lib:-_new}" 2>/dev/null >> $O/r06_r_${TAG:-ab}.jsonl
+      done
+    done
+  done
+  python - <<PY
+import json
+for l in open("$O/r06_r_${TAG:-ab}.jsonl"):
+    r = json.loads(l)
+    print("%-14s %9d x %4d %-6s %.4f ms/step  kernel %.4f ms  checksum %d  fallbacks %d/%d" % (r["label"], r["rows"], r["dims"], r["metric"], r["ms_per_step"], r["kernel_ms"], r["ids_checksum_last_batch"], r["i8_fallback"], r["filter_fallback"]))
+PY
+  if [ "${COUNT:-0}" = 1 ]; then
+    for shape in "${SH[@]}"; do
+      set -- $shape
+      echo "== epilogue counters, $shape"
+      EHX_LIB=$PWD/embeddinghub_amd/lib/libehx_count.so EHX_I8_COUNT=1 timeout 600 python scripts/ab_flat.py --rows $1 --dims $2 --metric $3 --steps 4 --warmup 2 2>&1 | grep -a "i8 count" | tail -2 | cut -c1-200
+    done
+  fi
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
