@@ -646,7 +646,7 @@ struct ScanArgsI8 {
   const uint8_t* perm;    // [cap] row index inside its tile of the row stored at each position (identity: unsorted tile)
   const float4* qparams;  // [q_tiles*256] (s_q, e_q, gamma_q, smallest threshold the query was scanned with so far)
   const float* thr;       // [q_tiles*256] score threshold of this pass per query (-inf: padding query)
-  float* dump = nullptr;  // sample pass: every lower bound -> dump[row - tile0*256][q_tiles*256]
+  float* dump = nullptr;  // sample pass: every lower bound -> dump[scan8_dump_index(q, row - tile0*256, rows of the sample)]
   uint64_t* cand;         // [grid][512][64] staging slots
   uint64_t* pool;         // [q_tiles*256][pool_cap] collected (score, id) keys of this pass, unsorted
   uint32_t* pool_cnt;     // [q_tiles*256]
@@ -684,6 +684,12 @@ __host__ __device__ inline size_t scanq8_index(uint64_t row, uint32_t stage, uin
   const uint32_t rr = (uint32_t)(row & 255u);
   const uint32_t chunk = (cc >> 4) ^ scan8_swz(rr);
   return ((size_t)(tile * ((ld8 >> 6) + 3u) + stage) * 256u + rr) * 64u + chunk * 16u + (cc & 15u);
+}
+// the sample pass's dump of lower bounds (flat_scan_i8_kernel<DUMP> -> sample_select256_kernel): blocks of 16 queries x 16
+// sample rows = 1 KiB, inside a block a query's 16 rows are contiguous; element index of (query q, sample row `row`) when
+// the sample holds n_s rows (n_s % 16 == 0)
+__host__ __device__ inline size_t scan8_dump_index(uint32_t q, uint32_t row, uint32_t n_s) {
+  return ((((size_t)(q >> 4) * (n_s >> 4)) + (row >> 4)) << 8) + ((q & 15u) << 4) + (row & 15u);
 }
 inline size_t scanq8_bytes(uint32_t q_rows, uint32_t ld8) { return (size_t)(q_rows >> 8) * ((ld8 >> 6) + 3u) * 256u * 64u; }
 constexpr size_t kScan8TailPadBytes = 3u * 256u * 64u;  // X8 tail padding: three stage blocks (DMA read-ahead)

@@ -161,6 +161,7 @@ struct I8Ctx {
   uint32_t* pool_cnt;    // [q_rows]
   uint32_t* ovf;         // [q_rows]
   const uint8_t* perm;   // [cap] position -> row index inside its tile (tiles ordered by step: k_misc.hip)
+  const float4* rowp;    // [cap + 512] row parameters by POSITION (the flush evaluates the staged hits' lower bounds)
   uint32_t pool_cap;
   uint32_t n;            // valid rows
   uint32_t q_tile0;      // global index of this workgroup's query 0 (q_tile * 256)
@@ -168,8 +169,13 @@ struct I8Ctx {
 };
 static_assert(sizeof(I8Ctx) <= 64, "I8Ctx slot");
 
-// Empty this wave's staging buffer into the pools of its queries (wave-uniform call).  Every entry takes one slot
-// of its query's pool with a global atomicAdd; the vmcnt queue is drained before returning, so the caller's counted
+// Empty this wave's staging buffer into the pools of its queries (wave-uniform call).  A staged entry is a HIT of the
+// integer level test — (exact integer dot product, position, query) — not yet a key: the flush evaluates its exact lower
+// bound, one entry per lane, drops what lies above the query's threshold, and gives every survivor one slot of its query's
+// pool with a global atomicAdd.  (Round 6.  Until then the epilogue evaluated every hit on the spot: an LDS round trip for
+// the row's parameters and the score's arithmetic with one or two lanes of 64 at work, while the three (seven) sibling waves
+// waited at the next stage barrier — a quarter of the scan time at 6.25 M x 128, profiles/r06_s_*.)  The row parameters come
+// from HBM here (the tile's LDS copy is long gone); the vmcnt queue is drained before returning, so the caller's counted
 // waits see DMA pieces only.
 template <bool HALF>
 __device__ __attribute__((noinline)) void i8_flush_staging() {
@@ -179,16 +185,22 @@ __device__ __attribute__((noinline)) void i8_flush_staging() {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint64_t* keys = (const uint64_t*)(smem + L::kStgKeyOff) + (size_t)w * L::kStgCap;
   const uint32_t* qls = (const uint32_t*)(smem + L::kStgQlOff) + (size_t)w * L::kStgCap;
+  const float4* qp_lds = (const float4*)(smem + L::kQpOff);
   uint32_t* cnt = (uint32_t*)(smem + L::kStgCntOff) + w;
   uint32_t n = *cnt;
   if (n > L::kStgCap) n = L::kStgCap;
   const uint32_t cap = ctx->pool_cap;
   for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
-    uint64_t key = keys[i];
+    const uint64_t e = keys[i];
     // the staged id is the row's POSITION in the scan copy; its tile may be stored ordered by step
-    const uint32_t posn = (uint32_t)key;
-    key = (key & 0xFFFFFFFFFFFFFF00ull) | (uint64_t)ctx->perm[posn];
-    const uint32_t q = ctx->q_tile0 + (uint32_t)(w & 3) * 64u + qls[i];
+    const uint32_t posn = (uint32_t)e;
+    const int v = (int)(uint32_t)(e >> 32);
+    const uint32_t qloc = (uint32_t)(w & 3) * 64u + qls[i];
+    const float4 qq = qp_lds[qloc];
+    const float S = i8_score(ctx->rowp[posn], qq, v);
+    if (!(S <= qq.w) || posn >= ctx->n) continue;
+    const uint64_t key = ((uint64_t)f32_to_ordered(S) << 32) | (uint64_t)((posn & 0xFFFFFF00u) | (uint32_t)ctx->perm[posn]);
+    const uint32_t q = ctx->q_tile0 + qloc;
     const uint32_t pos = atomicAdd(&ctx->pool_cnt[q], 1u);
     if (pos < cap) ctx->pool[(size_t)q * cap + pos] = key;
     else ctx->ovf[q] = 1u;  // the pool is full: the query is answered by the next engine
@@ -198,21 +210,15 @@ __device__ __attribute__((noinline)) void i8_flush_staging() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// phase 2 of the epilogue for one accumulator value per lane: lanes with `hi` evaluate their row's exact lower
-// bound and stage it when it does not exceed the query's threshold (qq.w).  LDS traffic only (see the header), and ONE
-// LDS round trip (the row's parameters): the staging buffer belongs to this wave alone, so its fill count lives in a
-// wave-uniform register (stg_n) and the slots are handed out by a ballot and a lane prefix count — round 3 took them
-// with an LDS atomic per key and waited for its return.
+// phase 2 of the epilogue for one accumulator value per lane: lanes with `hi` (the accumulator reached the integer level)
+// stage (value, position, query) for the flush, which judges it.  No read, no wait: the staging buffer belongs to this wave
+// alone, so its fill count lives in a wave-uniform register (stg_n) and the slots are handed out by a ballot and a lane
+// prefix count.
 template <bool HALF>
-__device__ __forceinline__ void i8_hit(int v, bool hi, uint32_t r_local, uint32_t tile_row0, uint32_t rp_off,
-                                       const float4 qq, int ql, int w, uint32_t n_rows, uint32_t& stg_n) {
+__device__ __forceinline__ void i8_hit(int v, bool hi, uint32_t r_local, uint32_t tile_row0, int ql, int w, uint32_t& stg_n) {
   using L = I8L<HALF>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const float4 P = *(const float4*)(smem + rp_off + r_local * 16u);
-  const float S = i8_score(P, qq, v);
-  const uint32_t grow = tile_row0 + r_local;
-  const bool ok = hi && (S <= qq.w) && grow < n_rows;
-  const uint64_t m = __ballot(ok);
+  const uint64_t m = __ballot(hi);
   if (m == 0ull) return;
   const uint32_t k = (uint32_t)__builtin_popcountll(m);
   uint32_t* cnt = (uint32_t*)(smem + L::kStgCntOff) + w;
@@ -222,11 +228,11 @@ __device__ __forceinline__ void i8_hit(int v, bool hi, uint32_t r_local, uint32_
     i8_flush_staging<HALF>();
     stg_n = 0u;
   }
-  if (ok) {
+  if (hi) {
     const uint32_t pos = stg_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     uint64_t* keys = (uint64_t*)(smem + L::kStgKeyOff) + (size_t)w * L::kStgCap;
     uint32_t* qls = (uint32_t*)(smem + L::kStgQlOff) + (size_t)w * L::kStgCap;
-    keys[pos] = ((uint64_t)f32_to_ordered(S) << 32) | grow;
+    keys[pos] = ((uint64_t)(uint32_t)v << 32) | (uint64_t)(tile_row0 + r_local);
     qls[pos] = (uint32_t)ql;
   }
   stg_n += k;
@@ -236,7 +242,7 @@ __device__ __forceinline__ void i8_hit(int v, bool hi, uint32_t r_local, uint32_
 
 size_t scan_i8_lds_bytes() { return I8L<false>::kLdsBytes; }
 
-// DUMP: the sample pass — every lower bound of the scanned tiles is written to a.dump[row - tile0*256][q] and
+// DUMP: the sample pass — every lower bound of the scanned tiles is written to a.dump[scan8_dump_index(q, row - tile0*256)] and
 // sample_select256_kernel turns them into the first thresholds.
 //
 // Round 4: the matrix instruction is v_mfma_i32_16x16x64_i8.  Same rate on paper as 32x32x32, but measured on this part
@@ -307,6 +313,7 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     ctx->pool_cnt = a.pool_cnt;
     ctx->ovf = a.ovf;
     ctx->perm = a.perm;
+    ctx->rowp = a.rowp;
     ctx->pool_cap = a.pool_cap;
     ctx->n = a.n;
     ctx->q_tile0 = qt * kTileQ;
@@ -432,21 +439,37 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     const int col0 = wc * 64 + j15;                          // + 16 cb: this lane's four queries
     const uint32_t rbase = lrow0 + 4u * (uint32_t)qd;  // + 16 rb + r: this lane's 32 rows
     if (DUMP) {
-      const size_t q_rows = (size_t)a.q_tiles * kTileQ;
-      float* const o0 = a.dump + (size_t)(tile_row0 - a.tile0 * kTileRows16 + rbase) * q_rows + (size_t)qt * kTileQ + col0;
+      // Blocks of 16 queries x 16 rows, a query's 16 rows contiguous (scan8_dump_index, ehx_kernels.h): the four
+      // accumulators of a block are four consecutive rows of one query — one 16-byte store — and the 64 lanes of a store
+      // cover ONE contiguous KiB (lane (j15, qd): query j15 of the block, rows 4 qd .. 4 qd + 3); sample_select256_kernel
+      // reads a query's scores as 64-byte runs.  (Round 6.  Row-major before: 4-byte stores, and the select read one element
+      // per 4-KiB stride; plainly query-major — 16 queries 8 KiB apart per store — made this kernel 9 us slower.)
+      const size_t n_s = (size_t)a.n_tiles * kTileRows16;
+      float* const o0 = a.dump + scan8_dump_index((uint32_t)qt * kTileQ + (uint32_t)col0,
+                                                  tile_row0 - a.tile0 * kTileRows16 + rbase, (uint32_t)n_s);
+      const size_t cb_step = (n_s >> 4) << 8;   // the next block of 16 queries
       const float4 q0 = qp_lds[col0], q1 = qp_lds[col0 + 16], q2 = qp_lds[col0 + 32], q3 = qp_lds[col0 + 48];
 #pragma unroll
       for (int rb = 0; rb < 8; ++rb) {
+        float4 s0, s1, s2, s3;
+        float* const f0 = (float*)&s0;
+        float* const f1 = (float*)&s1;
+        float* const f2 = (float*)&s2;
+        float* const f3 = (float*)&s3;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float4 P = rp[rbase + 16u * (uint32_t)rb + (uint32_t)r];
-          float* o = o0 + (size_t)(16 * rb + r) * q_rows;
-          o[0] = i8_score(P, q0, acc[rb][0][r]);
-          o[16] = i8_score(P, q1, acc[rb][1][r]);
-          o[32] = i8_score(P, q2, acc[rb][2][r]);
-          o[48] = i8_score(P, q3, acc[rb][3][r]);
-          asm volatile("" ::: "memory");  // (one row at a time: 32 rows of parameters held at once spill)
+          f0[r] = i8_score(P, q0, acc[rb][0][r]);
+          f1[r] = i8_score(P, q1, acc[rb][1][r]);
+          f2[r] = i8_score(P, q2, acc[rb][2][r]);
+          f3[r] = i8_score(P, q3, acc[rb][3][r]);
         }
+        float* const o = o0 + 256 * rb;   // the next 16 rows: the next KiB
+        *(float4*)(o) = s0;
+        *(float4*)(o + cb_step) = s1;
+        *(float4*)(o + 2 * cb_step) = s2;
+        *(float4*)(o + 3 * cb_step) = s3;
+        asm volatile("" ::: "memory");  // (one row block at a time: 32 rows of parameters held at once spill)
       }
       return;
     }
@@ -504,7 +527,6 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
       // ---- phase 2: which accumulators?  First the row blocks whose own maximum reaches the level (the eight per-block
       // maxima are at hand), then their four accumulators.  A 32-bit mask per lane (bit 4 rb + r), then one set bit per
       // lane and trip. ----
-      const float4 qq = qp_lds[col0 + 16 * cb];
       const int ql = cb * 16 + j15;
       uint32_t pend = 0u;
 #pragma unroll
@@ -540,7 +562,7 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
           v = r == 0 ? c4[0] : (r == 1 ? c4[1] : (r == 2 ? c4[2] : c4[3]));
           r_local = rbase + 16u * (uint32_t)(b >> 2) + (uint32_t)r;
         }
-        i8_hit<HALF>(v, hi, r_local, tile_row0, rp_off, qq, ql, w, a.n, stg_n);
+        i8_hit<HALF>(v, hi, r_local, tile_row0, ql, w, stg_n);
       }
     }
   };
@@ -581,7 +603,9 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
   }
   if (my_tiles > 0) {  // (a chunk past the end of the pass has nothing to scan and must not touch memory)
   // ---- prologue: row parameters of tile 0, stages 0..2 into ring slots 0..2 ----
-  if (w < (int)L::kRowpWaves) EHX_DMA(rdst, 0, voff, rsrc);
+  // (the row parameters travel through LDS for the sample pass only — DUMP, which scores every accumulator; a scan pass
+  // stages its hits unjudged and the flush reads the parameters of those few rows from HBM: round 6)
+  if (DUMP && w < (int)L::kRowpWaves) EHX_DMA(rdst, 0, voff, rsrc);
   // QRES (short rows: a tile is at most four stages, ld <= 256): the query tile's stage blocks — the same for every
   // row tile — are copied ONCE into the four slots of the Q ring and stay there; a stage then copies its two X pieces
   // per wave only (half the DMA instructions, half the L2 -> LDS bytes), and the query fragments of stage ks of a
@@ -716,7 +740,7 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     const uint32_t kquads = ktiles >> 2;
     // row parameters of tile 1 (consumed by its epilogue, a whole tile from now)
     rsrc += kTileRows16 * 16;
-    if (w < (int)L::kRowpWaves) EHX_DMA(rdst, L::kRowpSlot, voff, rsrc);
+    if (DUMP && w < (int)L::kRowpWaves) EHX_DMA(rdst, L::kRowpSlot, voff, rsrc);
     // Lock-step by TILE (round 5; a.sync_tol = the tolerance in tiles): each of the chunk's query-tile workgroups
     // publishes how many tiles it has completed in a word of its own (a plain store: no read-modify-write, no return
     // value to wait for) and, once per tile, looks at a snapshot of its siblings' words taken a tile earlier (an
@@ -794,7 +818,7 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
       // tile t+2 goes to the slot tile t-1 used: every wave left that epilogue long ago
       const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 2) % 3 == (t - 1) % 3
       rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
-      if (w < (int)L::kRowpWaves) {
+      if (DUMP && w < (int)L::kRowpWaves) {
         const uint32_t rd = rdst + rp_next * L::kRowpSlot;
         EHX_DMA(rd, 0, voff, rsrc);
       }
@@ -808,7 +832,7 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
     const uint32_t total_stages = my_tiles * ktiles;
     // row parameters of tile 1 (consumed by its epilogue, a whole tile from now)
     rsrc += kTileRows16 * 16;
-    if (w < (int)L::kRowpWaves) EHX_DMA(rdst, L::kRowpSlot, voff, rsrc);
+    if (DUMP && w < (int)L::kRowpWaves) EHX_DMA(rdst, L::kRowpSlot, voff, rsrc);
     uint32_t ks = 0, t = 0, slot = 0;
     // one stage whose ring slot is a run-time value: STAGE is the stage body to use (first stage of a tile or not)
 #define EHX_RT_DX0 EHX_SDMA(dx0, voff, xsrc)
@@ -845,7 +869,7 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
       // tile t+1 (counting the new t) goes to the slot tile t-2 used: every wave left that epilogue long ago
       const uint32_t rp_next = rp_slot == 0u ? 2u : rp_slot - 1u;  // (t + 1) % 3 == (t - 2) % 3
       rp_slot = rp_slot == 2u ? 0u : rp_slot + 1u;
-      if (w < (int)L::kRowpWaves) {
+      if (DUMP && w < (int)L::kRowpWaves) {
         const uint32_t rd = rdst + rp_next * L::kRowpSlot;
         EHX_DMA(rd, 0, voff, rsrc);
       }

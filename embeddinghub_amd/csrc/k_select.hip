@@ -98,65 +98,69 @@ __device__ __forceinline__ uint64_t wave_pick256(const uint64_t (&k)[kR], uint32
 // the smallest threshold a query was ever scanned with (qparams.w, maintained by select256_kernel) — a low rank
 // only bets that the final 256th best will still lie below it, which on a sample of 2048 rows is a safe bet
 // (rank 16 is the 0.8 % quantile; the 256th best of even 100 k rows is the 0.26 % one).
-// One workgroup of 4 waves per query: each wave keeps the best 64 of its quarter of the rows, wave 0 merges.
+//
+// Round 6: ONE wave per query, no sorting at all.  The sample pass dumps its scores in 16 x 16 blocks (scan8_dump_index: a
+// query's scores come as 64-byte runs, read with eight float4 loads per lane), every lane keeps its 32 scores as
+// order-preserving 32-bit keys in registers, and the rank-th smallest key is found by bisection of the key range: a step
+// counts the keys <= mid with one compare + ballot + scalar popcount per register (no cross-lane data movement), ~25 steps
+// for scores that span a few binades.  Rounds 2-5: four waves per query, each sorting its quarter 64 keys at a time with
+// 64-bit bitonic networks (28 shuffle layers per 64 scores) from a row-major dump read one 4-byte element per 4-KiB
+// stride — 25-27 us per batch whatever the shape, 2.6 % of a 6.25 M x 128 batch; now ~6.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sample_select256_kernel(const float* __restrict__ scores, uint32_t n_rows,
-                                                               uint32_t q_rows, uint32_t rank,
-                                                               float* __restrict__ thr) {
-  __shared__ uint64_t part[4][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+__global__ __launch_bounds__(64) void sample_select256_kernel(const float* __restrict__ scores, uint32_t n_rows,
+                                                              uint32_t nq, uint32_t rank, float* __restrict__ thr) {
+  constexpr int kV = 8;  // float4 loads per lane: up to 8 x 64 x 4 = 2048 scores
+  const int lane = threadIdx.x;
   const uint32_t q = blockIdx.x;
-  auto sort64 = [&](uint64_t v) {
+  if (q >= nq) return;
+  const uint32_t n4 = n_rows >> 2;  // (n_rows % 16 == 0: the sample is whole tiles)
+  uint32_t k[kV * 4];
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u, n_valid = 0u;
 #pragma unroll
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+  for (int i = 0; i < kV; ++i) {
+    const uint32_t at = (uint32_t)i * 64u + (uint32_t)lane;
+    float4 v = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff());
+    if (at < n4) v = *(const float4*)(scores + scan8_dump_index(q, at << 2, n_rows));   // rows 4 at .. 4 at + 3: 16 bytes of a 64-byte run
+    const float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int j = k2 >> 1; j > 0; j >>= 1) {
-        const uint64_t other = __shfl_xor(v, j, 64);
-        const bool up = (lane & k2) == 0;
-        const bool lower = (lane & j) == 0;
-        const uint64_t lo = umin64(v, other), hi = umax64(v, other);
-        v = (lower == up) ? lo : hi;
-      }
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = f[j] == f[j] && f[j] < __builtin_inff();
+      const uint32_t key = ok ? f32_to_ordered(f[j]) : 0xFFFFFFFFu;
+      k[i * 4 + j] = key;
+      kmin = min(kmin, key);
+      kmax = ok ? max(kmax, key) : kmax;
+      n_valid += (uint32_t)__builtin_popcountll(__ballot(ok));   // (wave-uniform)
     }
-    return v;
-  };
-  auto merge64 = [&](uint64_t best, uint64_t v_sorted) {
-    const uint64_t rv = __shfl(v_sorted, 63 - lane, 64);
-    best = umin64(best, rv);
-#pragma unroll
-    for (int j = 32; j > 0; j >>= 1) {
-      const uint64_t other = __shfl_xor(best, j, 64);
-      const uint64_t lo = umin64(best, other), hi = umax64(best, other);
-      best = (lane & j) == 0 ? lo : hi;
-    }
-    return best;
-  };
-  uint64_t best = kKeyInf;
-  for (uint32_t r0 = (uint32_t)w * 64u; r0 < n_rows; r0 += 256) {
-    const uint32_t row = r0 + (uint32_t)lane;
-    uint64_t key = kKeyInf;
-    if (row < n_rows) {
-      const float sc = scores[(size_t)row * q_rows + q];
-      if (sc == sc && sc < __builtin_inff()) key = ((uint64_t)f32_to_ordered(sc) << 32) | 0xFFFFFFFFull;
-    }
-    best = merge64(best, sort64(key));
   }
-  part[w][lane] = best;
-  __syncthreads();
-  if (w == 0) {
-    best = merge64(best, part[1][lane]);
-    best = merge64(best, part[2][lane]);
-    best = merge64(best, part[3][lane]);
-    const uint64_t kth = __shfl(best, (int)(rank - 1), 64);
-    if (lane == 0) thr[q] = kth == kKeyInf ? __builtin_inff() : ordered_to_f32((uint32_t)(kth >> 32));
+  if (n_valid < rank) {   // fewer valid scores than the rank asks for
+    if (lane == 0) thr[q] = __builtin_inff();
+    return;
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+    kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+  }
+  // smallest key x with |{keys <= x}| >= rank, x in [kmin, kmax] (kmax qualifies: n_valid >= rank)
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)kmin), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)kmax);
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    uint32_t cnt = 0u;
+#pragma unroll
+    for (int i = 0; i < kV * 4; ++i) cnt += (uint32_t)__builtin_popcountll(__ballot(k[i] <= mid));
+    if (cnt >= rank) hi = mid;
+    else lo = mid + 1u;
+  }
+  if (lane == 0) thr[q] = ordered_to_f32(lo);
 }
 
 hipError_t launch_sample_select256(const float* scores, uint32_t n_rows, uint32_t q_rows, uint32_t nq,
                                    uint32_t rank, float* thr, hipStream_t st) {
+  (void)q_rows;
   if (rank < 1) rank = 1;
   if (rank > 64) rank = 64;
-  hipLaunchKernelGGL(sample_select256_kernel, dim3(nq), dim3(256), 0, st, scores, n_rows, q_rows, rank, thr);
+  if (n_rows == 0 || n_rows > 2048 || (n_rows & 15u)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sample_select256_kernel, dim3(nq), dim3(64), 0, st, scores, n_rows, nq, rank, thr);
   return hipGetLastError();
 }
 
