@@ -705,11 +705,11 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
       std::lock_guard<std::mutex> cl(c.mu);
       if (!c.ev_valid) continue;
       HIP_TRY(hipEventSynchronize(c.ev[3]));
-      if (c.ev_seq > newest) {
+      if (c.timed_valid && c.ev_seq > newest) {   // (the set's last TIMED batch: every EHX_STATS_EVERY-th)
         newest = c.ev_seq;
         if (c.last_scan[0] && c.last_scan[1] && hipEventElapsedTime(&ms, c.last_scan[0], c.last_scan[1]) == hipSuccess)
           out->last_scan_ms = ms;
-        if (hipEventElapsedTime(&ms, c.ev[0], c.ev[3]) == hipSuccess) out->last_total_ms = ms;
+        if (hipEventElapsedTime(&ms, c.ev[0], c.ev[2]) == hipSuccess) out->last_total_ms = ms;
       }
       const uint64_t m = c.ring_count < 64 ? c.ring_count : 64;
       for (uint64_t i = 0; i < m; ++i)
@@ -776,6 +776,7 @@ int ehx_stats_reset(ehx_space* s) {
   for (auto& c : s->i8set) {
     std::lock_guard<std::mutex> cl(c.mu);
     c.ring_count = 0;
+    c.batches = 0;   // (the next batch of the set is a timed one)
   }
   if (s->dUncert) HIP_TRY(hipMemset(s->dUncert, 0, 2 * sizeof(unsigned long long)));
   if (s->dGraphCounters) HIP_TRY(hipMemset(s->dGraphCounters, 0, kGraphCounters * sizeof(unsigned long long)));

@@ -33,6 +33,7 @@ struct Env {
   bool i8_debug = false;          // EHX_I8_DEBUG: what the uncertified queries of a batch look like, on stderr
   bool i8_qres = true;            // EHX_I8_QRES=0: short rows through the query ring instead of the resident query tile
   bool i8_half = true;            // EHX_I8_HALF=0: rows of <= 128 dims through full-tile workgroups (one per CU)
+  uint32_t stats_every = 4;       // EHX_STATS_EVERY [1, 1024]: the int8 chain brackets the scan phase of every N-th batch of a scratch set with timing events
   bool i8_groupb = true;          // EHX_I8_GROUPB=0: L2^2 spaces scan under one min B per tile (no per-group B margins)
   uint32_t i8_skew = 64;          // EHX_I8_SKEW: half-tile workgroups: start skew of a SIMD's second wave, x 64 cycles (0: none)
   bool rerank_staged = true;      // EHX_RERANK_STAGED=0: every lane of the re-rank walks its own row
@@ -97,6 +98,10 @@ inline const Env& env() {
     v.i8_qres = flag("EHX_I8_QRES", true);
     v.i8_half = flag("EHX_I8_HALF", true);
     v.i8_groupb = flag("EHX_I8_GROUPB", true);
+    if (const char* g = str("EHX_STATS_EVERY")) {
+      const long x = atol(g);
+      v.stats_every = (uint32_t)(x < 1 ? 1 : (x > 1024 ? 1024 : x));
+    }
     if (const char* g = str("EHX_I8_SKEW")) {
       const long x = atol(g);
       v.i8_skew = (uint32_t)(x < 0 ? 0 : (x > 4096 ? 4096 : x));

@@ -230,6 +230,7 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
   r.uncert_flags = s->dUflags.p;
   HIP_TRY(launch_rerank(r, st));
   HIP_TRY(hipEventRecord(s->ev[3], st));
+  s->ev3_stream = st;
   s->ev_valid = true;
   s->ev_seq = ++s->ev_counter;
   if (count_stats) {
@@ -388,7 +389,8 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   }
   // (a caller's stream other than the space's own: searches already in flight there and here finish first)
   if ((rc = wait_searches_in_flight(s, st))) return rc;
-  HIP_TRY(hipEventRecord(sc.ev[0], st));
+  const bool timed = (sc.batches++ % env().stats_every) == 0;   // (the first batch after a reset is a timed one)
+  if (timed) HIP_TRY(hipEventRecord(sc.ev[0], st));
   HIP_TRY(launch_prep_queries_i8(d_queries, (uint32_t)nq, s->dims, s->ld, s->ld8, p.q_rows, s->metric, sc.dQ.p,
                                  sc.dQ8.p, sc.dQp8.p, sc.dQuv.p, sc.dThr8.p, sc.dI8Ctl.p, st));
   ScanArgsI8 a;
@@ -423,8 +425,11 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
   hipEvent_t* pr = sc.ring[sc.ring_count % 64];
   // (one record per mark: sc.ev[1] / ev[2] — "scan start / end of the LAST batch" for ehx_stats — are the ring's own events
   // of this batch; a second marker packet at the same place cost ~5 us of queue time each, twice per batch)
-  HIP_TRY(hipEventRecord(pr[0], st));
-  sc.last_scan[0] = sc.last_scan[1] = nullptr;   // (a pass that fails half way leaves no half pair for ehx_stats)
+  if (timed) {
+    HIP_TRY(hipEventRecord(pr[0], st));
+    sc.last_scan[0] = sc.last_scan[1] = nullptr;   // (a pass that fails half way leaves no half pair for ehx_stats)
+    sc.timed_valid = false;
+  }
   {  // sample pass: lower bounds of the first 2048 rows -> thr[q] = the k'-th best of them
     ScanPlan sp = plan_scan((uint32_t)nq, kSampleTiles, k, E.n_cus);
     a.dump = sc.dSample8.p;
@@ -444,7 +449,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
       if (i > 0) HIP_TRY(hipMemsetAsync(sync, 0, kSyncWordsI8 * sizeof(uint32_t), st));
     }
     HIP_TRY(scan(passes[i].plan, passes[i].tile0));
-    if (last) {  // (the last select and the re-rank are outside the timed scan phase, like flat_pass's final merge)
+    if (last && timed) {  // (the last select and the re-rank are outside the timed scan phase, like flat_pass's final merge)
       HIP_TRY(hipEventRecord(pr[1], st));
       sc.last_scan[0] = pr[0];   // both marks of THIS batch, set together
       sc.last_scan[1] = pr[1];
@@ -506,8 +511,13 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
     }
   }
   HIP_TRY(hipEventRecord(sc.ev[3], st));
+  sc.ev3_stream = st;
   sc.ev_valid = true;
-  sc.ev_seq = ++s->ev_counter;
+  if (timed) {
+    HIP_TRY(hipEventRecord(sc.ev[2], st));
+    sc.timed_valid = true;
+    sc.ev_seq = ++s->ev_counter;
+  }
   if (count_stats) {
     s->n_queries += nq;
     s->n_dist += (uint64_t)nq * s->n;
@@ -578,6 +588,7 @@ int exhaustive_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_quer
     if (pg + 1 == pages) HIP_TRY(hipEventRecord(s->ev[2], st));
   }
   HIP_TRY(hipEventRecord(s->ev[3], st));
+  s->ev3_stream = st;
   s->ev_valid = true;
   s->ev_seq = ++s->ev_counter;
   s->n_dist += (uint64_t)nq * s->n * pages;
@@ -711,6 +722,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
     if (subset) {
       HIP_TRY(launch_scatter_results(oi, od, oc, s->dFbIdx.p, (uint32_t)m, k, d_ids, d_dist, d_count, st));
       HIP_TRY(hipEventRecord(s->ev[3], st));
+      s->ev3_stream = st;
     }
     // verdict
     unc->clear();

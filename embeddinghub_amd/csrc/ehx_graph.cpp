@@ -483,6 +483,7 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
   HIP_TRY(hipEventRecord(s->ev[2], st));
   s->ring_count++;
   HIP_TRY(hipEventRecord(s->ev[3], st));
+  s->ev3_stream = st;
   s->ev_valid = true;
   s->ev_seq = ++s->ev_counter;
   s->n_queries += nq;

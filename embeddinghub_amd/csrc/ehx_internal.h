@@ -345,7 +345,13 @@ struct ehx_space {
     DevBuf<uint64_t> dCnt;    // [8] epilogue counters of diagnosis builds (EHX_I8_COUNT); the set's own: nothing shared
     unsigned long long* dUncert = nullptr;
     unsigned long long* hUncertPin = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start | (unused) | (unused) | all enqueued work done
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start of the last TIMED batch | (unused) | its end | all enqueued
+                                                              // work done (every batch: what writers and other streams wait for)
+    // Timing events are recorded on every EHX_STATS_EVERY-th batch of the set only (round 6: an event record between two
+    // kernels idles the queue ~6 us — start, scan start, scan end and end were 24 us of a 0.9-ms batch)
+    hipStream_t ev3_stream = nullptr;   // the stream ev[3] was last recorded on (work queued there later is behind it anyway)
+    uint64_t batches = 0;        // batches run in this set since the last ehx_stats_reset
+    bool timed_valid = false;    // ev[0] / ev[2] / last_scan[] hold a recorded batch
     hipEvent_t last_scan[2] = {nullptr, nullptr};            // scan start / end of the last batch: two of ring[][]'s events
     hipEvent_t verdict = nullptr;                            // blocking-sync: the verdict has landed in hUncertPin
     std::atomic<bool> ev_valid{false};
@@ -366,6 +372,7 @@ struct ehx_space {
   float* hStage = nullptr;  // pinned staging (Set / Get / query upload)
   size_t hStageBytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t ev3_stream = nullptr;   // the stream ev[3] was last recorded on
   std::atomic<bool> ev_valid{false};
   uint64_t ev_seq = 0;
   // ring of (start, stop) event pairs around the scan kernel: per-launch durations for the roofline

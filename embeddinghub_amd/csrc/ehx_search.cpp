@@ -244,12 +244,13 @@ static int knn_host_direct(ehx_space* s, size_t n_queries, const float* queries,
     if ((rc = flat_pass8(s, set, s->stream, n_queries, hs->dq.p, k, d_ids, d_dist, d_cnt, false, &kprime_used))) return rc;
     HIP_TRY(hipMemcpyAsync(sc.hUncertPin, sc.dUncert, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipEventRecord(sc.verdict, s->stream));
-    HIP_TRY(hipEventRecord(hs->done_ev, s->stream));
     ql.unlock();
     // the results start their way back NOW, before the verdict is known (it is clean for all but a few batches in a
     // thousand): one host wait per batch instead of two in a row — verdict, then copy.  A batch that did lose queries runs
     // the rest of the chain below and copies again (same slot stream: in order, the later copy wins).
-    HIP_TRY(hipStreamWaitEvent(hs->st, hs->done_ev, 0));
+    // (it waits for the verdict's event — recorded right behind the re-rank and the 8-byte verdict copy; a marker of its own
+    // cost the queue another ~6 us per batch)
+    HIP_TRY(hipStreamWaitEvent(hs->st, sc.verdict, 0));
     HIP_TRY(hipMemcpyAsync(hs->pin + qbytes, hs->dout.p, out_bytes, hipMemcpyDeviceToHost, hs->st));
     copied_early = true;
     HIP_TRY(hipEventSynchronize(sc.verdict));

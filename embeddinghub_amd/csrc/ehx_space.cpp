@@ -175,9 +175,11 @@ int ensure_rows(ehx_space* s, uint64_t rows) {
 // work enqueued on stream `st` from here on starts after every search of this space that is already in flight (whatever
 // stream it was given, whichever scratch set it runs in)
 int wait_searches_in_flight(ehx_space* s, hipStream_t st) {
-  if (s->ev_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
+  // (an event recorded on `st` itself orders nothing that the stream's own order does not: no wait packet — three of them per
+  // batch of the host pipeline, every batch on the space's stream, were ~10 us of queue time; round 6)
+  if (s->ev_valid && s->ev3_stream != st) HIP_TRY(hipStreamWaitEvent(st, s->ev[3], 0));
   for (auto& o : s->i8set)
-    if (o.ev_valid) HIP_TRY(hipStreamWaitEvent(st, o.ev[3], 0));
+    if (o.ev_valid && o.ev3_stream != st) HIP_TRY(hipStreamWaitEvent(st, o.ev[3], 0));
   return EHX_OK;
 }
 

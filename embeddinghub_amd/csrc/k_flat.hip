@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "ehx_kernels.h"
+#include "k_prep_query.h"
 
 namespace ehx {
 
@@ -303,13 +304,7 @@ __global__ __launch_bounds__(256) void single_query_kernel(const SingleQueryArgs
   __syncthreads();
   if (a.metric == 2) {
     if (tid == 0) {  // ONE sequential sum, hnswlib-python's order (prep_query_row's arithmetic)
-      float sum = 0.0f;
-      uint32_t i = 0;
-      for (; i + 4 <= a.dims; i += 4) {
-        const float4 v = *(const float4*)(sq + i);
-        sum = ex_add(ex_add(ex_add(ex_add(sum, v.x), v.y), v.z), v.w);
-      }
-      for (; i < a.dims; ++i) sum = ex_add(sum, sq[i]);
+      const float sum = seq_sum_lds(sq, a.dims);
       sq[0] = ex_div(1.0f, ex_add(ex_sqrt(sum), 1e-30f));
     }
     __syncthreads();

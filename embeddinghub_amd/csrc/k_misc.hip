@@ -693,21 +693,85 @@ hipError_t launch_tilep8_pad(float4* tilep8, uint64_t t0, uint64_t n, hipStream_
   return hipGetLastError();
 }
 
-namespace {
-__device__ __forceinline__ void prep_query8_row(const float* __restrict__ q_in, uint32_t nq, uint32_t dims, uint32_t ld8,
-                                                int metric, int8_t* __restrict__ Q8, float4* __restrict__ qparams,
-                                                float2* __restrict__ quv, float* __restrict__ thr, uint32_t row,
-                                                int lane) {
-  const uint32_t kts = ld8 >> 6;
-  // the three blocks after the last stage repeat the tile's first stages — block kts + j holds stage j mod kts — so
-  // that the scan's three-stage look-ahead reads linearly across a tile boundary (kts = 2: stages 0, 1, 0)
-  auto put = [&](uint32_t c, int8_t v) {
-    const uint32_t stg = c >> 6;
-    Q8[scanq8_index(row, stg, c & 63u, ld8)] = v;
-    for (uint32_t j = stg; j < 3u; j += kts) Q8[scanq8_index(row, kts + j, c & 63u, ld8)] = v;
+// Everything a batch of the int8 engine needs before its first scan launch, ONE launch (it was three: the fp32 query
+// rows of the re-rank, the int8 tiles + parameters, and a memset of the scan's control words).
+// ctl = [q_rows] pool counts | [q_rows] overflow flags | [kSyncWordsI8] counters.
+//
+// Round 6: one workgroup of TWO waves per query row.  The row is read once, coalesced, into LDS; wave 0 makes the prepared
+// fp32 row of the re-rank (cosine: the canonical norm is ONE sequential sum in hnswlib's order — lane 0 walks the row in LDS,
+// the same multiplications and additions as prep_query_row / seq_sumsq, bit for bit), wave 1 meanwhile the int8 tile and the
+// bound's parameters: every lane owns whole 16-byte chunks of the stage-blocked layout (16 columns: four LDS reads, ONE
+// 16-byte store per copy instead of sixteen byte stores).  Before: one wave per row did both in turn, read the row four
+// times from global memory and wrote the int8 tile a byte at a time — 27 us at 1024 x 768, 3 % of a 1 M-row batch.
+__global__ __launch_bounds__(128) void prep_queries_i8_kernel(const float* __restrict__ q_in, uint32_t nq, uint32_t dims,
+                                                              uint32_t ld, uint32_t ld8, uint32_t q_rows, int metric,
+                                                              float* __restrict__ q_out, int8_t* __restrict__ Q8,
+                                                              float4* __restrict__ qparams, float2* __restrict__ quv,
+                                                              float* __restrict__ thr, uint32_t* __restrict__ ctl) {
+  __shared__ __attribute__((aligned(16))) float xs[2048 + 64];   // the raw row, zero beyond dims (dims <= 2048: ehx_api.cpp)
+  const uint32_t row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool live = row < nq;
+  const uint32_t cmax = (ld8 > ld ? ld8 : ld);   // (<= 2048 + padding of the fp32 stride)
+  {
+    const float* in = q_in + (size_t)row * dims;
+    for (uint32_t c = (uint32_t)tid; c < cmax && c < 2048u + 64u; c += 128) xs[c] = (live && c < dims) ? in[c] : 0.0f;
+  }
+  __syncthreads();
+  if (w == 0) {
+    // ---- the prepared fp32 row ----
+    float* out = q_out + (size_t)row * ld;
+    float inv = 1.0f;
+    if (live && metric == 2) {
+      float v = 0.0f;
+      if (lane == 0) {
+        float sum = 0.0f;
+        uint32_t i = 0;
+        // (32 elements per trip, all eight LDS reads issued before the first addition: the chain of 768 dependent additions
+        // is the floor of this kernel, an LDS round trip per four of them on top was three times that)
+        for (; i + 32 <= dims; i += 32) {
+          float4 b[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) b[j] = *(const float4*)(xs + i + 4 * j);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            sum = ex_add(ex_add(ex_add(ex_add(sum, ex_mul(b[j].x, b[j].x)), ex_mul(b[j].y, b[j].y)), ex_mul(b[j].z, b[j].z)),
+                         ex_mul(b[j].w, b[j].w));
+        }
+        for (; i + 4 <= dims; i += 4) {
+          const float4 x4 = *(const float4*)(xs + i);
+          sum = ex_add(ex_add(ex_add(ex_add(sum, ex_mul(x4.x, x4.x)), ex_mul(x4.y, x4.y)), ex_mul(x4.z, x4.z)), ex_mul(x4.w, x4.w));
+        }
+        for (; i < dims; ++i) sum = ex_add(sum, ex_mul(xs[i], xs[i]));
+        v = inv_norm_of(sum);
+      }
+      inv = __shfl(v, 0, 64);
+    }
+    for (uint32_t i = (uint32_t)lane; i < ld; i += 64) {
+      float v = i < 2048u + 64u ? xs[i] : 0.0f;
+      if (live && metric == 2) v = ex_mul(v, inv);
+      out[i] = v;
+    }
+    if (lane == 0) {
+      ctl[row] = 0;
+      ctl[q_rows + row] = 0;
+    }
+    if (row == 0)
+      for (uint32_t i = lane; i < kSyncWordsI8; i += 64) ctl[2 * (size_t)q_rows + i] = 0;
+    return;
+  }
+  // ---- wave 1: the int8 tile (scanq8_index: [stage][row of the query tile][64 bytes, 16-byte chunks swizzled by the row];
+  // the three blocks after the last stage repeat the tile's first stages — block kts + j holds stage j mod kts — so that the
+  // scan's three-stage look-ahead reads linearly across a tile boundary) and the parameters ----
+  const uint32_t kts = ld8 >> 6, n_chunks = kts * 4u;   // (<= 128: two chunks per lane at most)
+  auto put16 = [&](uint32_t chunk, const int4 v) {
+    const uint32_t stg = chunk >> 2, cl = chunk & 3u;
+    // (scanq8_index(row, stage, 16 cl, ld8): the chunk's 16 bytes are contiguous and 16-byte aligned)
+    *(int4*)(Q8 + scanq8_index(row, stg, cl * 16u, ld8)) = v;
+    for (uint32_t j = stg; j < 3u; j += kts) *(int4*)(Q8 + scanq8_index(row, kts + j, cl * 16u, ld8)) = v;
   };
-  if (row >= nq) {
-    for (uint32_t c = lane; c < ld8; c += 64) put(c, 0);
+  if (!live) {
+    for (uint32_t ch = (uint32_t)lane; ch < n_chunks; ch += 64) put16(ch, make_int4(0, 0, 0, 0));
     if (lane == 0) {
       qparams[row] = make_float4(0.0f, 0.0f, 1.0f, __builtin_inff());
       quv[row] = make_float2(1.0f, 0.0f);
@@ -715,26 +779,49 @@ __device__ __forceinline__ void prep_query8_row(const float* __restrict__ q_in, 
     }
     return;
   }
-  const float* in = q_in + (size_t)row * dims;
+  float x[2][16];
   float ss = 0.0f;
-  for (uint32_t c = lane; c < dims; c += 64) ss += in[c] * in[c];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const uint32_t ch = (uint32_t)lane + 64u * (uint32_t)t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (ch < n_chunks) v = *(const float4*)(xs + ch * 16u + 4u * (uint32_t)j);
+      x[t][4 * j + 0] = v.x;
+      x[t][4 * j + 1] = v.y;
+      x[t][4 * j + 2] = v.z;
+      x[t][4 * j + 3] = v.w;
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+  }
   ss = wave_sum(ss);
   const bool ok = norm_ok(ss);
   const float beta = ok ? __builtin_sqrtf(ss) : 0.0f;
   const float inv = beta > 0.0f ? 1.0f / beta : 0.0f;
   float amax = 0.0f;
-  for (uint32_t c = lane; c < dims; c += 64) amax = fmaxf(amax, fabsf(in[c] * inv));
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) amax = fmaxf(amax, fabsf(x[t][j] * inv));
   amax = wave_max(amax);
   const float s = amax / 127.0f;
   const float rs = amax > 0.0f ? 127.0f / amax : 0.0f;
   float e2 = 0.0f;
-  for (uint32_t c = lane; c < ld8; c += 64) {
-    const float v = c < dims ? in[c] * inv : 0.0f;
-    float qf = rintf(v * rs);
-    qf = fminf(fmaxf(qf, -127.0f), 127.0f);
-    put(c, (int8_t)(int)qf);
-    const float res = v - s * qf;
-    e2 += res * res;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const uint32_t ch = (uint32_t)lane + 64u * (uint32_t)t;
+    uint32_t pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float v = x[t][j] * inv;   // (columns beyond dims: 0 -> code 0, residual 0)
+      float qf = rintf(v * rs);
+      qf = fminf(fmaxf(qf, -127.0f), 127.0f);
+      pk[j >> 2] |= ((uint32_t)(int)qf & 0xFFu) << (8 * (j & 3));
+      const float res = v - s * qf;
+      e2 += res * res;
+    }
+    if (ch < n_chunks) put16(ch, make_int4((int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]));
   }
   e2 = wave_sum(e2);
   if (lane == 0) {
@@ -755,33 +842,12 @@ __device__ __forceinline__ void prep_query8_row(const float* __restrict__ q_in, 
     thr[row] = __builtin_inff();
   }
 }
-}  // namespace
-
-// Everything a batch of the int8 engine needs before its first scan launch, ONE launch (it was three: the fp32 query
-// rows of the re-rank, the int8 tiles + parameters, and a memset of the scan's control words): one wave per query row
-// writes its prepared fp32 row, its int8 tile and parameters, and zeroes its pool count and overflow flag; block 0 also
-// zeroes the lock-step counters.  ctl = [q_rows] pool counts | [q_rows] overflow flags | [kSyncWordsI8] counters.
-__global__ __launch_bounds__(64) void prep_queries_i8_kernel(const float* __restrict__ q_in, uint32_t nq, uint32_t dims,
-                                                             uint32_t ld, uint32_t ld8, uint32_t q_rows, int metric,
-                                                             float* __restrict__ q_out, int8_t* __restrict__ Q8,
-                                                             float4* __restrict__ qparams, float2* __restrict__ quv,
-                                                             float* __restrict__ thr, uint32_t* __restrict__ ctl) {
-  const uint32_t row = blockIdx.x;
-  const int lane = threadIdx.x;
-  prep_query_row(q_in, nq, dims, ld, metric, q_out, row, lane);
-  prep_query8_row(q_in, nq, dims, ld8, metric, Q8, qparams, quv, thr, row, lane);
-  if (lane == 0) {
-    ctl[row] = 0;
-    ctl[q_rows + row] = 0;
-  }
-  if (row == 0)
-    for (uint32_t i = lane; i < kSyncWordsI8; i += 64) ctl[2 * (size_t)q_rows + i] = 0;
-}
 
 hipError_t launch_prep_queries_i8(const float* q_in, uint32_t nq, uint32_t dims, uint32_t ld, uint32_t ld8,
                                   uint32_t q_rows, int metric, float* q_out, int8_t* Q8, float4* qparams, float2* quv,
                                   float* thr, uint32_t* ctl, hipStream_t st) {
-  hipLaunchKernelGGL(prep_queries_i8_kernel, dim3(q_rows), dim3(64), 0, st, q_in, nq, dims, ld, ld8, q_rows, metric,
+  if (dims > 2048u || ld8 > 2048u || ld > 2048u + 64u) return hipErrorInvalidValue;   // (the int8 engine's own limit: ehx_api.cpp)
+  hipLaunchKernelGGL(prep_queries_i8_kernel, dim3(q_rows), dim3(128), 0, st, q_in, nq, dims, ld, ld8, q_rows, metric,
                      q_out, Q8, qparams, quv, thr, ctl);
   return hipGetLastError();
 }

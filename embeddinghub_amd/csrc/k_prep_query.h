@@ -9,6 +9,28 @@ __device__ __forceinline__ float inv_norm_of(float sumsq) {
   return ex_div(1.0f, ex_add(ex_sqrt(sumsq), 1e-30f));
 }
 
+// ((...((0 + s[0]) + s[1]) + ...) + s[n - 1]): ONE sequential sum of n floats in LDS (s 16-byte aligned), exactly in index
+// order.  32 elements per trip, the eight LDS reads issued before the first addition: the dependent additions are the floor
+// (768 of them ~3 us), an LDS round trip per four of them on top was three times that (round 6: 1024 x 768 queries prepared
+// in 13 us instead of 27; one query per call on a graph space 10 us less).
+__device__ __forceinline__ float seq_sum_lds(const float* s, uint32_t n) {
+  float sum = 0.0f;
+  uint32_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    float4 b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = *(const float4*)(s + i + 4 * j);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum = ex_add(ex_add(ex_add(ex_add(sum, b[j].x), b[j].y), b[j].z), b[j].w);
+  }
+  for (; i + 4 <= n; i += 4) {
+    const float4 v = *(const float4*)(s + i);
+    sum = ex_add(ex_add(ex_add(ex_add(sum, v.x), v.y), v.z), v.w);
+  }
+  for (; i < n; ++i) sum = ex_add(sum, s[i]);
+  return sum;
+}
+
 // one wave per output row: lane 0 computes the canonical norm, all lanes scale/copy
 __device__ __forceinline__ void prep_query_row(const float* __restrict__ q_in, uint32_t nq, uint32_t dims, uint32_t ld,
                                                int metric, float* __restrict__ q_out, uint32_t row, int lane) {
@@ -35,6 +57,13 @@ __device__ __forceinline__ void prep_query_row(const float* __restrict__ q_in, u
       __syncthreads();
       if (lane == 0) {
         uint32_t i = 0;
+        for (; i + 32 <= m; i += 32) {   // (seq_sum_lds's trip, continuing the running sum across 1024-element blocks)
+          float4 b[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) b[j] = *(const float4*)(sq + i + 4 * j);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sum = ex_add(ex_add(ex_add(ex_add(sum, b[j].x), b[j].y), b[j].z), b[j].w);
+        }
         for (; i + 4 <= m; i += 4) {
           const float4 v = *(const float4*)(sq + i);
           sum = ex_add(ex_add(ex_add(ex_add(sum, v.x), v.y), v.z), v.w);
