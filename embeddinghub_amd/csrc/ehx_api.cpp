@@ -718,6 +718,10 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
           ++got;
         }
     }
+    if (got == 0 && out->last_scan_ms > 0.0) {   // (only first batches so far: the int8 chain keeps them out of its ring)
+      sum = out->last_scan_ms;
+      got = 1;
+    }
     out->scan_launches = got;
     out->scan_ms_mean = got ? sum / (double)got : 0.0;
     (void)hipGetLastError();  // an event that was never recorded is not an error of the caller's next launch

@@ -33,7 +33,7 @@ struct Env {
   bool i8_debug = false;          // EHX_I8_DEBUG: what the uncertified queries of a batch look like, on stderr
   bool i8_qres = true;            // EHX_I8_QRES=0: short rows through the query ring instead of the resident query tile
   bool i8_half = true;            // EHX_I8_HALF=0: rows of <= 128 dims through full-tile workgroups (one per CU)
-  uint32_t stats_every = 4;       // EHX_STATS_EVERY [1, 1024]: the int8 chain brackets the scan phase of every N-th batch of a scratch set with timing events
+  uint32_t stats_every = 2;       // EHX_STATS_EVERY [1, 1024]: the int8 chain brackets the scan phase of every N-th batch of a scratch set with timing events
   bool i8_groupb = true;          // EHX_I8_GROUPB=0: L2^2 spaces scan under one min B per tile (no per-group B margins)
   uint32_t i8_skew = 64;          // EHX_I8_SKEW: half-tile workgroups: start skew of a SIMD's second wave, x 64 cycles (0: none)
   bool rerank_staged = true;      // EHX_RERANK_STAGED=0: every lane of the re-rank walks its own row

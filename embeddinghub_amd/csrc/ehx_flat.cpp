@@ -385,11 +385,14 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
     for (auto& e : sc.ev) HIP_TRY(hipEventCreate(&e));
     for (auto& pr2 : sc.ring)
       for (auto& e : pr2) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : sc.first_pair) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventCreateWithFlags(&sc.verdict, hipEventBlockingSync | hipEventDisableTiming));
   }
   // (a caller's stream other than the space's own: searches already in flight there and here finish first)
   if ((rc = wait_searches_in_flight(s, st))) return rc;
-  const bool timed = (sc.batches++ % env().stats_every) == 0;   // (the first batch after a reset is a timed one)
+  const uint64_t batch_no = sc.batches++;
+  const bool in_ring = (batch_no % env().stats_every) == env().stats_every - 1u;
+  const bool timed = in_ring || batch_no == 0;   // (the first batch after a reset is a timed one, outside the ring's mean)
   if (timed) HIP_TRY(hipEventRecord(sc.ev[0], st));
   HIP_TRY(launch_prep_queries_i8(d_queries, (uint32_t)nq, s->dims, s->ld, s->ld8, p.q_rows, s->metric, sc.dQ.p,
                                  sc.dQ8.p, sc.dQp8.p, sc.dQuv.p, sc.dThr8.p, sc.dI8Ctl.p, st));
@@ -422,7 +425,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
     a.xcd_map = pl.xcd_map;
     return launch_flat_scan_i8(a, st);
   };
-  hipEvent_t* pr = sc.ring[sc.ring_count % 64];
+  hipEvent_t* pr = in_ring ? sc.ring[sc.ring_count % 64] : sc.first_pair;
   // (one record per mark: sc.ev[1] / ev[2] — "scan start / end of the LAST batch" for ehx_stats — are the ring's own events
   // of this batch; a second marker packet at the same place cost ~5 us of queue time each, twice per batch)
   if (timed) {
@@ -453,7 +456,7 @@ int flat_pass8(ehx_space* s, int set, hipStream_t st, size_t nq, const float* d_
       HIP_TRY(hipEventRecord(pr[1], st));
       sc.last_scan[0] = pr[0];   // both marks of THIS batch, set together
       sc.last_scan[1] = pr[1];
-      sc.ring_count++;
+      if (in_ring) sc.ring_count++;
     }
     HIP_TRY(launch_select256(sc.dPool.p, pool_cnt, kPoolCap, (uint32_t)nq, rank_after(i), sc.dMerged8.p, width, i > 0,
                              sc.dThr8.p, sc.dQp8.p, st));

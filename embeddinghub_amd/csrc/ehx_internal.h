@@ -348,7 +348,9 @@ struct ehx_space {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start of the last TIMED batch | (unused) | its end | all enqueued
                                                               // work done (every batch: what writers and other streams wait for)
     // Timing events are recorded on every EHX_STATS_EVERY-th batch of the set only (round 6: an event record between two
-    // kernels idles the queue ~6 us — start, scan start, scan end and end were 24 us of a 0.9-ms batch)
+    // kernels idles the queue ~6 us — start, scan start, scan end and end were 24 us of a 0.9-ms batch): batches N - 1, 2 N - 1
+    // ... go into the ring behind scan_ms_mean; batch 0 is timed too (a caller that runs one batch and asks) but stays out of
+    // the ring — the first batch behind a reset starts on an idle queue and ran 5-10 % long in the bench's 10-step runs
     hipStream_t ev3_stream = nullptr;   // the stream ev[3] was last recorded on (work queued there later is behind it anyway)
     uint64_t batches = 0;        // batches run in this set since the last ehx_stats_reset
     bool timed_valid = false;    // ev[0] / ev[2] / last_scan[] hold a recorded batch
@@ -358,6 +360,7 @@ struct ehx_space {
     uint64_t ev_seq = 0;     // value of ehx_space::ev_counter when ev[] was last recorded (ehx_stats: which set is newest)
     hipEvent_t ring[64][2] = {};
     uint64_t ring_count = 0;
+    hipEvent_t first_pair[2] = {nullptr, nullptr};   // scan start / end of the set's FIRST batch after a reset (not in the ring)
     std::mutex mu;
   };
   I8Set i8set[2];
@@ -464,6 +467,10 @@ struct ehx_space {
           if (e) (void)hipEventDestroy(e);
           e = nullptr;
         }
+      for (auto& e : c.first_pair) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+      }
     }
     dGPack.release();
     dOutPack.release();

@@ -252,9 +252,10 @@ size_t scan_i8_lds_bytes() { return I8L<false>::kLdsBytes; }
 // registers each; a stage row's 64 bytes are ONE k-step: lane l holds bytes [16 (l >> 4), +16) of row / query l & 15 of
 // its block — one ds_read_b128 per block and stage, twelve per stage as before.  Every block gets exactly one MFMA
 // per stage.  An accumulator block holds, per lane, rows 4 (l >> 4) + 0..3 of its 16 rows for query l & 15.
-template <bool DUMP, bool REV, bool QRES = false, bool HALF = false>
+template <bool DUMP, bool REV, bool QRES = false, bool HALF = false, bool PAIR = false>
 __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(const ScanArgsI8 a) {
   static_assert(!QRES || (!REV && !DUMP), "QRES: the run-time-slot loop of the plain scan only");
+  static_assert(!PAIR || (!REV && !DUMP && !QRES && !HALF), "PAIR: the run-time-slot loop of the plain scan, stages in pairs");
   static_assert(!HALF || QRES, "HALF: short rows, the query tile resident in LDS");
   using L = I8L<HALF>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -905,15 +906,50 @@ __global__ __launch_bounds__(I8L<HALF>::kThreads, 2) void flat_scan_i8_kernel(co
         st = total_stages;
       }
     }
+    if constexpr (PAIR) {
+      // (an instantiation of its own: inside the one-stage kernel the second loop cost the first four spilled registers, one of
+      // them reloaded behind an s_waitcnt vmcnt(0) in every stage)
+      // Rows of an EVEN number of stages that is no multiple of four (d = 384, 640, 896 ...: ld % 128 == 0): the stages go in
+      // pairs — the query fragments change hands by name (fb0 -> fb1 -> fb0), no sixteen register copies per stage behind an
+      // lgkmcnt(0), as in the two loops above; a tile boundary always falls between two pairs.  Slots stay run-time values.
+      // (Round 6, after the two-stage loop of the half-tile kernel: -10 % there.)
+      {
+#define EHX_RT_STAGE2(M0, BC, BN)                                                               \
+  do {                                                                                          \
+    const uint32_t sn = ((slot + 1u) & 3u) << L::kXShift, sd = ((slot + 3u) & 3u) << L::kXShift; \
+    const uint32_t dx0 = xdst + sd, dq0 = qdst + sd;                                            \
+    const uint32_t an_ = a_off + sn, bn_ = b_off + sn;                                          \
+    EHX_STAGE16_BODY(M0, BC, BN, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1);     \
+    xsrc += kStageI8;                                                                           \
+    qsrc += kStageI8;                                                                           \
+    slot = (slot + 1u) & 3u;                                                                    \
+    ++st;                                                                                       \
+  } while (0)
 #pragma unroll 1
-    while (st < total_stages) {
-      if (ks == 0u)
-        EHX_RT_STAGE(EHX_STAGE16_BODY(EHX_MFZ, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
-      else
-        EHX_RT_STAGE(EHX_STAGE16_BODY(EHX_MF, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
-      if (++ks == ktiles) {
-        ks = 0;
-        tile_done();
+        while (st < total_stages) {   // (total_stages is even)
+          if (ks == 0u) EHX_RT_STAGE2(EHX_MFZ, fb0, fb1);
+          else EHX_RT_STAGE2(EHX_MF, fb0, fb1);
+          EHX_RT_STAGE2(EHX_MF, fb1, fb0);
+          ks += 2u;
+          if (ks == ktiles) {
+            ks = 0;
+            tile_done();
+          }
+        }
+#undef EHX_RT_STAGE2
+      }
+    }
+    if constexpr (!PAIR) {
+#pragma unroll 1
+      while (st < total_stages) {
+        if (ks == 0u)
+          EHX_RT_STAGE(EHX_STAGE16_BODY(EHX_MFZ, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
+        else
+          EHX_RT_STAGE(EHX_STAGE16_BODY(EHX_MF, fb0, fb1, an_, bn_, EHX_RT_DX0, EHX_RT_DQ0, EHX_RT_DX1, EHX_RT_DQ1));
+        if (++ks == ktiles) {
+          ks = 0;
+          tile_done();
+        }
       }
     }
 #undef EHX_RT_STAGE
@@ -955,7 +991,8 @@ hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st) {
   const void* fns[] = {(const void*)flat_scan_i8_kernel<false, true>, (const void*)flat_scan_i8_kernel<false, false>,
                        (const void*)flat_scan_i8_kernel<true, true>, (const void*)flat_scan_i8_kernel<true, false>,
                        (const void*)flat_scan_i8_kernel<false, false, true>,
-                       (const void*)flat_scan_i8_kernel<false, false, true, true>};
+                       (const void*)flat_scan_i8_kernel<false, false, true, true>,
+                       (const void*)flat_scan_i8_kernel<false, false, false, false, true>};
   if (hipError_t e = attr.ensure(fns, (int)(sizeof(fns) / sizeof(fns[0])), I8L<false>::kLdsBytes); e != hipSuccess) return e;
   if (a.ld == 0 || a.ld % kRowBI8) return hipErrorInvalidValue;
   const uint32_t grid = a.q_tiles * a.n_chunks;
@@ -976,6 +1013,9 @@ hipError_t launch_flat_scan_i8(const ScanArgsI8& a, hipStream_t st) {
                          I8L<true>::kLdsBytes, st, a);
     else if (qres_on && a.ld <= 4 * kRowBI8)
       hipLaunchKernelGGL((flat_scan_i8_kernel<false, false, true>), dim3(grid), dim3(I8L<false>::kThreads), I8L<false>::kLdsBytes, st, a);
+    else if ((a.ld / kRowBI8) % 2u == 0u)   // an even number of stages per tile (d = 384, 640, 896 ...): stages in pairs
+      hipLaunchKernelGGL((flat_scan_i8_kernel<false, false, false, false, true>), dim3(grid), dim3(I8L<false>::kThreads),
+                         I8L<false>::kLdsBytes, st, a);
     else EHX_LAUNCH_I8(false, false);
   }
 #undef EHX_LAUNCH_I8
