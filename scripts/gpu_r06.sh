@@ -239,5 +239,26 @@ PY
     done
   fi
   ;;
+u)  # the round's final library: whole GPU suite, rocprofv3 trace + FETCH / WRITE of the headline, trace + SQ counters of the
+    # configs[3] shard shape, batch timelines of four shapes, the default bench run
+  timeout 2700 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 | tee $O/r06_u_pytest_gpu_tail.txt
+  TAG=r06_u PASSES="trace fetch write" BENCH_ARGS="--config-legs 0 --structured-c3-rows 0" bash scripts/gpu_profile_i8.sh 2>&1 | tail -12
+  cp $O/prof/r06_u_i8_*summary.txt $O/prof/r06_u_i8_traffic.json $O/ 2>/dev/null
+  TAG=r06_u_6250k128 PASSES="trace sq" BENCH_ARGS="--config-legs 0 --structured-c3-rows 0 --rows 6250000 --dims 128 --metric-kind l2 --steps 8" bash scripts/gpu_profile_i8.sh 2>&1 | tail -4
+  cp $O/prof/r06_u_6250k128_*summary.txt $O/ 2>/dev/null
+  find $O/prof -name "*.db" -size +4M -delete
+  S=q bash scripts/gpu_r06.sh q 2>&1 | grep -v "^W2026" | grep "total\|^#"
+  for f in $O/r06_q_*_timeline.txt; do cp $f $O/r06_u_$(basename $f | sed s/r06_q_//); done
+  timeout 1200 python bench.py > $O/r06_u_bench_line.json 2> $O/r06_u_bench.err; echo "bench rc=$?"
+  cp $O/bench_detail.json $O/r06_u_bench_detail.json 2>/dev/null
+  grep -E "leg done|skipp" $O/r06_u_bench.err | tail -20 | cut -c1-220
+  python - <<PY
+import json
+l = json.load(open("$O/r06_u_bench_line.json"))
+print(json.dumps({k: l.get(k) for k in ("value", "ms_per_step", "roofline", "one_caller_ms_per_step", "device_resident_ms_per_step")})[:900])
+for k, v in l.get("configs", {}).items():
+    print(k, {kk: v.get(kk) for kk in ("ms_per_step", "frac", "kernel_ms", "oracle")})
+PY
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
