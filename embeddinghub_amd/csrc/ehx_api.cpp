@@ -705,6 +705,7 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
       std::lock_guard<std::mutex> cl(c.mu);
       if (!c.ev_valid) continue;
       HIP_TRY(hipEventSynchronize(c.ev[3]));
+      if (c.timed_valid) HIP_TRY(hipEventSynchronize(c.ev[2]));   // (recorded right behind ev[3] on timed batches)
       if (c.timed_valid && c.ev_seq > newest) {   // (the set's last TIMED batch: every EHX_STATS_EVERY-th)
         newest = c.ev_seq;
         if (c.last_scan[0] && c.last_scan[1] && hipEventElapsedTime(&ms, c.last_scan[0], c.last_scan[1]) == hipSuccess)
