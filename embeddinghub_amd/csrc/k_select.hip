@@ -371,17 +371,25 @@ __device__ __forceinline__ float rerank_floor(const Rerank256Args& a, uint32_t q
 // pieces in LDS and every lane then reads its own row's eight pieces back.  Piece p of row r sits at slot
 // p ^ ((r >> 1) & 7) of the row's line: the write is contiguous per instruction, the read conflict-free.  One chunk
 // (128 bytes of every row) is in flight while the previous one is accumulated.
+//
+// HALFX (round 6): binary16 rows — a 128-byte line is 64 elements, a 16-byte piece eight of them, widened exactly and fed to
+// the same steps as two float4 (rows of a multiple of 64 elements).  Until then fp16 spaces re-ranked with four lanes per
+// candidate walking their row in 8-byte pieces (rerank256_kernel<__half>): 2.03 ms per batch at 12.5 M x 1536 with a
+// 1024-wide list — 3-6 x what the bytes cost; it still serves rows of other lengths.
 constexpr uint32_t kStageFloat4 = 64 * 8;  // 64 rows x 8 pieces (8 KB)
-template <int METRIC01, bool SCALE>
-__device__ __forceinline__ float wave_rows_dist_staged(const float* __restrict__ q_lds, const float* __restrict__ X,
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+template <int METRIC01, bool SCALE, bool HALFX = false>
+__device__ __forceinline__ float wave_rows_dist_staged(const float* __restrict__ q_lds, const void* __restrict__ X,
                                                        uint32_t ld, uint32_t dims, uint32_t id, bool valid, float xscale,
                                                        float4* stage, int lane) {
-  const uint32_t n_chunks = dims / 32u;
+  const uint32_t n_chunks = dims / (HALFX ? 64u : 32u);
+  const size_t row_bytes = (size_t)ld * (HALFX ? 2u : 4u);
   const int sub = lane & 7, grp = lane >> 3;
   const uint32_t my = valid ? id : 0u;
   // the row this lane helps to load in instruction i is row i*8 + grp of the wave's 64
-#define EHX_SRC(i) \
-  ((const float4*)(X + (size_t)(uint32_t)__shfl((int)my, (i) * 8 + grp, 64) * ld) + (sub ^ ((((i) * 8 + grp) >> 1) & 7)))
+#define EHX_SRC(i)                                                                                               \
+  ((const float4*)((const char*)X + (size_t)(uint32_t)__shfl((int)my, (i) * 8 + grp, 64) * row_bytes) + \
+   (sub ^ ((((i) * 8 + grp) >> 1) & 7)))
   const float4 *s0 = EHX_SRC(0), *s1 = EHX_SRC(1), *s2 = EHX_SRC(2), *s3 = EHX_SRC(3), *s4 = EHX_SRC(4),
                *s5 = EHX_SRC(5), *s6 = EHX_SRC(6), *s7 = EHX_SRC(7);
 #undef EHX_SRC
@@ -409,8 +417,18 @@ __device__ __forceinline__ float wave_rows_dist_staged(const float* __restrict__
     stage[6 * 64 + lane] = R##6, stage[7 * 64 + lane] = R##7;                                            \
     EHX_FETCH(R, (C) + 3);                                                                               \
     wave_lds_sync();                                                                                     \
-    _Pragma("unroll") for (int p = 0; p < 8; ++p)                                                        \
-      canon_lane_step<METRIC01, SCALE>(stage[lane * 8 + (p ^ key)], q4[(size_t)(C) * 8 + p], xscale, p0, p1, p2, p3); \
+    _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                      \
+      const float4 raw_ = stage[lane * 8 + (p ^ key)];                                                   \
+      if constexpr (HALFX) {                                                                             \
+        const h8_t h_ = __builtin_bit_cast(h8_t, raw_);                                                  \
+        canon_lane_step<METRIC01, SCALE>(make_float4((float)h_[0], (float)h_[1], (float)h_[2], (float)h_[3]), \
+                                         q4[(size_t)(C) * 16 + 2 * p], xscale, p0, p1, p2, p3);          \
+        canon_lane_step<METRIC01, SCALE>(make_float4((float)h_[4], (float)h_[5], (float)h_[6], (float)h_[7]), \
+                                         q4[(size_t)(C) * 16 + 2 * p + 1], xscale, p0, p1, p2, p3);      \
+      } else {                                                                                           \
+        canon_lane_step<METRIC01, SCALE>(raw_, q4[(size_t)(C) * 8 + p], xscale, p0, p1, p2, p3);         \
+      }                                                                                                  \
+    }                                                                                                    \
   } while (0)
   a0 = a1 = a2 = a3 = a4 = a5 = a6 = a7 = b0 = b1 = b2 = b3 = b4 = b5 = b6 = b7 = c0 = c1 = c2 = c3 = c4 = c5 = c6 = c7 =
       make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -432,8 +450,9 @@ __device__ __forceinline__ float wave_rows_dist_staged(const float* __restrict__
 // fp32 rows: one wave per query, one candidate per lane; rows of a multiple of 32 floats are loaded by the wave
 // together (wave_rows_dist_staged), others by the lane itself with 16-byte loads through a register ring
 // (canon_dist_lane_t); the query sits in LDS
-template <int METRIC01, bool SCALE, bool STAGED>
+template <int METRIC01, bool SCALE, bool STAGED, bool HALFX = false>
 __global__ __launch_bounds__(64) void rerank256_lane_kernel(const Rerank256Args a, uint32_t q_in_lds) {
+  static_assert(!HALFX || STAGED, "binary16 rows: the staged form only");
   extern __shared__ __attribute__((aligned(16))) float qs[];
   float4* stage = (float4*)(qs + (q_in_lds ? a.ld : 0u));  // [kStageFloat4] when `staged`
   const int lane = threadIdx.x;
@@ -457,8 +476,8 @@ __global__ __launch_bounds__(64) void rerank256_lane_kernel(const Rerank256Args 
     float d = __builtin_inff();
     if (STAGED) {
       const float xs = (SCALE && valid) ? a.inv_norm[id] : 1.0f;
-      d = wave_rows_dist_staged<METRIC01, SCALE>(qs, (const float*)a.X, a.ld, a.dims, id, valid, xs, stage, lane);
-    } else if (valid) {
+      d = wave_rows_dist_staged<METRIC01, SCALE, HALFX>(qs, a.X, a.ld, a.dims, id, valid, xs, stage, lane);
+    } else if (!HALFX && valid) {
       const float* xv = (const float*)a.X + (size_t)id * a.ld;
       const float xs = SCALE ? a.inv_norm[id] : 1.0f;
       d = q_in_lds ? canon_dist_lane_t<METRIC01, SCALE>(qs, xv, xs, a.dims)
@@ -514,13 +533,21 @@ __global__ __launch_bounds__(256) void rerank256_kernel(const Rerank256Args a) {
 }
 
 hipError_t launch_rerank256(const Rerank256Args& a, hipStream_t st) {
-  if (a.x_half) {
-    hipLaunchKernelGGL(rerank256_kernel<__half>, dim3(a.nq), dim3(256), 0, st, a);
-    return hipGetLastError();
-  }
   const size_t qbytes = (size_t)a.ld * sizeof(float);
   const uint32_t in_lds = qbytes <= 32 * 1024 ? 1u : 0u;  // (very long rows: the query stays in global memory)
   const bool allow_staged = env().rerank_staged;  // (EHX_RERANK_STAGED=0: every lane walks its own row, A/B runs)
+  if (a.x_half) {
+    // binary16 rows of a multiple of 64 elements: one wave per query, the rows loaded by the wave together (round 6)
+    if (allow_staged && in_lds && (a.dims & 63u) == 0 && a.dims >= 64) {
+      const size_t ldsh = qbytes + kStageFloat4 * sizeof(float4);
+      if (a.metric == 0) hipLaunchKernelGGL((rerank256_lane_kernel<0, false, true, true>), dim3(a.nq), dim3(64), ldsh, st, a, 1u);
+      else if (a.metric == 1) hipLaunchKernelGGL((rerank256_lane_kernel<1, false, true, true>), dim3(a.nq), dim3(64), ldsh, st, a, 1u);
+      else hipLaunchKernelGGL((rerank256_lane_kernel<1, true, true, true>), dim3(a.nq), dim3(64), ldsh, st, a, 1u);
+      return hipGetLastError();
+    }
+    hipLaunchKernelGGL(rerank256_kernel<__half>, dim3(a.nq), dim3(256), 0, st, a);
+    return hipGetLastError();
+  }
   const uint32_t staged = (allow_staged && in_lds && (a.dims & 31u) == 0 && a.dims >= 32) ? 1u : 0u;
   const size_t lds = (in_lds ? qbytes : 0) + (staged ? kStageFloat4 * sizeof(float4) : 0);
 #define EHX_RR(M, S)                                                                                              \

@@ -203,7 +203,7 @@ q)  # launch-by-launch timeline of one batch of the int8 chain (device-resident 
     set -- $shape
     tag=r06_q_$1x$2_$3
     rm -rf $O/prof/$tag
-    (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/$O/prof/$tag -o p -- python $R/scripts/ab_flat.py --rows $1 --dims $2 --metric $3 --steps 24 --warmup 6 > $R/$O/prof/$tag.log 2>&1)
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/$O/prof/$tag -o p -- python $R/scripts/ab_flat.py --rows $1 --dims $2 --metric $3 $4 --steps ${QSTEPS:-24} --warmup 6 > $R/$O/prof/$tag.log 2>&1)
     tail -1 $O/prof/$tag.log | cut -c1-250
     python scripts/batch_timeline.py $O/prof/$tag | tee $O/${tag}_timeline.txt
   done
