@@ -263,19 +263,19 @@ PY
 v)  # the driver's own sequence on the final library: smoke(), then bench.py with the driver's arguments; and the SQ counters
     # of the headline's main pass (the wave-cycle split DESIGN quotes)
   timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-  timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r06_v_bench_line.json 2> $O/r06_v_bench.err; echo "bench rc=$?"
-  cp $O/bench_detail.json $O/r06_v_bench_detail.json 2>/dev/null
+  timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r06_${VT:-v}_bench_line.json 2> $O/r06_${VT:-v}_bench.err; echo "bench rc=$?"
+  cp $O/bench_detail.json $O/r06_${VT:-v}_bench_detail.json 2>/dev/null
   python - <<PY
 import json
-l = json.load(open("$O/r06_v_bench_line.json"))
+l = json.load(open("$O/r06_${VT:-v}_bench_line.json"))
 print(json.dumps({k: l.get(k) for k in ("value", "ms_per_step", "steps", "warmup", "roofline", "one_caller_ms_per_step", "device_resident_ms_per_step")})[:900])
 for k, v in l.get("configs", {}).items():
     print(k, {kk: v.get(kk) for kk in ("ms_per_step", "frac", "kernel_ms", "oracle")})
-print("line bytes", len(open("$O/r06_v_bench_line.json").read()))
+print("line bytes", len(open("$O/r06_${VT:-v}_bench_line.json").read()))
 PY
-  TAG=r06_v PASSES="sq" BENCH_ARGS="--config-legs 0 --structured-c3-rows 0" bash scripts/gpu_profile_i8.sh 2>&1 | tail -3
-  grep -v "^#   " $O/prof/r06_v_i8_pmc_sq_summary.txt > $O/r06_v_i8_pmc_sq_summary.txt
-  grep "Lb0ELb1ELb0ELb0E" $O/r06_v_i8_pmc_sq_summary.txt | cut -c1-150
+  TAG=r06_${VT:-v} PASSES="sq" BENCH_ARGS="--config-legs 0 --structured-c3-rows 0" bash scripts/gpu_profile_i8.sh 2>&1 | tail -3
+  grep -v "^#   " $O/prof/r06_${VT:-v}_i8_pmc_sq_summary.txt > $O/r06_${VT:-v}_i8_pmc_sq_summary.txt
+  grep "Lb0ELb1ELb0ELb0E" $O/r06_${VT:-v}_i8_pmc_sq_summary.txt | cut -c1-150
   find $O/prof -name "*.db" -size +4M -delete
   ;;
 *) echo "unknown session $S"; exit 2;;
