@@ -155,6 +155,7 @@ static int create_one(Engine& E, const std::string& nm, uint32_t dims, int metri
     HIP_TRY(hipMalloc((void**)&s->dMaxSumsq, sizeof(float)));
     HIP_TRY(hipMemset(s->dMaxSumsq, 0, sizeof(float)));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventCreate(&s->ev_end));
     for (auto& pr : s->ring)
       for (auto& e : pr) HIP_TRY(hipEventCreate(&e));
     uint64_t cap0 = s->params.initial_capacity ? s->params.initial_capacity : 128;  // index.h:21
@@ -692,8 +693,17 @@ int ehx_stats(ehx_space* s, ehx_stats_t* out) {
     if (s->ev_valid) {
       HIP_TRY(hipEventSynchronize(s->ev[3]));
       newest = s->ev_seq;
-      if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) out->last_scan_ms = ms;
-      if (hipEventElapsedTime(&ms, s->ev[0], s->ev[3]) == hipSuccess) out->last_total_ms = ms;
+      if (s->end_sampled) {   // graph search: the last TIMED batch (batch 0 and every EHX_STATS_EVERY-th)
+        if (s->g_timed_valid) {
+          HIP_TRY(hipEventSynchronize(s->ev_end));
+          if (s->scan_ev[0] && s->scan_ev[1] && hipEventElapsedTime(&ms, s->scan_ev[0], s->scan_ev[1]) == hipSuccess)
+            out->last_scan_ms = ms;
+          if (hipEventElapsedTime(&ms, s->ev[0], s->ev_end) == hipSuccess) out->last_total_ms = ms;
+        }
+      } else {
+        if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) out->last_scan_ms = ms;
+        if (hipEventElapsedTime(&ms, s->ev[0], s->ev[3]) == hipSuccess) out->last_total_ms = ms;
+      }
       const uint64_t m = s->ring_count < (uint64_t)ehx_space::kRing ? s->ring_count : (uint64_t)ehx_space::kRing;
       for (uint64_t i = 0; i < m; ++i)
         if (hipEventElapsedTime(&ms, s->ring[i][0], s->ring[i][1]) == hipSuccess) {
@@ -778,6 +788,7 @@ int ehx_stats_reset(ehx_space* s) {
   s->n_i8_queries = 0;
   s->n_i8_fallback = 0;
   s->ring_count = 0;
+  s->g_batches = 0;   // (the next graph batch is a timed one)
   for (auto& c : s->i8set) {
     std::lock_guard<std::mutex> cl(c.mu);
     c.ring_count = 0;

@@ -231,6 +231,7 @@ int flat_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_queries, u
   HIP_TRY(launch_rerank(r, st));
   HIP_TRY(hipEventRecord(s->ev[3], st));
   s->ev3_stream = st;
+  s->end_sampled = false;
   s->ev_valid = true;
   s->ev_seq = ++s->ev_counter;
   if (count_stats) {
@@ -592,6 +593,7 @@ int exhaustive_pass(ehx_space* s, hipStream_t st, size_t nq, const float* d_quer
   }
   HIP_TRY(hipEventRecord(s->ev[3], st));
   s->ev3_stream = st;
+  s->end_sampled = false;
   s->ev_valid = true;
   s->ev_seq = ++s->ev_counter;
   s->n_dist += (uint64_t)nq * s->n * pages;
@@ -726,6 +728,7 @@ int knn_device_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_qu
       HIP_TRY(launch_scatter_results(oi, od, oc, s->dFbIdx.p, (uint32_t)m, k, d_ids, d_dist, d_count, st));
       HIP_TRY(hipEventRecord(s->ev[3], st));
       s->ev3_stream = st;
+  s->end_sampled = false;
     }
     // verdict
     unc->clear();

@@ -417,8 +417,12 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
     int rcw = wait_searches_in_flight(s, st);
     if (rcw) return rcw;
   }
+  // timing events: batch 0 after a reset (outside the ring's mean) and every EHX_STATS_EVERY-th batch (ehx_internal.h)
+  const uint64_t batch_no = one ? 0 : s->g_batches++;
+  const bool in_ring = !one && (batch_no % env().stats_every) == env().stats_every - 1u;
+  const bool timed = !one && (in_ring || batch_no == 0);
   if (!one) {
-    HIP_TRY(hipEventRecord(s->ev[0], st));
+    if (timed) HIP_TRY(hipEventRecord(s->ev[0], st));
     HIP_TRY(launch_prep_queries(d_queries, (uint32_t)nq, s->dims, s->ld, q_rows, s->metric, s->dQ.p, st));
   }
   GraphArgs a;
@@ -469,9 +473,11 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
     s->n_queries += nq;
     return EHX_OK;
   }
-  hipEvent_t* pr = s->ring[s->ring_count % ehx_space::kRing];
-  HIP_TRY(hipEventRecord(s->ev[1], st));
-  HIP_TRY(hipEventRecord(pr[0], st));
+  hipEvent_t* pr = in_ring ? s->ring[s->ring_count % ehx_space::kRing] : &s->ev[1];   // (batch 0: ev[1] / ev[2])
+  if (timed) {
+    s->g_timed_valid = false;
+    HIP_TRY(hipEventRecord(pr[0], st));
+  }
   // (inside the timed kernel region: clearing the bitmaps is part of what a batch costs, log or memset)
   if (log_now && s->vis_dirty)  // (the whole buffer: an earlier, larger batch may have marked words beyond this one's)
     HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, s->dVisited.n * sizeof(uint32_t), st));
@@ -479,11 +485,19 @@ int knn_graph_locked(ehx_space* s, hipStream_t st, size_t nq, const float* d_que
     HIP_TRY(hipMemsetAsync(s->dVisited.p, 0, (size_t)nq * vis_words * sizeof(uint32_t), st));
   s->vis_dirty = !log_now;
   HIP_TRY(launch_graph_search(a, st));
-  HIP_TRY(hipEventRecord(pr[1], st));
-  HIP_TRY(hipEventRecord(s->ev[2], st));
-  s->ring_count++;
+  if (timed) {
+    HIP_TRY(hipEventRecord(pr[1], st));
+    s->scan_ev[0] = pr[0];
+    s->scan_ev[1] = pr[1];
+    if (in_ring) s->ring_count++;
+  }
   HIP_TRY(hipEventRecord(s->ev[3], st));
   s->ev3_stream = st;
+  s->end_sampled = true;
+  if (timed) {
+    HIP_TRY(hipEventRecord(s->ev_end, st));
+    s->g_timed_valid = true;
+  }
   s->ev_valid = true;
   s->ev_seq = ++s->ev_counter;
   s->n_queries += nq;

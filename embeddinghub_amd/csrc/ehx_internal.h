@@ -376,6 +376,14 @@ struct ehx_space {
   size_t hStageBytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t ev3_stream = nullptr;   // the stream ev[3] was last recorded on
+  // graph search (round 6): timing events on batch 0 and on every EHX_STATS_EVERY-th batch only — six event records per batch
+  // idled the queue ~36 us of a 0.35-ms batch.  scan_ev: the timed batch's scan window (a ring pair, or ev[1] / ev[2] for
+  // batch 0, which stays out of the ring); ev_end: recorded behind ev[3] on timed batches; end_sampled: the last batch was
+  // a graph search (the other engines record ev[0..3] on every batch and clear it)
+  hipEvent_t scan_ev[2] = {nullptr, nullptr};
+  hipEvent_t ev_end = nullptr;
+  bool end_sampled = false, g_timed_valid = false;
+  uint64_t g_batches = 0;
   std::atomic<bool> ev_valid{false};
   uint64_t ev_seq = 0;
   // ring of (start, stop) event pairs around the scan kernel: per-launch durations for the roofline
@@ -553,6 +561,8 @@ struct ehx_space {
     stream = nullptr;
     if (wstream) (void)hipStreamDestroy(wstream);
     wstream = nullptr;
+    if (ev_end) (void)hipEventDestroy(ev_end);
+    ev_end = nullptr;
     if (wev) (void)hipEventDestroy(wev);
     wev = nullptr;
     for (auto& e : sev) {
