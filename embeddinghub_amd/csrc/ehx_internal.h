@@ -222,7 +222,14 @@ struct ehx_space {
                              // copy's block order, RAW; dXs is the same pointer; cosine rows are scaled by inv_norm on
                              // the fly in the kernels (GraphArgs / InsertArgs .xscale); Get undoes the permutation
   DevBuf<uint64_t> dPermIds; // rows of a batch written in place (non-contiguous ids), for launch_permute_blocks
-  uint64_t cap = 0, n = 0;
+  uint64_t cap = 0;
+  // published row count.  Atomic (round 6): an appending Set publishes its rows with ONE release store under the space's lock
+  // held SHARED — rows below the new count are resident and described before the store, the arrays do not move while any search
+  // holds the lock shared — where it used to take the lock exclusively "for the length of one store": glibc's rwlock prefers
+  // readers, two pipelined search callers overlap without a gap, and the writer waited ~4 batches per chunk (12.5 M x 1536
+  // under search: 63 ms per 8192-row chunk against 3 un-contended).  A search may read the count more than once; every use
+  // tolerates a later, larger value (more rows valid than tiles scanned: "a search sees a prefix of the completed Sets").
+  std::atomic<uint64_t> n{0};
   // fp16-MFMA filter scan (k_flat16.hip): unit-normalised binary16 scan copy of the rows
   bool has16 = false;          // the space keeps the fp16 scan copy (maintained on every write, whatever use16 says)
   bool use16 = false;          // ... and scans with the fp16 filter right now (ehx_space_set_scan switches it)
